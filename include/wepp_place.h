@@ -1,0 +1,202 @@
+/*
+ * wepp_place.h -- C-ABI of the MI355X read-placement engine.
+ *
+ * Drop-in boundary for the reference's per-sample node loop.  The reference
+ * (TurakhiaLab/WEPP, vendored UShER sources) has no FFI layer; its seam is the
+ * C++ call
+ *     void mapper2_body(mapper2_input&, bool, bool)          src/usher_graph.hpp:104
+ * invoked from the tbb::parallel_for bodies of
+ *     int usher_common(...)                                  src/usher_common.hpp:18-22
+ *                                                            src/usher_common.cpp:386-411 (pass 1)
+ *                                                            src/usher_common.cpp:413-446 (pass 2)
+ * This library replaces BOTH passes for a whole batch of samples/reads with one
+ * call (wepp_place_batch); INTEGRATION.md shows the few lines a maintainer adds
+ * to usher_common.cpp to bind it.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every host buffer;
+ *  - every function returns 0 on success or a WEPP_E* code; the message is
+ *    available from wepp_last_error() (thread-local).  Nothing here calls
+ *    exit() or throws across the boundary (the reference's MAT layer exit(1)s,
+ *    src/mutation_annotated_tree.cpp:474,514,533);
+ *  - nucleotides are the reference's 4-bit one-hot/IUPAC masks A=1 C=2 G=4 T=8,
+ *    N=15 (src/mutation_annotated_tree.cpp:19-74);
+ *  - a handle is bound to one device and is not re-entrant; different handles
+ *    may be used concurrently from different host threads (one per GPU).
+ */
+#ifndef WEPP_PLACE_H
+#define WEPP_PLACE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WEPP_OK          0
+#define WEPP_EINVAL      1   /* malformed argument / precondition violated      */
+#define WEPP_ENOMEM      2   /* host or device allocation failed                */
+#define WEPP_EDEVICE     3   /* HIP runtime error (no device, launch failure..) */
+#define WEPP_ELIMIT      4   /* input exceeds a documented limit                */
+
+/* ---- packed 32-bit words ---------------------------------------------- *
+ * Sample/read entry = one element of Missing_Sample::mutations
+ * (src/usher_graph.hpp:34-54, filled by src/mutation_annotated_tree.cpp:2086-2127):
+ *     bits  0..19  position (0 .. 2^20-1)
+ *     bits 20..23  ref_nuc mask
+ *     bits 24..27  mut_nuc mask (15 for N)
+ *     bit  28      is_missing
+ */
+#define WEPP_MAX_POSITION 0xFFFFFu
+static inline uint32_t wepp_pack_read_word(uint32_t position, uint32_t ref_nuc, uint32_t mut_nuc,
+                                           uint32_t is_missing) {
+    return (position & 0xFFFFFu) | ((ref_nuc & 15u) << 20) | ((mut_nuc & 15u) << 24) |
+           ((is_missing & 1u) << 28);
+}
+
+/* ---- the tree as the caller hands it over ------------------------------ *
+ * A pointer-free description of MAT::Tree (src/mutation_annotated_tree.hpp:80-152):
+ * node ids 0..n_nodes-1 in any order, parent[i] = id of the parent or -1 for
+ * the single root; the children of a node are ordered by ascending id (the
+ * order Tree::create_node pushes them, src/mutation_annotated_tree.cpp:865-878).
+ * Node i owns mutations mut_*[mut_off[i] .. mut_off[i+1]), sorted by position
+ * (the loader guarantees it, src/mutation_annotated_tree.cpp:591-594);
+ * mut_pos < 0 = masked mutation (src/mutation_annotated_tree.hpp:68-70).
+ * mut_par (Mutation::par_nuc) may be NULL: the scorer never reads it
+ * (src/usher_mapper.cpp:168-506 only copies it), the flattener recomputes the
+ * true parent allele. */
+typedef struct {
+    uint32_t n_nodes;
+    const int32_t *parent;     /* [n_nodes]                */
+    const uint32_t *mut_off;   /* [n_nodes + 1]            */
+    const int32_t *mut_pos;    /* [mut_off[n_nodes]]       */
+    const uint8_t *mut_ref;    /* ref_nuc masks            */
+    const uint8_t *mut_par;    /* par_nuc masks or NULL    */
+    const uint8_t *mut_mut;    /* mut_nuc masks            */
+} wepp_tree_desc;
+
+typedef struct wepp_mat wepp_mat_t;   /* flattened MAT resident in one GPU's HBM */
+
+typedef struct {
+    uint64_t n_nodes;          /* N                                             */
+    uint64_t n_mutations;      /* M: non-masked mutation words                  */
+    uint64_t n_masked;         /* masked mutations (kept as node flags only)    */
+    uint64_t n_events;         /* E: enter + exit events of the sweep stream    */
+    uint64_t n_blocks;         /* sweep blocks (<=64 nodes, <=128 events each)  */
+    uint64_t n_leaves;
+    uint32_t max_depth;        /* root = 0                                      */
+    uint32_t max_position;     /* largest mutated position                      */
+    uint64_t stream_bytes;     /* bytes one sweep of the event stream reads     */
+    uint64_t device_bytes;     /* total HBM held by the handle                  */
+} wepp_mat_stats;
+
+/* Per-read result flags (out parameter `flags`). */
+#define WEPP_FLAG_HAS_UNIQUE 1u  /* best_node_has_unique, src/usher_common.cpp:374,401 */
+
+/* Build the flat MAT from `tree` and upload it to HIP device `device`.
+ * Replaces: MAT::Tree::breadth_first_expansion() per sample
+ * (src/usher_common.cpp:339), Tree::get_num_leaves() per tie
+ * (src/usher_mapper.cpp:465) and the ancestor walk of every mapper2_body call
+ * (src/usher_mapper.cpp:276-287) by a one-time precomputation. */
+int wepp_mat_create(const wepp_tree_desc *tree, int device, wepp_mat_t **out);
+int wepp_mat_destroy(wepp_mat_t *mat);
+int wepp_mat_get_stats(const wepp_mat_t *mat, wepp_mat_stats *out);
+/* bfs_ids[k] = caller node id of bfs[k] (breadth_first_expansion order,
+ * src/mutation_annotated_tree.cpp:1115-1141); buffer of n_nodes entries. */
+int wepp_mat_bfs_order(const wepp_mat_t *mat, uint32_t *bfs_ids);
+
+/* Place a batch of samples/reads: for read r with entries
+ * read_word[read_off[r] .. read_off[r+1]) (sorted by position, positions
+ * unique -- the precondition of the merge at src/usher_mapper.cpp:205-243)
+ * compute what the two passes at src/usher_common.cpp:386-446 leave in
+ *     best_j               -> best_bfs_j[r]   (index into the BFS order)
+ *     best_set_difference  -> score[r]
+ *     num_best             -> num_best[r]
+ *     best_node_has_unique -> flags[r] & WEPP_FLAG_HAS_UNIQUE
+ * Host buffers in, host buffers out (H2D / D2H inside).  Any output pointer
+ * may be NULL.  per_node_scores, when non-NULL, receives n_reads * n_nodes
+ * int32 values: the -p mode's node_set_difference[k] in BFS order
+ * (src/usher_common.cpp:403-409, +1 for ineligible nodes src/usher_mapper.cpp:500-505). */
+int wepp_place_batch(wepp_mat_t *mat, const uint32_t *read_off, const uint32_t *read_word,
+                     uint32_t n_reads, uint32_t *best_bfs_j, int32_t *score, uint32_t *num_best,
+                     uint32_t *flags, int32_t *per_node_scores);
+
+/* Same computation with every buffer already resident on the handle's device
+ * (device pointers); work is enqueued on `hip_stream` (a hipStream_t, NULL =
+ * the default stream) and NOT synchronised on return.  n_read_words =
+ * read_off[n_reads].  Used when the caller keeps reads in HBM. */
+int wepp_place_batch_device(wepp_mat_t *mat, const uint32_t *d_read_off, const uint32_t *d_read_word,
+                            uint32_t n_reads, uint64_t n_read_words, uint32_t *d_best_bfs_j,
+                            int32_t *d_score, uint32_t *d_num_best, uint32_t *d_flags,
+                            void *hip_stream);
+
+/* Tuning knob: reads that share one sweep of the event stream (1..64,
+ * default 64).  Affects speed only, never results. */
+int wepp_mat_set_tile_reads(wepp_mat_t *mat, uint32_t reads_per_tile);
+
+/* Timing of the dominant kernel of the most recent wepp_place_batch_device /
+ * wepp_place_batch call, measured with HIP events on the launch stream
+ * (blocks until that work has finished).  sweep_ms = the sweep kernel only;
+ * passes = event-stream sweeps it performed (tiles x 1). */
+int wepp_mat_last_timing(wepp_mat_t *mat, float *sweep_ms, uint64_t *passes, uint64_t *bytes_per_pass);
+
+const char *wepp_last_error(void);
+
+/* ---- synthetic workload generators (host only; no GPU needed) ---------- *
+ * The reference bundles no MAT or reads; every config is
+ * generated deterministically from seeds with a splitmix64 PRNG. */
+typedef struct wepp_gen_tree wepp_gen_tree_t;
+typedef struct wepp_gen_reads wepp_gen_reads_t;
+
+typedef struct {
+    uint64_t seed;
+    uint32_t n_nodes;
+    uint32_t genome_len;        /* positions 1..genome_len                      */
+    double   p_recent_parent;   /* prob. parent is one of the last 8 nodes      */
+    double   zipf_s;            /* site-weight exponent (homoplasy skew)        */
+    double   p_back_mutation;   /* prob. a mutation at a non-ref site reverts   */
+    double   p_ambiguous;       /* prob. a node mutation gets a 2-bit mut_nuc   */
+    double   p_masked_node;     /* prob. a non-root node gets a masked mutation */
+    uint32_t root_mutations;    /* mutations placed on the root                 */
+} wepp_gen_tree_params;
+
+typedef struct {
+    uint64_t seed;
+    uint32_t n_reads;
+    uint32_t read_len;          /* 150 (ARTIC) or ~1200 (midnight)              */
+    uint32_t amplicon_len;      /* 400 (ARTIC-like) or 1200 (midnight-like)     */
+    uint32_t amplicon_step;     /* tiling step between amplicon starts          */
+    double   p_substitution;    /* per-base sequencing error                    */
+    double   p_n;               /* per-base N                                   */
+    double   p_iupac;           /* prob. an error is an ambiguity code instead  */
+} wepp_gen_reads_params;
+
+int wepp_gen_tree_create(const wepp_gen_tree_params *p, wepp_gen_tree_t **out);
+int wepp_gen_tree_desc(const wepp_gen_tree_t *t, wepp_tree_desc *out);  /* borrowed pointers */
+int wepp_gen_tree_destroy(wepp_gen_tree_t *t);
+
+int wepp_gen_reads_create(const wepp_gen_tree_t *t, const wepp_gen_reads_params *p, wepp_gen_reads_t **out);
+/* borrowed pointers: read_off[n_reads+1], read_word[read_off[n_reads]] */
+int wepp_gen_reads_get(const wepp_gen_reads_t *r, uint32_t *n_reads, const uint32_t **read_off,
+                       const uint32_t **read_word);
+int wepp_gen_reads_destroy(wepp_gen_reads_t *r);
+
+/* ---- host-side introspection of the flattened MAT (no GPU needed) -------- *
+ * Lets the CPU test-suite check the flattener (orders, parent alleles, per-node
+ * constants, event stream) against the oracle.  `name` is one of: node_woff,
+ * words, nkey, nstat, rank2dfs, dfs2bfs, bfs2id, dfs2id, parent_dfs, dfs_end,
+ * num_leaves, blk_node0, blk_eoff, blk_sum, ev_word, ev_meta, cp_off, cp_word.
+ * The returned pointer is borrowed from the handle; *elem_bytes is the element
+ * size and *count the number of elements. */
+typedef struct wepp_flat wepp_flat_t;
+int wepp_flat_create(const wepp_tree_desc *tree, wepp_flat_t **out);
+int wepp_flat_get(const wepp_flat_t *flat, const char *name, const void **data, uint64_t *count,
+                  uint32_t *elem_bytes);
+int wepp_flat_scalars(const wepp_flat_t *flat, wepp_mat_stats *stats, uint32_t *cp_stride);
+int wepp_flat_destroy(wepp_flat_t *flat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEPP_PLACE_H */

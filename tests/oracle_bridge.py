@@ -1,0 +1,137 @@
+"""ctypes bridge to oracle/mapper2_oracle.c (the CPU restatement of the
+reference).  Test infrastructure: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg import this module.  The shared object is built
+on demand with gcc into oracle/_build/ (git-ignored)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "oracle", "mapper2_oracle.c")
+OUT_DIR = os.path.join(ROOT, "oracle", "_build")
+OUT = os.path.join(OUT_DIR, "liboracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < os.path.getmtime(SRC):
+        os.makedirs(OUT_DIR, exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-DNDEBUG", "-shared", "-fPIC", "-o", OUT, SRC, "-lpthread"])
+    return OUT
+
+
+class OracleResult(ctypes.Structure):
+    _fields_ = [
+        ("score", ctypes.c_int32),
+        ("num_best", ctypes.c_uint32),
+        ("best_j", ctypes.c_uint32),
+        ("best_node_id", ctypes.c_int32),
+        ("has_unique", ctypes.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.oracle_tree_build.restype = ctypes.c_void_p
+        L.oracle_tree_build.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6
+        L.oracle_tree_free.argtypes = [ctypes.c_void_p]
+        L.oracle_place_sample.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
+            ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(OracleResult), ctypes.c_void_p]
+        L.oracle_place_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
+        for f in ("oracle_tree_bfs_ids", "oracle_tree_dfs_ids", "oracle_tree_num_leaves"):
+            getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleTree:
+    """The reference's pointer tree rebuilt from a wepp_amd.Tree description."""
+
+    def __init__(self, tree):
+        L = lib()
+        self.n = tree.n_nodes
+        par = tree.mut_par if tree.mut_par is not None else tree.mut_ref
+        self._keep = (tree.parent, tree.mut_off, tree.mut_pos, tree.mut_ref, par, tree.mut_mut)
+        dummy = np.zeros(1, np.uint8)
+        m = int(tree.mut_off[-1])
+        self._h = L.oracle_tree_build(
+            self.n, _p(tree.parent), _p(tree.mut_off),
+            _p(tree.mut_pos if m else np.zeros(1, np.int32)), _p(tree.mut_ref if m else dummy),
+            _p(par if m else dummy), _p(tree.mut_mut if m else dummy))
+        if not self._h:
+            raise ValueError("oracle_tree_build rejected the tree")
+
+    def bfs_ids(self):
+        out = np.zeros(self.n, np.int32)
+        lib().oracle_tree_bfs_ids(self._h, _p(out))
+        return out
+
+    def dfs_ids(self):
+        out = np.zeros(self.n, np.int32)
+        lib().oracle_tree_dfs_ids(self._h, _p(out))
+        return out
+
+    def num_leaves(self):
+        out = np.zeros(self.n, np.int64)
+        lib().oracle_tree_num_leaves(self._h, _p(out))
+        return out
+
+    def place_sample(self, pos, ref, mut, missing, per_node_scores=False, want_best_vec=False):
+        """One Missing_Sample against every node (usher_common.cpp:339-446)."""
+        pos = np.ascontiguousarray(pos, np.int32)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        mut = np.ascontiguousarray(mut, np.uint8)
+        missing = np.ascontiguousarray(missing, np.uint8)
+        n = len(pos)
+        z32 = np.zeros(1, np.int32)
+        z8 = np.zeros(1, np.uint8)
+        res = OracleResult()
+        nsd = np.zeros(self.n, np.int32) if per_node_scores else None
+        bv = np.zeros(self.n, np.uint32) if want_best_vec else None
+        lib().oracle_place_sample(
+            self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8), _p(missing if n else z8),
+            1 if per_node_scores else 0, _p(nsd) if per_node_scores else None, ctypes.byref(res),
+            _p(bv) if want_best_vec else None)
+        out = dict(score=res.score, num_best=res.num_best, best_j=res.best_j, best_node_id=res.best_node_id,
+                   has_unique=res.has_unique)
+        if per_node_scores:
+            out["node_scores"] = nsd
+        if want_best_vec:
+            out["best_j_vec"] = np.sort(bv[: res.num_best])
+        return out
+
+    def place_batch(self, reads, nthreads=1):
+        """reads: wepp_amd.Reads.  Returns dict of arrays."""
+        from wepp_amd import unpack_read_word
+        R = reads.n_reads
+        pos, ref, mut, miss = unpack_read_word(reads.read_word)
+        if pos.size == 0:
+            pos = np.zeros(1, np.int32); ref = np.zeros(1, np.uint8); mut = np.zeros(1, np.uint8); miss = np.zeros(1, np.uint8)
+        res = (OracleResult * max(R, 1))()
+        lib().oracle_place_batch(self._h, R, _p(reads.read_off), _p(np.ascontiguousarray(pos)),
+                                 _p(np.ascontiguousarray(ref)), _p(np.ascontiguousarray(mut)),
+                                 _p(np.ascontiguousarray(miss)), ctypes.cast(res, ctypes.c_void_p), int(nthreads))
+        arr = np.frombuffer(res, dtype=np.dtype([("score", "<i4"), ("num_best", "<u4"), ("best_j", "<u4"),
+                                                 ("best_node_id", "<i4"), ("has_unique", "<u4")]), count=R).copy()
+        return arr
+
+    def close(self):
+        if self._h:
+            lib().oracle_tree_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

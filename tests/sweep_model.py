@@ -1,0 +1,180 @@
+"""Pure-Python model of the GPU sweep (wepp_amd/csrc/place_kernels.hip) over
+the flattened MAT, used by the CPU test-suite to check the flattener and the
+closed form against the oracle when no GPU is present.  It is NOT a product
+path (nothing in wepp_amd imports it) and it is only usable on small trees.
+"""
+import numpy as np
+
+INF = 0x7FFFFFFF
+SCORE_INF = 0x3FFFFFFF
+NS_CNT = 0x3FFF
+NS_LEAF, NS_MASKED, NS_ELIG0, NS_ROOT = 1 << 28, 1 << 29, 1 << 30, 1 << 31
+EV_EXIT, EV_LEAF = 64, 128
+
+
+def _tw(w):
+    w = int(w)
+    return w & 0xFFFFF, (w >> 20) & 15, (w >> 24) & 15, (w >> 28) & 15  # pos, ref, par, mut
+
+
+def f_state(x, tref, s):
+    _, sref, a, missing = s
+    c0 = 1 if (x != 0 and x != tref) else 0
+    cs = 0 if missing else (1 if (a & (x if x else sref)) == 0 else 0)
+    return cs - c0
+
+
+def enter_delta(w, s):
+    _, ref, par, mut = _tw(w)
+    return f_state(mut, ref, s) - f_state(par, ref, s)
+
+
+def own_adjust(w, s):
+    _, ref, par, mut = _tw(w)
+    _, sref, a, missing = s
+    static_common = 1 if mut == ref else 0
+    static_sub = (1 if (par != 0 and par != ref) else 0) if static_common else 0
+    if missing:
+        actual_common, actual_sub = 1, 0
+    else:
+        actual_common = 1 if (a & mut) != 0 else 0
+        actual_sub = (1 if (a & (par if par else sref)) == 0 else 0) if actual_common else 0
+    return static_sub - actual_sub, actual_common - static_common
+
+
+class FlatModel:
+    def __init__(self, flat):
+        self.f = flat
+        for name in ("node_woff", "words", "nkey", "nstat", "rank2dfs", "dfs2bfs", "blk_node0", "blk_eoff",
+                     "blk_sum", "ev_word", "ev_meta", "cp_off", "cp_word", "dfs2id", "bfs2id"):
+            setattr(self, name, flat.get(name))
+        self.NB = int(flat.stats.n_blocks)
+        self.N = int(flat.stats.n_nodes)
+        self.cp_stride = flat.cp_stride
+
+    def _c_none(self, S):
+        return sum(1 for (_, sref, a, missing) in S if not missing and (a & sref) == 0)
+
+    def chunk_start_c(self, S, b0):
+        """c at the first node of block b0 from the checkpoint words (b0 % cp_stride == 0)."""
+        Sd = {s[0]: s for s in S}
+        c = self._c_none(S)
+        cpi = b0 // self.cp_stride
+        for e in range(int(self.cp_off[cpi]), int(self.cp_off[cpi + 1])):
+            w = self.cp_word[e]
+            s = Sd.get(int(w) & 0xFFFFF)
+            if s is not None:
+                c += enter_delta(w, s)
+        return c
+
+    def place(self, S, b0=0, b1=None, c0=None, node_scores=None, trace_c=None):
+        """Sweep blocks [b0, b1) for one read S = [(pos, ref, mut, missing)].
+        Returns (best score, best rank, count, c at the end).  node_scores
+        (optional int array indexed by DFS idx) receives the -p mode value."""
+        Sd = {s[0]: s for s in S}
+        b1 = self.NB if b1 is None else b1
+        c = self.chunk_start_c(S, b0) if c0 is None else c0
+        bs, br, cnt = INF, 0xFFFFFFFF, 0
+        for b in range(b0, b1):
+            if trace_c is not None:
+                trace_c[b] = c
+            e0, e1 = int(self.blk_eoff[b]), int(self.blk_eoff[b + 1])
+            n0 = int(self.blk_node0[b])
+            nn = int(self.blk_node0[b + 1]) - n0
+            hits = [e for e in range(e0, e1) if (int(self.ev_word[e]) & 0xFFFFF) in Sd]
+            if not hits and node_scores is None:
+                base, rank, sc, _ = (int(x) for x in self.blk_sum[b])
+                if base != SCORE_INF:
+                    s = base + c
+                    if s < bs:
+                        bs, br, cnt = s, rank, sc
+                    elif s == bs:
+                        cnt += sc
+                        br = min(br, rank)
+                continue
+            cadd = [0] * nn
+            adj = [0] * nn
+            dcom = [0] * nn
+            touched = [False] * nn
+            net = 0
+            for e in hits:
+                w = self.ev_word[e]
+                mt = int(self.ev_meta[e])
+                s = Sd[int(w) & 0xFFFFF]
+                d = enter_delta(w, s)
+                o = mt & 63
+                if mt & EV_EXIT:
+                    for i in range(o, nn):
+                        cadd[i] -= d
+                    net -= d
+                else:
+                    if not (mt & EV_LEAF):
+                        is_root = (n0 + o) == 0
+                        for i in range(o if is_root else o + 1, nn):
+                            cadd[i] += d
+                        net += d
+                    touched[o] = True
+                    a, dc = own_adjust(w, s)
+                    adj[o] += a
+                    dcom[o] += dc
+            for i in range(nn):
+                key = int(self.nkey[n0 + i])
+                st = int(self.nstat[n0 + i])
+                base, rank = key >> 32, key & 0xFFFFFFFF
+                nmut, ncom0 = st & NS_CNT, (st >> 14) & NS_CNT
+                leaf, masked, root = bool(st & NS_LEAF), bool(st & NS_MASKED), bool(st & NS_ROOT)
+                score = base + c + cadd[i]
+                if root:
+                    elig = True
+                elif masked:
+                    elig = False
+                elif touched[i]:
+                    score += adj[i]
+                    ncom = ncom0 + dcom[i]
+                    elig = (ncom > 0) if leaf else (ncom > 0 or ncom == nmut)
+                else:
+                    elig = bool(st & NS_ELIG0)
+                if node_scores is not None:
+                    node_scores[n0 + i] = score if elig else score + 1   # usher_mapper.cpp:500-505
+                if elig:
+                    if score < bs:
+                        bs, br, cnt = score, rank, 1
+                    elif score == bs:
+                        cnt += 1
+                        br = min(br, rank)
+            c += net
+        return bs, br, cnt, c
+
+    def has_unique(self, S, rank):
+        d = int(self.rank2dfs[rank])
+        st = int(self.nstat[d])
+        if st & NS_ROOT:
+            return 0
+        if st & NS_MASKED:
+            return 1
+        Sd = {s[0]: s for s in S}
+        ncom = (st >> 14) & NS_CNT
+        for w in range(int(self.node_woff[d]), int(self.node_woff[d + 1])):
+            s = Sd.get(int(self.words[w]) & 0xFFFFF)
+            if s is not None:
+                ncom += own_adjust(self.words[w], s)[1]
+        return 1 if ncom < (st & NS_CNT) else 0
+
+    def place_full(self, S, nchunks=1):
+        """Whole placement the way the kernels do it: chunks + finalize."""
+        ncp = len(self.cp_off) - 1
+        nchunks = max(1, min(nchunks, ncp))
+        cps = (ncp + nchunks - 1) // nchunks
+        bpc = cps * self.cp_stride
+        bs, br, cnt = INF, 0xFFFFFFFF, 0
+        b = 0
+        while b < self.NB:
+            s, r, c_, _ = self.place(S, b, min(self.NB, b + bpc))
+            if s < bs:
+                bs, br, cnt = s, r, c_
+            elif s == bs:
+                cnt += c_
+                br = min(br, r)
+            b += bpc
+        d = int(self.rank2dfs[br])
+        return dict(score=bs, num_best=cnt, best_j=int(self.dfs2bfs[d]), has_unique=self.has_unique(S, br))

@@ -1,0 +1,133 @@
+"""ctypes loader for libwepp_place.so (the C-ABI of include/wepp_place.h).
+
+There is no Python or CPU fallback: if the shared library has not been built
+(`make -C wepp_amd/csrc`, or `__graft_entry__.build()`), importing this module
+raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwepp_place.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first "
+        "(make -C wepp_amd/csrc, or python -c 'import __graft_entry__ as g; g.build()'). "
+        "wepp_amd has no CPU fallback."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class TreeDescC(ctypes.Structure):
+    _fields_ = [
+        ("n_nodes", ctypes.c_uint32),
+        ("parent", c_i32p),
+        ("mut_off", c_u32p),
+        ("mut_pos", c_i32p),
+        ("mut_ref", c_u8p),
+        ("mut_par", c_u8p),
+        ("mut_mut", c_u8p),
+    ]
+
+
+class MatStats(ctypes.Structure):
+    _fields_ = [
+        ("n_nodes", ctypes.c_uint64),
+        ("n_mutations", ctypes.c_uint64),
+        ("n_masked", ctypes.c_uint64),
+        ("n_events", ctypes.c_uint64),
+        ("n_blocks", ctypes.c_uint64),
+        ("n_leaves", ctypes.c_uint64),
+        ("max_depth", ctypes.c_uint32),
+        ("max_position", ctypes.c_uint32),
+        ("stream_bytes", ctypes.c_uint64),
+        ("device_bytes", ctypes.c_uint64),
+    ]
+
+
+class GenTreeParams(ctypes.Structure):
+    _fields_ = [
+        ("seed", ctypes.c_uint64),
+        ("n_nodes", ctypes.c_uint32),
+        ("genome_len", ctypes.c_uint32),
+        ("p_recent_parent", ctypes.c_double),
+        ("zipf_s", ctypes.c_double),
+        ("p_back_mutation", ctypes.c_double),
+        ("p_ambiguous", ctypes.c_double),
+        ("p_masked_node", ctypes.c_double),
+        ("root_mutations", ctypes.c_uint32),
+    ]
+
+
+class GenReadsParams(ctypes.Structure):
+    _fields_ = [
+        ("seed", ctypes.c_uint64),
+        ("n_reads", ctypes.c_uint32),
+        ("read_len", ctypes.c_uint32),
+        ("amplicon_len", ctypes.c_uint32),
+        ("amplicon_step", ctypes.c_uint32),
+        ("p_substitution", ctypes.c_double),
+        ("p_n", ctypes.c_double),
+        ("p_iupac", ctypes.c_double),
+    ]
+
+
+# every symbol include/wepp_place.h declares (tests/test_abi.py checks the list
+# against the header)
+_V = ctypes.c_void_p
+_SIGS = {
+    "wepp_mat_create": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.c_int, ctypes.POINTER(_V)]),
+    "wepp_mat_destroy": (ctypes.c_int, [_V]),
+    "wepp_mat_get_stats": (ctypes.c_int, [_V, ctypes.POINTER(MatStats)]),
+    "wepp_mat_bfs_order": (ctypes.c_int, [_V, _V]),
+    "wepp_place_batch": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, _V, _V, _V, _V, _V]),
+    "wepp_place_batch_device": (
+        ctypes.c_int,
+        [_V, _V, _V, ctypes.c_uint32, ctypes.c_uint64, _V, _V, _V, _V, _V],
+    ),
+    "wepp_mat_set_tile_reads": (ctypes.c_int, [_V, ctypes.c_uint32]),
+    "wepp_mat_last_timing": (
+        ctypes.c_int,
+        [_V, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
+    ),
+    "wepp_last_error": (ctypes.c_char_p, []),
+    "wepp_gen_tree_create": (ctypes.c_int, [ctypes.POINTER(GenTreeParams), ctypes.POINTER(_V)]),
+    "wepp_gen_tree_desc": (ctypes.c_int, [_V, ctypes.POINTER(TreeDescC)]),
+    "wepp_gen_tree_destroy": (ctypes.c_int, [_V]),
+    "wepp_gen_reads_create": (ctypes.c_int, [_V, ctypes.POINTER(GenReadsParams), ctypes.POINTER(_V)]),
+    "wepp_gen_reads_get": (
+        ctypes.c_int,
+        [_V, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(c_u32p), ctypes.POINTER(c_u32p)],
+    ),
+    "wepp_gen_reads_destroy": (ctypes.c_int, [_V]),
+    "wepp_flat_create": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.POINTER(_V)]),
+    "wepp_flat_get": (
+        ctypes.c_int,
+        [_V, ctypes.c_char_p, ctypes.POINTER(_V), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)],
+    ),
+    "wepp_flat_scalars": (ctypes.c_int, [_V, ctypes.POINTER(MatStats), ctypes.POINTER(ctypes.c_uint32)]),
+    "wepp_flat_destroy": (ctypes.c_int, [_V]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so is stale
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = sorted(_SIGS)
+
+
+class WeppError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"wepp error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise WeppError(rc, lib.wepp_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,288 @@
+"""Host-side Python mirror of the C-ABI (thin: numpy arrays in, numpy arrays out).
+
+Names follow the reference's domain: a *tree* is a mutation-annotated tree
+(MAT::Tree, src/mutation_annotated_tree.hpp:104-152), a *read* / *sample* is a
+Missing_Sample (src/usher_graph.hpp:34-54), *placing* is the per-sample loop
+of usher_common (src/usher_common.cpp:307-470).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+A, C, G, T, N = 1, 2, 4, 8, 15  # nucleotide masks, src/mutation_annotated_tree.cpp:19-74
+
+
+def pack_read_word(position, ref_nuc, mut_nuc, is_missing=0):
+    """numpy-friendly twin of wepp_pack_read_word (include/wepp_place.h)."""
+    position = np.asarray(position, dtype=np.uint32)
+    return (
+        (position & np.uint32(0xFFFFF))
+        | ((np.asarray(ref_nuc, dtype=np.uint32) & np.uint32(15)) << np.uint32(20))
+        | ((np.asarray(mut_nuc, dtype=np.uint32) & np.uint32(15)) << np.uint32(24))
+        | ((np.asarray(is_missing, dtype=np.uint32) & np.uint32(1)) << np.uint32(28))
+    ).astype(np.uint32)
+
+
+def unpack_read_word(w):
+    w = np.asarray(w, dtype=np.uint32)
+    return (
+        (w & 0xFFFFF).astype(np.int32),
+        ((w >> 20) & 15).astype(np.uint8),
+        ((w >> 24) & 15).astype(np.uint8),
+        ((w >> 28) & 1).astype(np.uint8),
+    )
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Tree:
+    """Pointer-free description of a MAT (see wepp_tree_desc in include/wepp_place.h)."""
+
+    def __init__(self, parent, mut_off, mut_pos, mut_ref, mut_mut, mut_par=None):
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32)
+        self.mut_off = np.ascontiguousarray(mut_off, dtype=np.uint32)
+        self.mut_pos = np.ascontiguousarray(mut_pos, dtype=np.int32)
+        self.mut_ref = np.ascontiguousarray(mut_ref, dtype=np.uint8)
+        self.mut_mut = np.ascontiguousarray(mut_mut, dtype=np.uint8)
+        self.mut_par = None if mut_par is None else np.ascontiguousarray(mut_par, dtype=np.uint8)
+        if self.mut_off.shape[0] != self.parent.shape[0] + 1:
+            raise ValueError("mut_off must have n_nodes + 1 entries")
+
+    @property
+    def n_nodes(self):
+        return int(self.parent.shape[0])
+
+    @classmethod
+    def from_lists(cls, parent, muts):
+        """muts[i] = list of (position, ref_nuc, mut_nuc) or (position, ref, par, mut)."""
+        off = np.zeros(len(parent) + 1, dtype=np.uint32)
+        pos, ref, par, mut = [], [], [], []
+        for i, ml in enumerate(muts):
+            off[i + 1] = off[i] + len(ml)
+            for m in ml:
+                if len(m) == 3:
+                    p, r, mu = m
+                    pa = r
+                else:
+                    p, r, pa, mu = m
+                pos.append(p); ref.append(r); par.append(pa); mut.append(mu)
+        return cls(parent, off, np.array(pos, np.int32), np.array(ref, np.uint8), np.array(mut, np.uint8),
+                   np.array(par, np.uint8))
+
+    def desc(self):
+        d = _lib.TreeDescC()
+        d.n_nodes = self.n_nodes
+        d.parent = self.parent.ctypes.data_as(_lib.c_i32p)
+        d.mut_off = self.mut_off.ctypes.data_as(_lib.c_u32p)
+        d.mut_pos = self.mut_pos.ctypes.data_as(_lib.c_i32p)
+        d.mut_ref = self.mut_ref.ctypes.data_as(_lib.c_u8p)
+        d.mut_par = self.mut_par.ctypes.data_as(_lib.c_u8p) if self.mut_par is not None else None
+        d.mut_mut = self.mut_mut.ctypes.data_as(_lib.c_u8p)
+        return d
+
+
+class Reads:
+    """A batch of samples/reads in CSR form: read_off[R+1], read_word[...]."""
+
+    def __init__(self, read_off, read_word):
+        self.read_off = np.ascontiguousarray(read_off, dtype=np.uint32)
+        self.read_word = np.ascontiguousarray(read_word, dtype=np.uint32)
+
+    @property
+    def n_reads(self):
+        return int(self.read_off.shape[0] - 1)
+
+    @classmethod
+    def from_lists(cls, reads):
+        """reads[r] = list of (position, ref_nuc, mut_nuc[, is_missing])."""
+        off = np.zeros(len(reads) + 1, dtype=np.uint32)
+        words = []
+        for r, ents in enumerate(reads):
+            off[r + 1] = off[r] + len(ents)
+            for e in ents:
+                miss = e[3] if len(e) > 3 else 0
+                words.append(int(pack_read_word(e[0], e[1], e[2], miss)))
+        return cls(off, np.array(words, dtype=np.uint32))
+
+    def slice(self, lo, hi):
+        a, b = int(self.read_off[lo]), int(self.read_off[hi])
+        return Reads(self.read_off[lo:hi + 1] - self.read_off[lo], self.read_word[a:b])
+
+    def entries(self, r):
+        a, b = int(self.read_off[r]), int(self.read_off[r + 1])
+        return unpack_read_word(self.read_word[a:b])
+
+
+def generate_tree(seed, n_nodes, genome_len=29903, p_recent_parent=0.25, zipf_s=0.6, p_back_mutation=0.02,
+                  p_ambiguous=0.0, p_masked_node=0.0, root_mutations=0):
+    """Deterministic synthetic MAT (wepp_gen_tree_create); returns (Tree, handle)."""
+    p = _lib.GenTreeParams(seed, n_nodes, genome_len, p_recent_parent, zipf_s, p_back_mutation, p_ambiguous,
+                           p_masked_node, root_mutations)
+    h = ctypes.c_void_p()
+    check(lib.wepp_gen_tree_create(ctypes.byref(p), ctypes.byref(h)))
+    return GenTree(h)
+
+
+class GenTree:
+    def __init__(self, handle):
+        self._h = handle
+        d = _lib.TreeDescC()
+        check(lib.wepp_gen_tree_desc(self._h, ctypes.byref(d)))
+        n = d.n_nodes
+        m = int(np.ctypeslib.as_array(d.mut_off, shape=(n + 1,))[n])
+        mk = lambda p, dt: (np.ctypeslib.as_array(p, shape=(m,)).astype(dt, copy=True) if m else np.zeros(0, dt))
+        self.tree = Tree(
+            np.ctypeslib.as_array(d.parent, shape=(n,)).copy(),
+            np.ctypeslib.as_array(d.mut_off, shape=(n + 1,)).copy(),
+            mk(d.mut_pos, np.int32), mk(d.mut_ref, np.uint8), mk(d.mut_mut, np.uint8), mk(d.mut_par, np.uint8),
+        )
+
+    def reads(self, seed, n_reads, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.001,
+              p_n=0.005, p_iupac=0.0):
+        p = _lib.GenReadsParams(seed, n_reads, read_len, amplicon_len, amplicon_step, p_substitution, p_n, p_iupac)
+        h = ctypes.c_void_p()
+        check(lib.wepp_gen_reads_create(self._h, ctypes.byref(p), ctypes.byref(h)))
+        try:
+            n = ctypes.c_uint32()
+            po = _lib.c_u32p()
+            pw = _lib.c_u32p()
+            check(lib.wepp_gen_reads_get(h, ctypes.byref(n), ctypes.byref(po), ctypes.byref(pw)))
+            off = np.ctypeslib.as_array(po, shape=(n.value + 1,)).copy()
+            nw = int(off[-1])
+            words = np.ctypeslib.as_array(pw, shape=(nw,)).copy() if nw else np.zeros(0, np.uint32)
+        finally:
+            lib.wepp_gen_reads_destroy(h)
+        return Reads(off, words)
+
+    def close(self):
+        if self._h:
+            lib.wepp_gen_tree_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FlatView:
+    """Host-only view of the flattened MAT (wepp_flat_*), for the CPU tests."""
+
+    _DT = {"nkey": np.int64, "ev_meta": np.uint8}
+
+    def __init__(self, tree):
+        self._tree = tree
+        self._h = ctypes.c_void_p()
+        d = tree.desc()
+        check(lib.wepp_flat_create(ctypes.byref(d), ctypes.byref(self._h)))
+        st = _lib.MatStats()
+        cs = ctypes.c_uint32()
+        check(lib.wepp_flat_scalars(self._h, ctypes.byref(st), ctypes.byref(cs)))
+        self.stats = st
+        self.cp_stride = cs.value
+
+    def get(self, name):
+        data = ctypes.c_void_p()
+        cnt = ctypes.c_uint64()
+        eb = ctypes.c_uint32()
+        check(lib.wepp_flat_get(self._h, name.encode(), ctypes.byref(data), ctypes.byref(cnt), ctypes.byref(eb)))
+        if cnt.value == 0:
+            return np.zeros(0, np.uint32)
+        if name == "blk_sum":
+            raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 4,)).copy()
+            return raw.reshape(-1, 4)
+        dt = self._DT.get(name, np.uint32)
+        cptr = ctypes.cast(data, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt)))
+        return np.ctypeslib.as_array(cptr, shape=(cnt.value,)).copy()
+
+    def close(self):
+        if self._h:
+            lib.wepp_flat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PlacementResult:
+    def __init__(self, best_bfs_j, score, num_best, flags):
+        self.best_bfs_j = best_bfs_j
+        self.score = score
+        self.num_best = num_best
+        self.flags = flags
+
+    @property
+    def has_unique(self):
+        return (self.flags & 1).astype(np.uint8)
+
+
+class Mat:
+    """Flattened MAT resident in one GPU's HBM (wepp_mat_t)."""
+
+    def __init__(self, tree, device=0):
+        self._h = ctypes.c_void_p()
+        d = tree.desc()
+        self._keep = tree
+        check(lib.wepp_mat_create(ctypes.byref(d), int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+        st = _lib.MatStats()
+        check(lib.wepp_mat_get_stats(self._h, ctypes.byref(st)))
+        self.stats = st
+        self.n_nodes = int(st.n_nodes)
+
+    def bfs_order(self):
+        out = np.zeros(self.n_nodes, dtype=np.uint32)
+        check(lib.wepp_mat_bfs_order(self._h, _ptr(out)))
+        return out
+
+    def set_tile_reads(self, t):
+        check(lib.wepp_mat_set_tile_reads(self._h, int(t)))
+
+    def place_batch(self, reads, per_node_scores=False):
+        """Host buffers in/out: wepp_place_batch."""
+        n = reads.n_reads
+        bj = np.zeros(n, np.uint32)
+        sc = np.zeros(n, np.int32)
+        nb = np.zeros(n, np.uint32)
+        fl = np.zeros(n, np.uint32)
+        pns = np.zeros((n, self.n_nodes), np.int32) if per_node_scores else None
+        rw = reads.read_word if reads.read_word.size else np.zeros(1, np.uint32)
+        check(lib.wepp_place_batch(self._h, _ptr(reads.read_off), _ptr(rw), n, _ptr(bj), _ptr(sc), _ptr(nb),
+                                   _ptr(fl), _ptr(pns) if per_node_scores else None))
+        res = PlacementResult(bj, sc, nb, fl)
+        if per_node_scores:
+            res.per_node_scores = pns
+        return res
+
+    def place_batch_device(self, d_read_off, d_read_word, n_reads, n_read_words, d_best, d_score, d_num_best,
+                           d_flags, stream=0):
+        """Device pointers (ints) in/out: wepp_place_batch_device; not synchronised."""
+        check(lib.wepp_place_batch_device(self._h, d_read_off, d_read_word, int(n_reads), int(n_read_words),
+                                          d_best, d_score, d_num_best, d_flags, stream or None))
+
+    def last_timing(self):
+        ms = ctypes.c_float()
+        passes = ctypes.c_uint64()
+        bpp = ctypes.c_uint64()
+        check(lib.wepp_mat_last_timing(self._h, ctypes.byref(ms), ctypes.byref(passes), ctypes.byref(bpp)))
+        return ms.value, passes.value, bpp.value
+
+    def close(self):
+        if self._h:
+            lib.wepp_mat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,268 @@
+// capi.cpp -- extern "C" shim: handle lifetime, HBM residency, launches.
+//
+// Replaces the per-sample body of usher_common (src/usher_common.cpp:339-446):
+// the BFS expansion, the N empty vectors per sample, both tbb::parallel_for
+// passes over mapper2_body and the locked argmin become one batch call.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wepp_place.h"
+#include "device_mat.hpp"
+#include "errors.hpp"
+#include "flatmat.hpp"
+
+using namespace wepp;
+
+struct wepp_mat {
+    int device = 0;
+    DevMAT dev{};
+    wepp_mat_stats stats{};
+    std::vector<uint32_t> bfs2id;
+    std::vector<void*> allocs;
+    uint32_t tile_reads = 64;
+    uint32_t ncp = 1;
+    // grow-only workspace for the per-(chunk, read) partial results
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint32_t* d_max = nullptr;
+    uint32_t* h_max = nullptr;   // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint64_t last_passes = 0;
+};
+
+namespace {
+
+int hip_fail(hipError_t e, const char* what) {
+    return set_error(WEPP_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+    } while (0)
+
+template <typename T>
+int upload(wepp_mat* h, const std::vector<T>& v, const T** out) {
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    h->allocs.push_back(p);
+    h->stats.device_bytes += bytes;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return WEPP_OK;
+}
+
+void release(wepp_mat* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->d_max) (void)hipFree(h->d_max);
+    if (h->h_max) (void)hipHostFree(h->h_max);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+}  // namespace
+
+extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_t** out) {
+    if (!tree || !out) return set_error(WEPP_EINVAL, "null argument");
+    *out = nullptr;
+    FlatMAT f;
+    std::string err;
+    try {
+        int rc = flatten_tree(*tree, f, err);
+        if (rc != WEPP_OK) return set_error(rc, err);
+    } catch (const std::bad_alloc&) {
+        return set_error(WEPP_ENOMEM, "out of host memory while flattening the tree");
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return set_error(WEPP_EDEVICE, "no HIP device available (the placement engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(WEPP_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    wepp_mat* h = new (std::nothrow) wepp_mat();
+    if (!h) return set_error(WEPP_ENOMEM, "out of host memory");
+    h->device = device;
+    h->bfs2id = f.bfs2id;
+    h->stats.n_nodes = f.N;
+    h->stats.n_mutations = f.M;
+    h->stats.n_masked = f.n_masked;
+    h->stats.n_events = f.E;
+    h->stats.n_blocks = f.NB;
+    h->stats.n_leaves = f.n_leaves;
+    h->stats.max_depth = f.max_depth;
+    h->stats.max_position = f.max_pos;
+    // one sweep reads every event word plus the per-block offsets and summary
+    h->stats.stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(BlkSum) + 8);
+    h->ncp = (uint32_t)f.cp_off.size() - 1;
+
+    DevMAT& d = h->dev;
+    d.N = f.N;
+    d.NB = f.NB;
+    d.cp_stride = f.cp_stride;
+    d.max_pos = f.max_pos;
+    d.bm_words = (f.max_pos >> 5) + 1;
+    int rc;
+#define UP(field) if ((rc = upload(h, f.field, &d.field)) != WEPP_OK) { release(h); return rc; }
+    UP(node_woff) UP(words) UP(nkey) UP(nstat) UP(rank2dfs) UP(dfs2bfs)
+    UP(blk_node0) UP(blk_eoff) UP(blk_sum) UP(ev_word) UP(ev_meta) UP(cp_off) UP(cp_word)
+#undef UP
+    e = hipMalloc((void**)&h->d_max, 16);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_max, 16, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = sweep_set_max_lds(160 * 1024);
+    if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
+    *out = h;
+    return WEPP_OK;
+}
+
+extern "C" int wepp_mat_destroy(wepp_mat_t* mat) {
+    release(mat);
+    return WEPP_OK;
+}
+
+extern "C" int wepp_mat_get_stats(const wepp_mat_t* mat, wepp_mat_stats* out) {
+    if (!mat || !out) return set_error(WEPP_EINVAL, "null argument");
+    *out = mat->stats;
+    return WEPP_OK;
+}
+
+extern "C" int wepp_mat_bfs_order(const wepp_mat_t* mat, uint32_t* bfs_ids) {
+    if (!mat || !bfs_ids) return set_error(WEPP_EINVAL, "null argument");
+    std::memcpy(bfs_ids, mat->bfs2id.data(), mat->bfs2id.size() * sizeof(uint32_t));
+    return WEPP_OK;
+}
+
+extern "C" int wepp_mat_set_tile_reads(wepp_mat_t* mat, uint32_t reads_per_tile) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    if (reads_per_tile < 1 || reads_per_tile > 64) return set_error(WEPP_EINVAL, "reads_per_tile must be 1..64");
+    mat->tile_reads = reads_per_tile;
+    return WEPP_OK;
+}
+
+extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                                       uint32_t n_reads, uint64_t n_read_words, uint32_t* d_best_bfs_j,
+                                       int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags,
+                                       void* hip_stream) {
+    if (!mat || !d_read_off) return set_error(WEPP_EINVAL, "null argument");
+    if (n_read_words && !d_read_word) return set_error(WEPP_EINVAL, "null read_word");
+    if (n_reads == 0) return WEPP_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(mat->device));
+    const uint32_t T = mat->tile_reads;
+    const uint32_t ntiles = (n_reads + T - 1) / T;
+
+    // largest tile (read words) decides how much LDS a workgroup asks for
+    HIP_TRY(hipMemsetAsync(mat->d_max, 0, 4, stream));
+    HIP_TRY(launch_tile_max_entries(d_read_off, n_reads, T, mat->d_max, stream));
+    HIP_TRY(hipMemcpyAsync(mat->h_max, mat->d_max, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint32_t max_ent = *mat->h_max;
+    const uint32_t bm_bytes = mat->dev.bm_words * 4;
+    uint32_t cap = (max_ent + 63) & ~63u;
+    bool s_in_lds = true;
+    uint32_t lds_bytes = bm_bytes + cap * 4;
+    if (lds_bytes > 64 * 1024) { s_in_lds = false; lds_bytes = bm_bytes; }
+    if (lds_bytes > 160 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
+
+    // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
+    const uint32_t target_waves = 8192;
+    uint32_t nchunks = std::max<uint32_t>(1, (target_waves + ntiles - 1) / ntiles);
+    nchunks = std::min(nchunks, mat->ncp);
+    const uint32_t cps_per_chunk = (mat->ncp + nchunks - 1) / nchunks;
+    const uint32_t bpc = cps_per_chunk * mat->dev.cp_stride;
+    nchunks = (mat->dev.NB + bpc - 1) / bpc;
+
+    const size_t need = (size_t)nchunks * n_reads * 12;
+    if (need > mat->ws_bytes) {
+        if (mat->ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(mat->ws); mat->ws = nullptr; mat->ws_bytes = 0; }
+        hipError_t e = hipMalloc(&mat->ws, need);
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+        mat->ws_bytes = need;
+    }
+    int32_t* part_score = (int32_t*)mat->ws;
+    uint32_t* part_rank = (uint32_t*)(part_score + (size_t)nchunks * n_reads);
+    uint32_t* part_cnt = part_rank + (size_t)nchunks * n_reads;
+
+    HIP_TRY(hipEventRecord(mat->ev0, stream));
+    HIP_TRY(launch_sweep(mat->dev, d_read_off, d_read_word, n_reads, T, ntiles, nchunks, bpc, s_in_lds, lds_bytes,
+                         part_score, part_rank, part_cnt, stream));
+    HIP_TRY(hipEventRecord(mat->ev1, stream));
+    mat->timed = true;
+    mat->last_passes = (uint64_t)ntiles;   // every tile sweeps the whole stream once (split over its chunks)
+    HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, n_reads, nchunks, part_score, part_rank, part_cnt,
+                            d_best_bfs_j, d_score, d_num_best, d_flags, stream));
+    return WEPP_OK;
+}
+
+extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* sweep_ms, uint64_t* passes, uint64_t* bytes_per_pass) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    if (!mat->timed) return set_error(WEPP_EINVAL, "no placement has been launched on this handle yet");
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipEventSynchronize(mat->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, mat->ev0, mat->ev1));
+    if (sweep_ms) *sweep_ms = ms;
+    if (passes) *passes = mat->last_passes;
+    if (bytes_per_pass) *bytes_per_pass = mat->stats.stream_bytes;
+    return WEPP_OK;
+}
+
+extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word,
+                                uint32_t n_reads, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
+                                uint32_t* flags, int32_t* per_node_scores) {
+    if (!mat || !read_off) return set_error(WEPP_EINVAL, "null argument");
+    if (per_node_scores) return set_error(WEPP_EINVAL, "per_node_scores is not implemented yet");
+    if (n_reads == 0) return WEPP_OK;
+    if (read_off[0] != 0) return set_error(WEPP_EINVAL, "read_off[0] must be 0");
+    const uint64_t nw = read_off[n_reads];
+    if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
+    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions
+    for (uint32_t r = 0; r < n_reads; r++) {
+        if (read_off[r + 1] < read_off[r]) return set_error(WEPP_EINVAL, "read_off not monotone");
+        for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
+            if ((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu))
+                return set_error(WEPP_EINVAL, "read " + std::to_string(r) + ": entries must be sorted by position with unique positions");
+        for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
+            if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0)
+                return set_error(WEPP_EINVAL, "read " + std::to_string(r) + ": zero nucleotide mask");
+    }
+    HIP_TRY(hipSetDevice(mat->device));
+    uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
+    int rc = WEPP_OK;
+    hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n_reads * 16);
+    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
+    e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nw) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = hip_fail(e, "H2D copy of the reads"); goto done; }
+    rc = wepp_place_batch_device(mat, d_off, d_word, n_reads, nw, d_out, (int32_t*)(d_out + n_reads),
+                                 d_out + 2 * (size_t)n_reads, d_out + 3 * (size_t)n_reads, nullptr);
+    if (rc != WEPP_OK) goto done;
+    e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess && best_bfs_j) e = hipMemcpy(best_bfs_j, d_out, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && score) e = hipMemcpy(score, d_out + n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && num_best) e = hipMemcpy(num_best, d_out + 2 * (size_t)n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && flags) e = hipMemcpy(flags, d_out + 3 * (size_t)n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "placement kernels / D2H copy of the results");
+done:
+    if (d_off) (void)hipFree(d_off);
+    if (d_word) (void)hipFree(d_word);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}

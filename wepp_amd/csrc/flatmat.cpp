@@ -1,0 +1,346 @@
+// flatmat.cpp -- Tree -> FlatMAT flattener (host, one-time).
+//
+// Reference behaviour folded into constants here (paths relative to
+// /root/reference/src):
+//   * BFS / DFS enumeration      mutation_annotated_tree.cpp:1115-1163
+//   * get_num_leaves             mutation_annotated_tree.cpp:839-852
+//   * ancestor walk "most recent mutation per position, masked skipped"
+//                                usher_mapper.cpp:276-287
+//   * root: every root mutation enters the ancestral set
+//                                usher_mapper.cpp:266-271
+//   * masked node mutation => has_unique, break
+//                                usher_mapper.cpp:198-201
+//   * a node mutation whose position is not in the sample is "common" iff it
+//     reverts to the reference allele
+//                                usher_mapper.cpp:244-260
+//   * eligibility predicate      usher_mapper.cpp:455-456
+//   * tie-break (num_leaves, then larger BFS index j)
+//                                usher_mapper.cpp:484-487
+#include "flatmat.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace wepp {
+
+namespace {
+inline uint32_t cost0(uint32_t x, uint32_t ref) { return (x != 0 && x != ref) ? 1u : 0u; }
+}  // namespace
+
+int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
+    const uint32_t N = t.n_nodes;
+    if (N == 0 || !t.parent || !t.mut_off) { err = "empty tree or null arrays"; return WEPP_EINVAL; }
+    if (N >= 0xFFFFFFF0u) { err = "too many nodes"; return WEPP_ELIMIT; }
+    const uint64_t Mall = t.mut_off[N];
+    if (Mall && (!t.mut_pos || !t.mut_ref || !t.mut_mut)) { err = "null mutation arrays"; return WEPP_EINVAL; }
+    if (Mall >= 0xFFFFFFF0ull) { err = "too many mutations"; return WEPP_ELIMIT; }
+
+    // ---- children CSR (ascending id order), root ---------------------------
+    std::vector<uint32_t> coff(N + 1, 0), child(N ? N - 1 : 0);
+    int64_t root = -1;
+    for (uint32_t i = 0; i < N; i++) {
+        int32_t p = t.parent[i];
+        if (p < 0) {
+            if (root >= 0) { err = "more than one root"; return WEPP_EINVAL; }
+            root = i;
+        } else {
+            if ((uint32_t)p >= N || (uint32_t)p == i) { err = "parent id out of range"; return WEPP_EINVAL; }
+            coff[p + 1]++;
+        }
+        if (t.mut_off[i + 1] < t.mut_off[i]) { err = "mut_off not monotone"; return WEPP_EINVAL; }
+    }
+    if (root < 0) { err = "no root"; return WEPP_EINVAL; }
+    for (uint32_t i = 0; i < N; i++) coff[i + 1] += coff[i];
+    {
+        std::vector<uint32_t> fill(coff.begin(), coff.end() - 1);
+        for (uint32_t i = 0; i < N; i++)
+            if (t.parent[i] >= 0) child[fill[t.parent[i]]++] = i;
+    }
+
+    // ---- BFS order (mutation_annotated_tree.cpp:1115-1141) ------------------
+    std::vector<uint32_t> bfs_of_id(N, 0xFFFFFFFFu);
+    f.bfs2id.assign(N, 0);
+    {
+        uint32_t head = 0, tail = 0;
+        f.bfs2id[tail++] = (uint32_t)root;
+        while (head < tail) {
+            uint32_t c = f.bfs2id[head];
+            bfs_of_id[c] = head++;
+            for (uint32_t k = coff[c]; k < coff[c + 1]; k++) {
+                if (tail >= N) { err = "tree has a cycle"; return WEPP_EINVAL; }
+                f.bfs2id[tail++] = child[k];
+            }
+        }
+        if (tail != N) { err = "tree is disconnected or has a cycle"; return WEPP_EINVAL; }
+    }
+
+    // ---- DFS pre-order (mutation_annotated_tree.cpp:1143-1163) --------------
+    f.dfs2id.assign(N, 0);
+    std::vector<uint32_t> dfs_of_id(N), depth(N, 0);
+    {
+        std::vector<uint32_t> stack;
+        stack.reserve(1024);
+        stack.push_back((uint32_t)root);
+        uint32_t cnt = 0;
+        while (!stack.empty()) {
+            uint32_t c = stack.back();
+            stack.pop_back();
+            dfs_of_id[c] = cnt;
+            f.dfs2id[cnt++] = c;
+            for (uint32_t k = coff[c + 1]; k > coff[c]; k--) stack.push_back(child[k - 1]);
+        }
+    }
+    f.N = N;
+    f.parent_dfs.assign(N, 0);
+    f.dfs_end.assign(N, 0);
+    f.num_leaves.assign(N, 0);
+    f.dfs2bfs.assign(N, 0);
+    f.max_depth = 0;
+    for (uint32_t d = 0; d < N; d++) {
+        uint32_t id = f.dfs2id[d];
+        f.dfs2bfs[d] = bfs_of_id[id];
+        if (t.parent[id] >= 0) {
+            uint32_t pd = dfs_of_id[t.parent[id]];
+            f.parent_dfs[d] = pd;
+            depth[d] = depth[pd] + 1;
+            f.max_depth = std::max(f.max_depth, depth[d]);
+        }
+    }
+    // subtree end + leaf counts: reverse DFS order visits children before parents
+    f.n_leaves = 0;
+    for (uint32_t d = 0; d < N; d++) f.dfs_end[d] = d;
+    for (uint32_t d = N; d-- > 0;) {
+        uint32_t id = f.dfs2id[d];
+        if (coff[id] == coff[id + 1]) { f.num_leaves[d] = 1; f.n_leaves++; }
+        if (d != 0) {
+            uint32_t pd = f.parent_dfs[d];
+            f.num_leaves[pd] += f.num_leaves[d];
+            f.dfs_end[pd] = std::max(f.dfs_end[pd], f.dfs_end[d]);
+        }
+    }
+
+    // ---- mutation words in DFS order, validation ----------------------------
+    f.node_woff.assign(N + 1, 0);
+    f.nstat.assign(N, 0);
+    f.n_masked = 0;
+    uint32_t max_pos = 0;
+    std::vector<uint32_t> root_masked_cost(1, 0);
+    for (uint32_t d = 0; d < N; d++) {
+        uint32_t id = f.dfs2id[d];
+        uint32_t nm = 0;
+        int32_t prev = INT32_MIN;
+        bool masked = false;
+        for (uint32_t k = t.mut_off[id]; k < t.mut_off[id + 1]; k++) {
+            int32_t p = t.mut_pos[k];
+            if (p < prev) { err = "node mutations not sorted by position (node id " + std::to_string(id) + ")"; return WEPP_EINVAL; }
+            if (p >= 0 && p == prev) { err = "duplicate mutation position in node id " + std::to_string(id); return WEPP_EINVAL; }
+            prev = p;
+            if (p < 0) {
+                masked = true;
+                f.n_masked++;
+                // root: masked mutations enter the ancestral set (usher_mapper.cpp:267-270)
+                // and cost 1 in the back-mutation loop iff ref_nuc != mut_nuc (:429-437)
+                if (d == 0 && (t.mut_ref[k] & 15) != (t.mut_mut[k] & 15)) root_masked_cost[0]++;
+                continue;
+            }
+            if ((uint32_t)p > WEPP_MAX_POSITION) { err = "mutation position exceeds 2^20-1"; return WEPP_ELIMIT; }
+            if ((t.mut_mut[k] & 15) == 0 || (t.mut_ref[k] & 15) == 0) { err = "zero nucleotide mask on a non-masked mutation"; return WEPP_EINVAL; }
+            max_pos = std::max(max_pos, (uint32_t)p);
+            nm++;
+        }
+        if (nm > NS_CNT_MASK) { err = "more than 16383 mutations on one node"; return WEPP_ELIMIT; }
+        f.node_woff[d + 1] = f.node_woff[d] + nm;
+        if (masked && d != 0) f.nstat[d] |= NS_MASKED;
+        if (coff[id] == coff[id + 1]) f.nstat[d] |= NS_LEAF;
+    }
+    f.nstat[0] |= NS_ROOT;
+    f.M = f.node_woff[N];
+    f.max_pos = max_pos;
+    f.words.assign(f.M, 0);
+
+    // ---- true parent alleles, D0, per-node constants ------------------------
+    // state[p] = allele mask of the most recent mutation at p on the current
+    // root path (0 = none); refm[p] = the (single) ref mask seen at p.
+    std::vector<uint8_t> state((size_t)max_pos + 1, 0), refm((size_t)max_pos + 1, 0);
+    std::vector<int32_t> D0(N, 0);
+    std::vector<int32_t> base(N, 0);
+    {
+        std::vector<uint32_t> open;           // stack of open nodes (DFS idx)
+        open.reserve(f.max_depth + 2);
+        std::vector<uint8_t> undo(f.M, 0);     // previous state per word
+        for (uint32_t d = 0; d < N; d++) {
+            while (!open.empty() && f.dfs_end[open.back()] < d) {
+                uint32_t x = open.back();
+                open.pop_back();
+                for (uint32_t w = f.node_woff[x + 1]; w > f.node_woff[x]; w--)
+                    state[f.words[w - 1] & W_POS_MASK] = undo[w - 1];
+            }
+            uint32_t id = f.dfs2id[d];
+            int32_t dpar = (d == 0) ? 0 : D0[f.parent_dfs[d]];
+            int32_t dcur = dpar;
+            uint32_t nback_cost = 0, ncommon0 = 0;
+            uint32_t w = f.node_woff[d];
+            for (uint32_t k = t.mut_off[id]; k < t.mut_off[id + 1]; k++) {
+                int32_t p = t.mut_pos[k];
+                if (p < 0) continue;
+                uint32_t ref = t.mut_ref[k] & 15, mut = t.mut_mut[k] & 15;
+                if (refm[p] == 0) refm[p] = (uint8_t)ref;
+                else if (refm[p] != ref) { err = "inconsistent ref_nuc at position " + std::to_string(p); return WEPP_EINVAL; }
+                uint32_t par = state[p];
+                f.words[w] = w_pack((uint32_t)p, ref, par, mut);
+                undo[w] = (uint8_t)par;
+                state[p] = (uint8_t)mut;
+                dcur += (int32_t)cost0(mut, ref) - (int32_t)cost0(par, ref);
+                if (mut == ref) { ncommon0++; nback_cost += cost0(par, ref); }
+                w++;
+            }
+            D0[d] = dcur;
+            uint32_t nmut = f.node_woff[d + 1] - f.node_woff[d];
+            uint32_t st = f.nstat[d];
+            bool leaf = st & NS_LEAF, masked = st & NS_MASKED;
+            bool elig0;
+            if (d == 0) {
+                // root score = D(root) (usher_mapper.cpp:266-271); its masked mutations are
+                // seen by the root only (descendants skip masked ancestors, :281)
+                base[0] = dcur + (int32_t)root_masked_cost[0];
+                elig0 = true;             // root always competes (usher_mapper.cpp:455)
+                ncommon0 = 0;             // root: node_num_mut = num_common_mut = 0
+            } else {
+                base[d] = masked ? dpar : dpar - (int32_t)nback_cost;   // masked: loop breaks before any common
+                if (masked) elig0 = false;                    // has_unique, num_common 0
+                else if (leaf) elig0 = ncommon0 > 0;
+                else elig0 = (ncommon0 > 0) || (ncommon0 == nmut);
+            }
+            f.nstat[d] = st | (nmut & NS_CNT_MASK) | ((ncommon0 & NS_CNT_MASK) << 14) | (elig0 ? NS_ELIG0 : 0);
+            open.push_back(d);
+        }
+    }
+
+    // ---- tie-break rank: larger num_leaves first, then larger BFS index -----
+    f.rank2dfs.resize(N);
+    std::iota(f.rank2dfs.begin(), f.rank2dfs.end(), 0u);
+    std::sort(f.rank2dfs.begin(), f.rank2dfs.end(), [&](uint32_t a, uint32_t b) {
+        if (f.num_leaves[a] != f.num_leaves[b]) return f.num_leaves[a] > f.num_leaves[b];
+        return f.dfs2bfs[a] > f.dfs2bfs[b];
+    });
+    f.nkey.assign(N, 0);
+    for (uint32_t r = 0; r < N; r++) {
+        uint32_t d = f.rank2dfs[r];
+        f.nkey[d] = ((int64_t)base[d] << 32) | (int64_t)r;
+    }
+
+    // ---- sweep stream ---------------------------------------------------------
+    // events at DFS position x: enter words of node x, and exit words of every
+    // internal node a with dfs_end[a] + 1 == x.  Leaves emit no exit (their
+    // enter is flagged EV_LEAF and changes no other node's state).
+    std::vector<uint32_t> evcnt(N + 1, 0);
+    for (uint32_t d = 0; d < N; d++) {
+        uint32_t nm = f.node_woff[d + 1] - f.node_woff[d];
+        evcnt[d] += nm;
+        if (!(f.nstat[d] & NS_LEAF) && f.dfs_end[d] + 1 < N) evcnt[f.dfs_end[d] + 1] += nm;
+    }
+    // blocks
+    f.blk_node0.clear();
+    f.blk_eoff.clear();
+    {
+        uint32_t d = 0;
+        uint64_t eoff = 0;
+        while (d < N) {
+            f.blk_node0.push_back(d);
+            f.blk_eoff.push_back((uint32_t)eoff);
+            uint32_t nn = 0;
+            uint64_t ne = 0;
+            while (d < N && nn < BLK_MAX_NODES && (nn == 0 || ne + evcnt[d] <= BLK_MAX_EVENTS)) {
+                ne += evcnt[d];
+                nn++;
+                d++;
+            }
+            eoff += ne;
+            if (eoff >= 0xFFFFFFF0ull) { err = "too many sweep events"; return WEPP_ELIMIT; }
+        }
+        f.NB = (uint32_t)f.blk_node0.size();
+        f.blk_node0.push_back(N);
+        f.blk_eoff.push_back((uint32_t)eoff);
+        f.E = eoff;
+    }
+    // per-position event offsets, then fill
+    {
+        std::vector<uint32_t> epos(N + 1, 0);
+        for (uint32_t d = 0; d < N; d++) epos[d + 1] = epos[d] + evcnt[d];
+        std::vector<uint32_t> fill(epos.begin(), epos.end() - 1);
+        f.ev_word.assign(f.E, 0);
+        f.ev_meta.assign(f.E, 0);
+        // block index of each node is implicit: offset within block = d - blk_node0[b]
+        uint32_t b = 0;
+        std::vector<uint32_t> blk_of;  // only needed for exit placement: compute by scan
+        blk_of.resize(N);
+        for (uint32_t d = 0; d < N; d++) {
+            while (f.blk_node0[b + 1] <= d) b++;
+            blk_of[d] = b;
+        }
+        for (uint32_t d = 0; d < N; d++) {
+            // the root scores itself with its own mutations applied, so its enter
+            // events are never flagged EV_LEAF (single-node tree)
+            bool leaf = (f.nstat[d] & NS_LEAF) && d != 0;
+            uint32_t off = d - f.blk_node0[blk_of[d]];
+            for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
+                uint32_t e = fill[d]++;
+                f.ev_word[e] = f.words[w];
+                f.ev_meta[e] = (uint8_t)(off | (leaf ? EV_LEAF : 0));
+            }
+            if (!(f.nstat[d] & NS_LEAF) && f.dfs_end[d] + 1 < N) {
+                uint32_t x = f.dfs_end[d] + 1;
+                uint32_t xoff = x - f.blk_node0[blk_of[x]];
+                for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
+                    uint32_t e = fill[x]++;
+                    f.ev_word[e] = f.words[w];
+                    f.ev_meta[e] = (uint8_t)(xoff | EV_EXIT);
+                }
+            }
+        }
+    }
+    // block summaries over statically eligible nodes
+    f.blk_sum.assign(f.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, 0});
+    for (uint32_t b = 0; b < f.NB; b++) {
+        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, 0};
+        for (uint32_t d = f.blk_node0[b]; d < f.blk_node0[b + 1]; d++) {
+            if (!(f.nstat[d] & NS_ELIG0)) continue;
+            int32_t bs = (int32_t)(f.nkey[d] >> 32);
+            uint32_t rk = (uint32_t)(f.nkey[d] & 0xFFFFFFFFll);
+            if (bs < s.base) { s.base = bs; s.rank = rk; s.cnt = 1; }
+            else if (bs == s.base) { s.cnt++; s.rank = std::min(s.rank, rk); }
+        }
+        f.blk_sum[b] = s;
+    }
+
+    // ---- checkpoints ------------------------------------------------------------
+    f.cp_stride = std::max<uint32_t>(1, (f.NB + 255) / 256);
+    {
+        uint32_t ncp = (f.NB + f.cp_stride - 1) / f.cp_stride;
+        f.cp_off.assign(ncp + 1, 0);
+        f.cp_word.clear();
+        std::vector<uint32_t> path;
+        for (uint32_t i = 0; i < ncp; i++) {
+            f.cp_off[i] = (uint32_t)f.cp_word.size();
+            // Running state of a sequential sweep when it reaches block b: the
+            // enter words of every non-leaf node still open after node g-1, i.e.
+            // g-1 itself (unless it is a leaf) and all its ancestors.  Subtrees
+            // ending exactly at g-1 are closed by exit events INSIDE block b.
+            uint32_t g = f.blk_node0[i * f.cp_stride];
+            path.clear();
+            if (g > 0) {
+                uint32_t a = g - 1;
+                if (!(f.nstat[a] & NS_LEAF)) path.push_back(a);
+                while (a != 0) { a = f.parent_dfs[a]; path.push_back(a); }
+            }
+            for (size_t k = path.size(); k-- > 0;) {
+                uint32_t x = path[k];
+                for (uint32_t w = f.node_woff[x]; w < f.node_woff[x + 1]; w++) f.cp_word.push_back(f.words[w]);
+            }
+        }
+        f.cp_off[ncp] = (uint32_t)f.cp_word.size();
+    }
+    return WEPP_OK;
+}
+
+}  // namespace wepp

@@ -1,0 +1,81 @@
+// flatmat.hpp -- host-side flattened mutation-annotated tree (MAT).
+//
+// The reference keeps the MAT as a pointer graph (MAT::Node / MAT::Tree,
+// src/mutation_annotated_tree.hpp:80-152) and re-derives, for every
+// (sample, node) pair, the root-to-node genotype by walking parents
+// (src/usher_mapper.cpp:276-287).  Here the tree is flattened ONCE into
+// DFS-ordered arrays that live in HBM; everything that does not depend on the
+// read is folded into per-node constants.  See DESIGN.md section 3 for the
+// layout and section 2 for the closed form the constants implement.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/wepp_place.h"
+
+namespace wepp {
+
+// ---- packed tree mutation word: pos:20 | ref:4 | par:4 | mut:4 -------------
+// `par` is the TRUE allele state of the parent genotype at this position
+// (0 = no mutation above on the root path), recomputed by the flattener;
+// Mutation::par_nuc of the reference (mutation_annotated_tree.hpp:48) is never
+// read by the scorer.
+constexpr uint32_t W_POS_MASK = 0xFFFFFu;
+inline uint32_t w_pack(uint32_t pos, uint32_t ref, uint32_t par, uint32_t mut) {
+    return (pos & W_POS_MASK) | ((ref & 15u) << 20) | ((par & 15u) << 24) | ((mut & 15u) << 28);
+}
+
+// ---- per-node static word ---------------------------------------------------
+// nmut:14 | ncommon0:14 | leaf | masked | elig0 | root
+constexpr uint32_t NS_CNT_MASK = 0x3FFFu;
+constexpr uint32_t NS_LEAF = 1u << 28, NS_MASKED = 1u << 29, NS_ELIG0 = 1u << 30, NS_ROOT = 1u << 31;
+constexpr int32_t SCORE_INF = 0x3FFFFFFF;
+
+// ---- sweep-stream event meta byte: off:6 | exit | leaf ----------------------
+constexpr uint8_t EV_OFF_MASK = 63, EV_EXIT = 64, EV_LEAF = 128;
+
+constexpr uint32_t BLK_MAX_NODES = 64;    // one node per lane on the slow path
+constexpr uint32_t BLK_MAX_EVENTS = 128;  // two event words per lane per load
+
+struct BlkSum {          // read-independent summary of one sweep block
+    int32_t base;        // min static score over statically eligible nodes (SCORE_INF if none)
+    uint32_t rank;       // tie-break rank of that minimum
+    uint32_t cnt;        // number of statically eligible nodes attaining `base`
+    uint32_t pad;
+};
+
+struct FlatMAT {
+    uint32_t N = 0, n_leaves = 0, max_depth = 0, max_pos = 0;
+    uint64_t M = 0, E = 0, n_masked = 0;
+    uint32_t NB = 0;
+    // node-major CSR in DFS pre-order (depth_first_expansion order,
+    // mutation_annotated_tree.cpp:1143-1163 == .pb node_mutations order)
+    std::vector<uint32_t> node_woff;   // [N+1]
+    std::vector<uint32_t> words;       // [M] non-masked mutation words
+    std::vector<int64_t> nkey;         // [N] (base << 32) | rank
+    std::vector<uint32_t> nstat;       // [N]
+    std::vector<uint32_t> rank2dfs;    // [N]
+    std::vector<uint32_t> dfs2bfs;     // [N] BFS index j of each node (tie-break key, usher_common.cpp:391,400)
+    std::vector<uint32_t> bfs2id;      // [N] caller id of bfs[k]            (host only)
+    std::vector<uint32_t> dfs2id;      // [N] caller id of dfs[k]            (host only)
+    std::vector<uint32_t> parent_dfs;  // [N] DFS index of parent (root: 0)  (host only)
+    std::vector<uint32_t> dfs_end;     // [N] last DFS index of the subtree  (host only)
+    std::vector<uint32_t> num_leaves;  // [N]                                (host only)
+    // sweep stream: blocks of <=64 consecutive DFS nodes with <=128 events
+    std::vector<uint32_t> blk_node0;   // [NB+1]
+    std::vector<uint32_t> blk_eoff;    // [NB+1]
+    std::vector<BlkSum> blk_sum;       // [NB]
+    std::vector<uint32_t> ev_word;     // [E]
+    std::vector<uint8_t> ev_meta;      // [E]
+    // checkpoints: enter words of every node still open when a sequential sweep
+    // reaches block i*cp_stride (node blk_node0[..]-1 unless a leaf, and its ancestors)
+    uint32_t cp_stride = 1;
+    std::vector<uint32_t> cp_off;      // [ncp+1]
+    std::vector<uint32_t> cp_word;
+};
+
+// Returns WEPP_OK or an error code; `err` receives the message.
+int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err);
+
+}  // namespace wepp

@@ -1,0 +1,414 @@
+// place_kernels.hip -- CDNA4 (gfx950) kernels of the read-placement engine.
+//
+// What is computed: for every read, exactly what the two passes of the
+// reference's per-sample loop leave behind (src/usher_common.cpp:386-446, each
+// iteration being mapper2_body, src/usher_mapper.cpp:168-506): the minimum
+// parsimony score over eligible nodes, the number of eligible nodes attaining
+// it, and the winner under the (num_leaves, BFS index) tie-break.
+//
+// How (DESIGN.md sections 2-4): the score of node n for read S is
+//     score(n) = base(n) + c_S(parent(n)) + adj_S(n)
+// where base(n) is read-independent, c_S is the read-dependent correction of
+// the parent genotype and adj_S(n) is non-zero only when n itself mutates a
+// position listed in S.  c_S changes only at "events": entering / leaving the
+// subtree of a node that mutates a position of S.  The tree is stored as a
+// DFS-ordered event stream cut into blocks of <=64 nodes / <=128 events, with a
+// read-independent summary per block.  One wavefront sweeps the stream once
+// for a TILE of up to 64 reads (lane = read): blocks without an event for a
+// read cost that read one summary update; blocks with events are re-evaluated
+// node by node (lane = node) for just the reads concerned.
+//
+// Integer work only: no MFMA.  The bound is the event stream (HBM/L2 bytes).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_mat.hpp"
+
+namespace wepp {
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// ---- word field helpers ------------------------------------------------------
+__device__ __forceinline__ uint32_t w_pos(uint32_t w) { return w & 0xFFFFFu; }
+__device__ __forceinline__ uint32_t tw_ref(uint32_t w) { return (w >> 20) & 15u; }
+__device__ __forceinline__ uint32_t tw_par(uint32_t w) { return (w >> 24) & 15u; }
+__device__ __forceinline__ uint32_t tw_mut(uint32_t w) { return (w >> 28) & 15u; }
+__device__ __forceinline__ uint32_t rw_ref(uint32_t w) { return (w >> 20) & 15u; }
+__device__ __forceinline__ uint32_t rw_mut(uint32_t w) { return (w >> 24) & 15u; }
+__device__ __forceinline__ uint32_t rw_missing(uint32_t w) { return (w >> 28) & 1u; }
+
+// f(x) = cost of allele state x for the read entry `s` minus its cost for an
+// empty read; x == 0 means "no mutation on the root path" (then the read is
+// compared with ITS OWN ref_nuc, usher_mapper.cpp:302-305,342).
+__device__ __forceinline__ int f_state(uint32_t x, uint32_t tref, uint32_t s) {
+    int c0 = (x != 0 && x != tref) ? 1 : 0;                                   // usher_mapper.cpp:426-437
+    int cs = rw_missing(s) ? 0 : (((rw_mut(s) & (x ? x : rw_ref(s))) == 0) ? 1 : 0);  // :295,314-320,342
+    return cs - c0;
+}
+// change of c_S for the descendants of a node carrying tree word `w`
+__device__ __forceinline__ int enter_delta(uint32_t w, uint32_t s) {
+    return f_state(tw_mut(w), tw_ref(w), s) - f_state(tw_par(w), tw_ref(w), s);
+}
+// own-score / common-count adjustments of the node carrying `w`
+// (usher_mapper.cpp:205-264: "common" test with the sample vs. without it)
+__device__ __forceinline__ void own_adjust(uint32_t w, uint32_t s, int& adj_score, int& adj_common) {
+    const uint32_t ref = tw_ref(w), par = tw_par(w), mut = tw_mut(w);
+    const int static_common = (mut == ref) ? 1 : 0;
+    const int static_sub = static_common ? ((par != 0 && par != ref) ? 1 : 0) : 0;
+    int actual_common, actual_sub;
+    if (rw_missing(s)) { actual_common = 1; actual_sub = 0; }                  // :210-212
+    else {
+        actual_common = ((rw_mut(s) & mut) != 0) ? 1 : 0;                       // :215
+        actual_sub = actual_common ? (((rw_mut(s) & (par ? par : rw_ref(s))) == 0) ? 1 : 0) : 0;
+    }
+    adj_score += static_sub - actual_sub;
+    adj_common += actual_common - static_common;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// lower_bound over a position-sorted slice of read words; returns the entry
+// with exactly `pos` or NONE.
+template <typename SPtr>
+__device__ __forceinline__ uint32_t find_entry(SPtr S, uint32_t off, uint32_t k, uint32_t pos) {
+    uint32_t lo = 0, hi = k;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        uint32_t p = w_pos(S[off + mid]);
+        if (p < pos) lo = mid + 1; else hi = mid;
+    }
+    if (lo < k) {
+        uint32_t s = S[off + lo];
+        if (w_pos(s) == pos) return s;
+    }
+    return NONE;
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------
+// tile_max_entries: largest number of read words any tile brings into LDS.
+// -----------------------------------------------------------------------------
+__global__ void k_tile_max_entries(const uint32_t* __restrict__ read_off, uint32_t n_reads, uint32_t T,
+                                   uint32_t* __restrict__ out_max) {
+    uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ntiles = (n_reads + T - 1) / T;
+    uint32_t v = 0;
+    if (tile < ntiles) {
+        uint32_t r0 = tile * T, r1 = min(n_reads, r0 + T);
+        v = read_off[r1] - read_off[r0];
+    }
+    v = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
+}
+
+// -----------------------------------------------------------------------------
+// The sweep.  grid = ntiles * nchunks single-wave workgroups.
+// LDS: [bm_words] position bitmap of the tile, then (S_IN_LDS) the tile's read
+// words.  part_* receive one (score, rank, count) per (chunk, read).
+// -----------------------------------------------------------------------------
+template <bool S_IN_LDS>
+__global__ __launch_bounds__(64) void k_sweep(DevMAT m, const uint32_t* __restrict__ read_off,
+                                              const uint32_t* __restrict__ read_word, uint32_t n_reads,
+                                              uint32_t T, uint32_t ntiles, uint32_t blocks_per_chunk,
+                                              int32_t* __restrict__ part_score,
+                                              uint32_t* __restrict__ part_rank,
+                                              uint32_t* __restrict__ part_cnt) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* bitmap = lds;
+    uint32_t* S_lds = lds + m.bm_words;
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x % ntiles;
+    const uint32_t chunk = blockIdx.x / ntiles;
+    const uint32_t r0 = tile * T;
+    const uint32_t nr = min(T, n_reads - r0);
+    const bool have = lane < nr;
+
+    const uint32_t sbeg = read_off[r0];
+    const uint32_t send = read_off[r0 + nr];
+    const uint32_t so = have ? read_off[r0 + lane] : sbeg;
+    const uint32_t se = have ? read_off[r0 + lane + 1] : sbeg;
+    const uint32_t n_ent = send - sbeg;
+
+    for (uint32_t i = lane; i < m.bm_words; i += 64) bitmap[i] = 0;
+    __syncthreads();
+    for (uint32_t i = lane; i < n_ent; i += 64) {
+        uint32_t w = read_word[sbeg + i];
+        if (S_IN_LDS) S_lds[i] = w;
+        uint32_t p = w_pos(w);
+        if (p <= m.max_pos) atomicOr(&bitmap[p >> 5], 1u << (p & 31));
+    }
+    __syncthreads();
+
+    // Slice of this lane's read inside S (LDS copy or the global array).
+    const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : (read_word + sbeg);
+    const uint32_t my_off = so - sbeg;
+    const uint32_t my_k = se - so;
+
+    auto bit = [&](uint32_t pos) -> bool { return (pos <= m.max_pos) && ((bitmap[pos >> 5] >> (pos & 31)) & 1u); };
+
+    // c for "no mutation anywhere on the path": every non-missing entry is
+    // compared with its own reference allele (usher_mapper.cpp:302-305,342).
+    int c = 0;
+    for (uint32_t j = 0; j < my_k; j++) {
+        uint32_t s = S[my_off + j];
+        if (!rw_missing(s)) c += ((rw_mut(s) & rw_ref(s)) == 0) ? 1 : 0;
+    }
+
+    const uint32_t b0 = chunk * blocks_per_chunk;
+    const uint32_t b1 = min(m.NB, b0 + blocks_per_chunk);
+
+    // ---- state at the chunk start: enter words of every node still open there -
+    {
+        const uint32_t cpi = b0 / m.cp_stride;
+        const uint32_t e0 = m.cp_off[cpi], e1 = m.cp_off[cpi + 1];
+        for (uint32_t e = e0; e < e1; e += 64) {
+            const bool valid = e + lane < e1;
+            const uint32_t w = valid ? m.cp_word[e + lane] : 0;
+            unsigned long long hm = __ballot(valid && bit(w_pos(w)));
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+                const uint32_t s = find_entry(S, my_off, my_k, w_pos(wl));
+                if (s != NONE) c += enter_delta(wl, s);
+            }
+        }
+    }
+
+    int bs = 0x7FFFFFFF;        // best score of this lane's read
+    uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
+    uint32_t cnt = 0;           // eligible nodes attaining bs
+
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t e0 = m.blk_eoff[b], e1 = m.blk_eoff[b + 1];
+        const uint32_t n0 = m.blk_node0[b];
+        const uint32_t nn = m.blk_node0[b + 1] - n0;
+
+        // ---- does any read of the tile list a position mutated in this block? --
+        bool anyhit = false;
+        for (uint32_t e = e0; e < e1; e += 128) {
+            const bool v0 = e + lane < e1, v1 = e + 64 + lane < e1;
+            const uint32_t w0 = v0 ? m.ev_word[e + lane] : 0;
+            const uint32_t w1 = v1 ? m.ev_word[e + 64 + lane] : 0;
+            const bool h = (v0 && bit(w_pos(w0))) || (v1 && bit(w_pos(w1)));
+            if (__ballot(h)) anyhit = true;
+        }
+
+        unsigned long long slow = 0;
+        if (anyhit) {
+            // which reads: every lane looks the hit positions up in its own read
+            for (uint32_t e = e0; e < e1; e += 64) {
+                const bool valid = e + lane < e1;
+                const uint32_t w = valid ? m.ev_word[e + lane] : 0;
+                unsigned long long hm = __ballot(valid && bit(w_pos(w)));
+                while (hm) {
+                    const int l = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+                    const bool found = have && (find_entry(S, my_off, my_k, w_pos(wl)) != NONE);
+                    slow |= __ballot(found);
+                }
+            }
+        }
+
+        // ---- summary update for every read without an event in this block ------
+        {
+            const BlkSum sum = m.blk_sum[b];
+            if (sum.base != SCORE_INF_DEV && !((slow >> lane) & 1ull)) {
+                const int s = sum.base + c;
+                if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
+                else if (s == bs) { cnt += sum.cnt; br = min(br, sum.rank); }
+            }
+        }
+
+        // ---- node-by-node evaluation for the reads with events -----------------
+        while (slow) {
+            const int r = __builtin_ctzll(slow);
+            slow &= slow - 1;
+            const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
+            const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
+            const int c_r = __builtin_amdgcn_readlane(c, r);
+            const int bs_r = __builtin_amdgcn_readlane(bs, r);
+
+            const bool nvalid = lane < nn;
+            const int64_t key = nvalid ? m.nkey[n0 + lane] : 0;
+            const uint32_t st = nvalid ? m.nstat[n0 + lane] : 0;
+            int cadd = 0, adj = 0, dcom = 0, net = 0;
+            bool touched = false;
+
+            for (uint32_t e = e0; e < e1; e += 64) {
+                const bool valid = e + lane < e1;
+                const uint32_t w = valid ? m.ev_word[e + lane] : 0;
+                const uint32_t mt = valid ? (uint32_t)m.ev_meta[e + lane] : 0;
+                const uint32_t sw = (valid && bit(w_pos(w))) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
+                unsigned long long hm = __ballot(sw != NONE);
+                while (hm) {
+                    const int l = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+                    const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mt, l);
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)sw, l);
+                    const int delta = enter_delta(wl, sl);
+                    const uint32_t o = ml & EV_OFF_MASK_DEV;
+                    if (ml & EV_EXIT_DEV) {
+                        // the subtree that carried wl ended just before node o
+                        cadd += (lane >= o) ? -delta : 0;
+                        net -= delta;
+                    } else {
+                        if (!(ml & EV_LEAF_DEV)) {
+                            // descendants of node o see the new allele; the root also
+                            // scores itself with its own mutations applied (usher_mapper.cpp:266-271)
+                            const bool is_root = (n0 + o) == 0;
+                            cadd += (lane > o || (is_root && lane == o)) ? delta : 0;
+                            net += delta;
+                        }
+                        if (lane == o) {
+                            touched = true;
+                            own_adjust(wl, sl, adj, dcom);
+                        }
+                    }
+                }
+            }
+
+            const int base = (int)(key >> 32);
+            const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
+            const uint32_t nmut = st & NS_CNT_MASK_DEV;
+            const uint32_t ncom0 = (st >> 14) & NS_CNT_MASK_DEV;
+            const bool leaf = st & NS_LEAF_DEV, masked = st & NS_MASKED_DEV, root = st & NS_ROOT_DEV;
+            bool elig;
+            int score = base + c_r + cadd;
+            if (root) elig = true;
+            else if (masked) elig = false;
+            else if (touched) {
+                score += adj;
+                const int ncom = (int)ncom0 + dcom;
+                elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
+            } else elig = st & NS_ELIG0_DEV;
+            elig = elig && nvalid;
+
+            if (__ballot(elig && score <= bs_r)) {
+                const int smin = wave_min_i32(elig ? score : 0x7FFFFFFF);
+                const bool at_min = elig && score == smin;
+                const uint32_t cntb = (uint32_t)__popcll(__ballot(at_min));
+                const uint32_t rmin = wave_min_u32(at_min ? rank : 0xFFFFFFFFu);
+                if (lane == (uint32_t)r) {
+                    if (smin < bs) { bs = smin; br = rmin; cnt = cntb; }
+                    else if (smin == bs) { cnt += cntb; br = min(br, rmin); }
+                }
+            }
+            if (lane == (uint32_t)r) c += net;
+        }
+    }
+
+    if (have) {
+        const size_t o = (size_t)chunk * n_reads + r0 + lane;
+        part_score[o] = bs;
+        part_rank[o] = br;
+        part_cnt[o] = cnt;
+    }
+}
+
+// -----------------------------------------------------------------------------
+// finalize: combine the chunks of a read, map the winner back to the
+// reference's BFS index and recompute its has_unique flag
+// (usher_mapper.cpp:184,199,262,472,492).
+// -----------------------------------------------------------------------------
+__global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
+                           const uint32_t* __restrict__ read_word, uint32_t n_reads, uint32_t nchunks,
+                           const int32_t* __restrict__ part_score, const uint32_t* __restrict__ part_rank,
+                           const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ best_bfs_j,
+                           int32_t* __restrict__ score, uint32_t* __restrict__ num_best,
+                           uint32_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int bs = 0x7FFFFFFF;
+    uint32_t br = 0xFFFFFFFFu, cnt = 0;
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        const size_t o = (size_t)ch * n_reads + r;
+        const int s = part_score[o];
+        if (s < bs) { bs = s; br = part_rank[o]; cnt = part_cnt[o]; }
+        else if (s == bs) { cnt += part_cnt[o]; br = min(br, part_rank[o]); }
+    }
+    const uint32_t d = m.rank2dfs[br];
+    const uint32_t st = m.nstat[d];
+    uint32_t hu = 0;
+    if (!(st & NS_ROOT_DEV)) {
+        if (st & NS_MASKED_DEV) hu = 1;
+        else {
+            int ncom = (int)((st >> 14) & NS_CNT_MASK_DEV);
+            int dummy = 0;
+            const uint32_t so = read_off[r], k = read_off[r + 1] - so;
+            for (uint32_t w = m.node_woff[d]; w < m.node_woff[d + 1]; w++) {
+                const uint32_t tw = m.words[w];
+                const uint32_t s = find_entry(read_word, so, k, w_pos(tw));
+                if (s != NONE) own_adjust(tw, s, dummy, ncom);
+            }
+            hu = (ncom < (int)(st & NS_CNT_MASK_DEV)) ? 1u : 0u;
+        }
+    }
+    if (best_bfs_j) best_bfs_j[r] = m.dfs2bfs[d];
+    if (score) score[r] = bs;
+    if (num_best) num_best[r] = cnt;
+    if (flags) flags[r] = hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+}
+
+// -----------------------------------------------------------------------------
+// launchers (called from capi.cpp)
+// -----------------------------------------------------------------------------
+hipError_t launch_tile_max_entries(const uint32_t* d_read_off, uint32_t n_reads, uint32_t T,
+                                   uint32_t* d_out_max, hipStream_t stream) {
+    uint32_t ntiles = (n_reads + T - 1) / T;
+    uint32_t blocks = (ntiles + 255) / 256;
+    hipLaunchKernelGGL(k_tile_max_entries, dim3(blocks), dim3(256), 0, stream, d_read_off, n_reads, T, d_out_max);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                        uint32_t n_reads, uint32_t T, uint32_t ntiles, uint32_t nchunks,
+                        uint32_t blocks_per_chunk, bool s_in_lds, uint32_t lds_bytes, int32_t* part_score,
+                        uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream) {
+    const dim3 grid(ntiles * nchunks), block(64);
+    if (s_in_lds)
+        hipLaunchKernelGGL(k_sweep<true>, grid, block, lds_bytes, stream, m, d_read_off, d_read_word, n_reads, T,
+                           ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+    else
+        hipLaunchKernelGGL(k_sweep<false>, grid, block, lds_bytes, stream, m, d_read_off, d_read_word, n_reads, T,
+                           ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                           uint32_t n_reads, uint32_t nchunks, const int32_t* part_score,
+                           const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
+                           int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
+    const uint32_t blocks = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, m, d_read_off, d_read_word, n_reads,
+                       nchunks, part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags);
+    return hipGetLastError();
+}
+
+hipError_t sweep_set_max_lds(uint32_t bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace wepp
