@@ -135,11 +135,15 @@ int wepp_place_batch_device(wepp_mat_t *mat, const uint32_t *d_read_off, const u
  * default 64).  Affects speed only, never results. */
 int wepp_mat_set_tile_reads(wepp_mat_t *mat, uint32_t reads_per_tile);
 
-/* Timing of the dominant kernel of the most recent wepp_place_batch_device /
- * wepp_place_batch call, measured with HIP events on the launch stream
- * (blocks until that work has finished).  sweep_ms = the sweep kernel only;
- * passes = event-stream sweeps it performed (tiles x 1). */
-int wepp_mat_last_timing(wepp_mat_t *mat, float *sweep_ms, uint64_t *passes, uint64_t *bytes_per_pass);
+/* Timing of the dominant kernel (the sweep), measured with HIP events recorded
+ * on the launch stream around every sweep launch since the handle was created
+ * or wepp_mat_timing_reset() was called (the most recent 64 launches are kept).
+ * Blocks until those launches have finished.  mean_sweep_ms = mean duration of
+ * one sweep launch; passes = event-stream sweeps one launch performs (= tiles);
+ * bytes_per_pass = algorithmic bytes of one sweep (wepp_mat_stats.stream_bytes). */
+int wepp_mat_timing_reset(wepp_mat_t *mat);
+int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_launches, uint64_t *passes,
+                         uint64_t *bytes_per_pass);
 
 const char *wepp_last_error(void);
 

@@ -571,3 +571,140 @@ int oracle_place_batch(const otree *T, uint32_t n_reads, const uint32_t *read_of
     free(th); free(jobs);
     return 0;
 }
+
+/* ---- node-parallel driver: the reference's parallelisation ---------------- *
+ * tbb::parallel_for over the node range (usher_common.cpp:386-411): every
+ * thread owns a contiguous range of BFS indices and runs pass 1 for sample
+ * after sample with a PRIVATE best state; the private states are merged with
+ * the same rule mapper2_body applies under its lock (usher_mapper.cpp:466-498),
+ * which gives the result of the serial loop (the result is independent of the
+ * evaluation order).  Pass 2 (usher_common.cpp:413-446)
+ * then runs serially over the merged best_j_vec, as in the reference.  Used as
+ * the timed CPU baseline of bench.py. */
+typedef struct {
+    const otree *T;
+    const uint32_t *read_off;
+    const omut *S_all;
+    uint32_t n_reads;
+    size_t k_lo, k_hi;
+    o_best_state *st;        /* [n_reads] private states of this thread */
+} np_job;
+
+static void np_state_init(o_best_state *st, const otree *T, int nS, uint8_t *nhu) {
+    st->best_node_num_leaves = 0;
+    st->best_set_difference = nS + T->root->nmuts + 1;
+    st->best_j = 0;
+    st->has_unique = 0;
+    st->node_has_unique = nhu;
+    st->best_j_vec.v = NULL; st->best_j_vec.n = 0; st->best_j_vec.cap = 0;
+    jvec_push(&st->best_j_vec, 0);
+    st->num_best = 1;
+    st->best_node = T->root;
+}
+
+static void *np_worker(void *p) {
+    np_job *jb = (np_job *)p;
+    anc_vec scratch = {0, 0, 0, 0};
+    uint8_t *nhu = (uint8_t *)calloc((size_t)jb->T->n, 1);
+    for (uint32_t r = 0; r < jb->n_reads; r++) {
+        const omut *S = jb->S_all + jb->read_off[r];
+        int nS = (int)(jb->read_off[r + 1] - jb->read_off[r]);
+        o_best_state *st = &jb->st[r];
+        np_state_init(st, jb->T, nS, nhu);
+        for (size_t k = jb->k_lo; k < jb->k_hi; k++) {
+            o_mapper2_input inp;
+            fill_input(&inp, jb->T, st, S, nS, k, NULL);
+            o_mapper2_body(&inp, 0, &scratch);
+        }
+        st->node_has_unique = NULL;
+    }
+    free(nhu);
+    free(scratch.v); free(scratch.pos);
+    return NULL;
+}
+
+int oracle_place_batch_nodepar(const otree *T, uint32_t n_reads, const uint32_t *read_off, const int32_t *r_pos,
+                               const uint8_t *r_ref, const uint8_t *r_mut, const uint8_t *r_missing,
+                               oracle_result *out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > T->n) nthreads = T->n;
+    uint32_t nw = read_off[n_reads];
+    omut *S_all = (omut *)calloc(nw ? nw : 1, sizeof(omut));
+    for (uint32_t i = 0; i < nw; i++) {
+        S_all[i].position = r_pos[i];
+        S_all[i].ref_nuc = (int8_t)r_ref[i];
+        S_all[i].par_nuc = (int8_t)r_ref[i];
+        S_all[i].mut_nuc = (int8_t)r_mut[i];
+        S_all[i].is_missing = r_missing[i];
+    }
+    np_job *jobs = (np_job *)calloc((size_t)nthreads, sizeof(np_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].T = T; jobs[t].read_off = read_off; jobs[t].S_all = S_all; jobs[t].n_reads = n_reads;
+        jobs[t].k_lo = (size_t)((uint64_t)T->n * (uint64_t)t / (uint64_t)nthreads);
+        jobs[t].k_hi = (size_t)((uint64_t)T->n * (uint64_t)(t + 1) / (uint64_t)nthreads);
+        jobs[t].st = (o_best_state *)calloc(n_reads ? n_reads : 1, sizeof(o_best_state));
+    }
+    if (nthreads == 1) np_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, np_worker, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    anc_vec scratch = {0, 0, 0, 0};
+    uint8_t *nhu = (uint8_t *)calloc((size_t)T->n, 1);
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const omut *S = S_all + read_off[r];
+        int nS = (int)(read_off[r + 1] - read_off[r]);
+        /* merge the private states (usher_mapper.cpp:466-498) */
+        o_best_state m;
+        np_state_init(&m, T, nS, nhu);
+        for (int t = 0; t < nthreads; t++) {
+            o_best_state *s = &jobs[t].st[r];
+            /* a thread whose range never beat the initial value keeps the
+             * initial (root, j=0) placeholder, which must not be merged */
+            int is_initial = (s->best_set_difference == nS + T->root->nmuts + 1);
+            if (!is_initial) {
+                if (s->best_set_difference < m.best_set_difference) {
+                    m.best_set_difference = s->best_set_difference;
+                    m.best_node = s->best_node; m.best_node_num_leaves = s->best_node_num_leaves;
+                    m.best_j = s->best_j; m.num_best = s->num_best; m.has_unique = s->has_unique;
+                    m.best_j_vec.n = 0;
+                    for (size_t i = 0; i < s->best_j_vec.n; i++) jvec_push(&m.best_j_vec, s->best_j_vec.v[i]);
+                } else if (s->best_set_difference == m.best_set_difference) {
+                    if ((s->best_node_num_leaves > m.best_node_num_leaves) ||
+                        ((s->best_node_num_leaves == m.best_node_num_leaves) && (m.best_j < s->best_j))) {
+                        m.best_node = s->best_node; m.best_node_num_leaves = s->best_node_num_leaves;
+                        m.best_j = s->best_j; m.has_unique = s->has_unique;
+                    }
+                    m.num_best += s->num_best;
+                    for (size_t i = 0; i < s->best_j_vec.n; i++) jvec_push(&m.best_j_vec, s->best_j_vec.v[i]);
+                }
+            }
+            free(s->best_j_vec.v);
+        }
+        /* pass 2, usher_common.cpp:413-446 */
+        m.best_set_difference += 1;
+        size_t ntmp = m.best_j_vec.n;
+        size_t *tmp_vec = (size_t *)malloc(sizeof(size_t) * (ntmp ? ntmp : 1));
+        memcpy(tmp_vec, m.best_j_vec.v, sizeof(size_t) * ntmp);
+        m.num_best = 0;
+        m.best_j_vec.n = 0;
+        for (size_t l = 0; l < ntmp; l++) {
+            o_mapper2_input inp;
+            fill_input(&inp, T, &m, S, nS, tmp_vec[l], NULL);
+            o_mapper2_body(&inp, 0, &scratch);
+        }
+        free(tmp_vec);
+        out[r].best_set_difference = m.best_set_difference;
+        out[r].num_best = (uint32_t)m.num_best;
+        out[r].best_j = (uint32_t)m.best_j;
+        out[r].best_node_id = m.best_node->id;
+        out[r].best_node_has_unique = (uint32_t)m.has_unique;
+        free(m.best_j_vec.v);
+    }
+    free(nhu);
+    free(scratch.v); free(scratch.pos);
+    for (int t = 0; t < nthreads; t++) free(jobs[t].st);
+    free(th); free(jobs); free(S_all);
+    return 0;
+}

@@ -44,6 +44,7 @@ def lib():
         L.oracle_place_sample.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
             ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(OracleResult), ctypes.c_void_p]
         L.oracle_place_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
+        L.oracle_place_batch_nodepar.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         for f in ("oracle_tree_bfs_ids", "oracle_tree_dfs_ids", "oracle_tree_num_leaves"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
@@ -110,15 +111,18 @@ class OracleTree:
             out["best_j_vec"] = np.sort(bv[: res.num_best])
         return out
 
-    def place_batch(self, reads, nthreads=1):
-        """reads: wepp_amd.Reads.  Returns dict of arrays."""
+    def place_batch(self, reads, nthreads=1, node_parallel=False):
+        """reads: wepp_amd.Reads.  Returns a structured array.  node_parallel=True
+        splits the NODE range over the threads like the reference's
+        tbb::parallel_for (usher_common.cpp:386); otherwise reads are split."""
         from wepp_amd import unpack_read_word
         R = reads.n_reads
         pos, ref, mut, miss = unpack_read_word(reads.read_word)
         if pos.size == 0:
             pos = np.zeros(1, np.int32); ref = np.zeros(1, np.uint8); mut = np.zeros(1, np.uint8); miss = np.zeros(1, np.uint8)
         res = (OracleResult * max(R, 1))()
-        lib().oracle_place_batch(self._h, R, _p(reads.read_off), _p(np.ascontiguousarray(pos)),
+        fn = lib().oracle_place_batch_nodepar if node_parallel else lib().oracle_place_batch
+        fn(self._h, R, _p(reads.read_off), _p(np.ascontiguousarray(pos)),
                                  _p(np.ascontiguousarray(ref)), _p(np.ascontiguousarray(mut)),
                                  _p(np.ascontiguousarray(miss)), ctypes.cast(res, ctypes.c_void_p), int(nthreads))
         arr = np.frombuffer(res, dtype=np.dtype([("score", "<i4"), ("num_best", "<u4"), ("best_j", "<u4"),

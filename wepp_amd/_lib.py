@@ -92,9 +92,11 @@ _SIGS = {
         [_V, _V, _V, ctypes.c_uint32, ctypes.c_uint64, _V, _V, _V, _V, _V],
     ),
     "wepp_mat_set_tile_reads": (ctypes.c_int, [_V, ctypes.c_uint32]),
+    "wepp_mat_timing_reset": (ctypes.c_int, [_V]),
     "wepp_mat_last_timing": (
         ctypes.c_int,
-        [_V, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
+        [_V, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64),
+         ctypes.POINTER(ctypes.c_uint64)],
     ),
     "wepp_last_error": (ctypes.c_char_p, []),
     "wepp_gen_tree_create": (ctypes.c_int, [ctypes.POINTER(GenTreeParams), ctypes.POINTER(_V)]),

@@ -269,12 +269,18 @@ class Mat:
         check(lib.wepp_place_batch_device(self._h, d_read_off, d_read_word, int(n_reads), int(n_read_words),
                                           d_best, d_score, d_num_best, d_flags, stream or None))
 
+    def timing_reset(self):
+        check(lib.wepp_mat_timing_reset(self._h))
+
     def last_timing(self):
+        """(mean sweep-kernel ms per launch, launches averaged, passes per launch, bytes per pass)."""
         ms = ctypes.c_float()
+        nl = ctypes.c_uint32()
         passes = ctypes.c_uint64()
         bpp = ctypes.c_uint64()
-        check(lib.wepp_mat_last_timing(self._h, ctypes.byref(ms), ctypes.byref(passes), ctypes.byref(bpp)))
-        return ms.value, passes.value, bpp.value
+        check(lib.wepp_mat_last_timing(self._h, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(passes),
+                                       ctypes.byref(bpp)))
+        return ms.value, nl.value, passes.value, bpp.value
 
     def close(self):
         if self._h:

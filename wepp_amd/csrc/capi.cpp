@@ -31,8 +31,9 @@ struct wepp_mat {
     size_t ws_bytes = 0;
     uint32_t* d_max = nullptr;
     uint32_t* h_max = nullptr;   // pinned
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    static constexpr uint32_t kRing = 64;
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    uint64_t n_timed = 0;   // sweep launches since the last timing reset
     uint64_t last_passes = 0;
 };
 
@@ -68,8 +69,10 @@ void release(wepp_mat* h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->d_max) (void)hipFree(h->d_max);
     if (h->h_max) (void)hipHostFree(h->h_max);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (uint32_t i = 0; i < wepp_mat::kRing; i++) {
+        if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
+        if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
+    }
     delete h;
 }
 
@@ -122,8 +125,10 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
 #undef UP
     e = hipMalloc((void**)&h->d_max, 16);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_max, 16, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
+        e = hipEventCreate(&h->ev0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
+    }
     if (e == hipSuccess) e = sweep_set_max_lds(160 * 1024);
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     *out = h;
@@ -198,25 +203,40 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     uint32_t* part_rank = (uint32_t*)(part_score + (size_t)nchunks * n_reads);
     uint32_t* part_cnt = part_rank + (size_t)nchunks * n_reads;
 
-    HIP_TRY(hipEventRecord(mat->ev0, stream));
+    const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
+    HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
     HIP_TRY(launch_sweep(mat->dev, d_read_off, d_read_word, n_reads, T, ntiles, nchunks, bpc, s_in_lds, lds_bytes,
                          part_score, part_rank, part_cnt, stream));
-    HIP_TRY(hipEventRecord(mat->ev1, stream));
-    mat->timed = true;
+    HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
+    mat->n_timed++;
     mat->last_passes = (uint64_t)ntiles;   // every tile sweeps the whole stream once (split over its chunks)
     HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, n_reads, nchunks, part_score, part_rank, part_cnt,
                             d_best_bfs_j, d_score, d_num_best, d_flags, stream));
     return WEPP_OK;
 }
 
-extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* sweep_ms, uint64_t* passes, uint64_t* bytes_per_pass) {
+extern "C" int wepp_mat_timing_reset(wepp_mat_t* mat) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
-    if (!mat->timed) return set_error(WEPP_EINVAL, "no placement has been launched on this handle yet");
+    mat->n_timed = 0;
+    return WEPP_OK;
+}
+
+extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint32_t* n_launches, uint64_t* passes,
+                                    uint64_t* bytes_per_pass) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    if (mat->n_timed == 0) return set_error(WEPP_EINVAL, "no placement has been launched on this handle since the last reset");
     HIP_TRY(hipSetDevice(mat->device));
-    HIP_TRY(hipEventSynchronize(mat->ev1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, mat->ev0, mat->ev1));
-    if (sweep_ms) *sweep_ms = ms;
+    const uint32_t n = (uint32_t)std::min<uint64_t>(mat->n_timed, wepp_mat::kRing);
+    double sum = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t slot = (uint32_t)((mat->n_timed - 1 - i) % wepp_mat::kRing);
+        HIP_TRY(hipEventSynchronize(mat->ev1[slot]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, mat->ev0[slot], mat->ev1[slot]));
+        sum += ms;
+    }
+    if (mean_sweep_ms) *mean_sweep_ms = (float)(sum / n);
+    if (n_launches) *n_launches = n;
     if (passes) *passes = mat->last_passes;
     if (bytes_per_pass) *bytes_per_pass = mat->stats.stream_bytes;
     return WEPP_OK;
