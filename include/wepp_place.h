@@ -43,12 +43,12 @@ extern "C" {
 /* ---- packed 32-bit words ---------------------------------------------- *
  * Sample/read entry = one element of Missing_Sample::mutations
  * (src/usher_graph.hpp:34-54, filled by src/mutation_annotated_tree.cpp:2086-2127):
- *     bits  0..19  position (0 .. 2^20-1)
+ *     bits  0..19  position (0 .. 2^20-2)
  *     bits 20..23  ref_nuc mask
  *     bits 24..27  mut_nuc mask (15 for N)
  *     bit  28      is_missing
  */
-#define WEPP_MAX_POSITION 0xFFFFFu
+#define WEPP_MAX_POSITION 0xFFFFEu
 static inline uint32_t wepp_pack_read_word(uint32_t position, uint32_t ref_nuc, uint32_t mut_nuc,
                                            uint32_t is_missing) {
     return (position & 0xFFFFFu) | ((ref_nuc & 15u) << 20) | ((mut_nuc & 15u) << 24) |
@@ -61,7 +61,9 @@ static inline uint32_t wepp_pack_read_word(uint32_t position, uint32_t ref_nuc, 
  * the single root; the children of a node are ordered by ascending id (the
  * order Tree::create_node pushes them, src/mutation_annotated_tree.cpp:865-878).
  * Node i owns mutations mut_*[mut_off[i] .. mut_off[i+1]), sorted by position
- * (the loader guarantees it, src/mutation_annotated_tree.cpp:591-594);
+ * (the loader guarantees it, src/mutation_annotated_tree.cpp:591-594), ref_nuc
+ * one-hot (src/mutation_annotated_tree.cpp:572) and the same at every mutation
+ * of a position;
  * mut_pos < 0 = masked mutation (src/mutation_annotated_tree.hpp:68-70).
  * mut_par (Mutation::par_nuc) may be NULL: the scorer never reads it
  * (src/usher_mapper.cpp:168-506 only copies it), the flattener recomputes the

@@ -9,12 +9,12 @@ INF = 0x7FFFFFFF
 SCORE_INF = 0x3FFFFFFF
 NS_CNT = 0x3FFF
 NS_LEAF, NS_MASKED, NS_ELIG0, NS_ROOT = 1 << 28, 1 << 29, 1 << 30, 1 << 31
-EV_EXIT, EV_LEAF = 64, 128
+W_EXIT, W_LEAF = 1 << 30, 1 << 31
 
 
 def _tw(w):
     w = int(w)
-    return w & 0xFFFFF, (w >> 20) & 15, (w >> 24) & 15, (w >> 28) & 15  # pos, ref, par, mut
+    return w & 0xFFFFF, 1 << ((w >> 20) & 3), (w >> 22) & 15, (w >> 26) & 15  # pos, ref mask, par, mut
 
 
 def f_state(x, tref, s):
@@ -67,7 +67,11 @@ class FlatModel:
                 c += enter_delta(w, s)
         return c
 
-    def place(self, S, b0=0, b1=None, c0=None, node_scores=None, trace_c=None):
+    n_heavy = 0
+    n_light = 0
+    verify_prune = True   # evaluate pruned blocks anyway and assert that nothing could have won
+
+    def place(self, S, b0=0, b1=None, c0=None, node_scores=None, trace_c=None, prune=True):
         """Sweep blocks [b0, b1) for one read S = [(pos, ref, mut, missing)].
         Returns (best score, best rank, count, c at the end).  node_scores
         (optional int array indexed by DFS idx) receives the -p mode value."""
@@ -82,8 +86,10 @@ class FlatModel:
             n0 = int(self.blk_node0[b])
             nn = int(self.blk_node0[b + 1]) - n0
             hits = [e for e in range(e0, e1) if (int(self.ev_word[e]) & 0xFFFFF) in Sd]
+            base, rank, sc, min_all = (int(x) for x in self.blk_sum[b])
+            if min_all >= 0x80000000:
+                min_all -= 1 << 32
             if not hits and node_scores is None:
-                base, rank, sc, _ = (int(x) for x in self.blk_sum[b])
                 if base != SCORE_INF:
                     s = base + c
                     if s < bs:
@@ -97,26 +103,35 @@ class FlatModel:
             dcom = [0] * nn
             touched = [False] * nn
             net = 0
+            H = 0
             for e in hits:
-                w = self.ev_word[e]
-                mt = int(self.ev_meta[e])
-                s = Sd[int(w) & 0xFFFFF]
+                w = int(self.ev_word[e])
+                o = int(self.ev_meta[e]) & 63
+                s = Sd[w & 0xFFFFF]
                 d = enter_delta(w, s)
-                o = mt & 63
-                if mt & EV_EXIT:
+                if w & W_EXIT:
                     for i in range(o, nn):
                         cadd[i] -= d
                     net -= d
+                    H += abs(d)
                 else:
-                    if not (mt & EV_LEAF):
+                    if not (w & W_LEAF):
                         is_root = (n0 + o) == 0
                         for i in range(o if is_root else o + 1, nn):
                             cadd[i] += d
                         net += d
+                        H += abs(d)
+                    H += 1
                     touched[o] = True
                     a, dc = own_adjust(w, s)
                     adj[o] += a
                     dcom[o] += dc
+            pruned = bool(hits) and prune and node_scores is None and (min_all + c - H > bs)
+            self.n_heavy += 0 if (pruned or not hits) else 1
+            self.n_light += 1 if pruned else 0
+            if pruned and not self.verify_prune:
+                c += net
+                continue
             for i in range(nn):
                 key = int(self.nkey[n0 + i])
                 st = int(self.nstat[n0 + i])
@@ -136,7 +151,9 @@ class FlatModel:
                     elig = bool(st & NS_ELIG0)
                 if node_scores is not None:
                     node_scores[n0 + i] = score if elig else score + 1   # usher_mapper.cpp:500-505
-                if elig:
+                if elig and pruned:
+                    assert score > bs, "pruning bound violated"
+                if elig and not pruned:
                     if score < bs:
                         bs, br, cnt = score, rank, 1
                     elif score == bs:

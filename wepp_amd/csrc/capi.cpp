@@ -108,8 +108,8 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     h->stats.n_leaves = f.n_leaves;
     h->stats.max_depth = f.max_depth;
     h->stats.max_position = f.max_pos;
-    // one sweep reads every event word plus the per-block offsets and summary
-    h->stats.stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(BlkSum) + 8);
+    // one sweep reads every event word plus the per-block event offset and summary
+    h->stats.stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(BlkSum) + 4);
     h->ncp = (uint32_t)f.cp_off.size() - 1;
 
     DevMAT& d = h->dev;

@@ -12,7 +12,8 @@ namespace wepp {
 constexpr int32_t SCORE_INF_DEV = SCORE_INF;
 constexpr uint32_t NS_CNT_MASK_DEV = NS_CNT_MASK;
 constexpr uint32_t NS_LEAF_DEV = NS_LEAF, NS_MASKED_DEV = NS_MASKED, NS_ELIG0_DEV = NS_ELIG0, NS_ROOT_DEV = NS_ROOT;
-constexpr uint32_t EV_OFF_MASK_DEV = EV_OFF_MASK, EV_EXIT_DEV = EV_EXIT, EV_LEAF_DEV = EV_LEAF;
+constexpr uint32_t EV_OFF_MASK_DEV = EV_OFF_MASK;
+constexpr uint32_t W_EXIT_DEV = W_EXIT, W_LEAF_DEV = W_LEAF, W_PAD_DEV = W_PAD;
 constexpr uint32_t WEPP_FLAG_HAS_UNIQUE_DEV = WEPP_FLAG_HAS_UNIQUE;
 
 struct DevMAT {

@@ -60,7 +60,7 @@ extern "C" int wepp_flat_scalars(const wepp_flat_t* flat, wepp_mat_stats* stats,
         stats->n_leaves = f.n_leaves;
         stats->max_depth = f.max_depth;
         stats->max_position = f.max_pos;
-        stats->stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(wepp::BlkSum) + 8);
+        stats->stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(wepp::BlkSum) + 4);
     }
     if (cp_stride) *cp_stride = f.cp_stride;
     return WEPP_OK;

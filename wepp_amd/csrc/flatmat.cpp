@@ -143,8 +143,9 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
                 if (d == 0 && (t.mut_ref[k] & 15) != (t.mut_mut[k] & 15)) root_masked_cost[0]++;
                 continue;
             }
-            if ((uint32_t)p > WEPP_MAX_POSITION) { err = "mutation position exceeds 2^20-1"; return WEPP_ELIMIT; }
+            if ((uint32_t)p > WEPP_MAX_POSITION) { err = "mutation position exceeds 2^20-2"; return WEPP_ELIMIT; }
             if ((t.mut_mut[k] & 15) == 0 || (t.mut_ref[k] & 15) == 0) { err = "zero nucleotide mask on a non-masked mutation"; return WEPP_EINVAL; }
+            if ((t.mut_ref[k] & 15) & ((t.mut_ref[k] & 15) - 1)) { err = "ref_nuc must be a single nucleotide (position " + std::to_string(p) + ")"; return WEPP_EINVAL; }
             max_pos = std::max(max_pos, (uint32_t)p);
             nm++;
         }
@@ -187,7 +188,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
                 if (refm[p] == 0) refm[p] = (uint8_t)ref;
                 else if (refm[p] != ref) { err = "inconsistent ref_nuc at position " + std::to_string(p); return WEPP_EINVAL; }
                 uint32_t par = state[p];
-                f.words[w] = w_pack((uint32_t)p, ref, par, mut);
+                f.words[w] = w_pack((uint32_t)p, (uint32_t)__builtin_ctz(ref), par, mut);
                 undo[w] = (uint8_t)par;
                 state[p] = (uint8_t)mut;
                 dcur += (int32_t)cost0(mut, ref) - (int32_t)cost0(par, ref);
@@ -239,7 +240,8 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
         evcnt[d] += nm;
         if (!(f.nstat[d] & NS_LEAF) && f.dfs_end[d] + 1 < N) evcnt[f.dfs_end[d] + 1] += nm;
     }
-    // blocks
+    // blocks: <=64 nodes and <=128 events; the event count of a block is padded
+    // to an even number so that every lane can fetch two words with one 8-byte load
     f.blk_node0.clear();
     f.blk_eoff.clear();
     {
@@ -255,7 +257,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
                 nn++;
                 d++;
             }
-            eoff += ne;
+            eoff += ne + (ne & 1);
             if (eoff >= 0xFFFFFFF0ull) { err = "too many sweep events"; return WEPP_ELIMIT; }
         }
         f.NB = (uint32_t)f.blk_node0.size();
@@ -263,50 +265,63 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
         f.blk_eoff.push_back((uint32_t)eoff);
         f.E = eoff;
     }
-    // per-position event offsets, then fill
+    // fill: events of a block in DFS-position order (exits of a position first)
     {
-        std::vector<uint32_t> epos(N + 1, 0);
-        for (uint32_t d = 0; d < N; d++) epos[d + 1] = epos[d] + evcnt[d];
-        std::vector<uint32_t> fill(epos.begin(), epos.end() - 1);
-        f.ev_word.assign(f.E, 0);
+        f.ev_word.assign(f.E, W_PAD);
         f.ev_meta.assign(f.E, 0);
-        // block index of each node is implicit: offset within block = d - blk_node0[b]
-        uint32_t b = 0;
-        std::vector<uint32_t> blk_of;  // only needed for exit placement: compute by scan
-        blk_of.resize(N);
-        for (uint32_t d = 0; d < N; d++) {
-            while (f.blk_node0[b + 1] <= d) b++;
-            blk_of[d] = b;
-        }
-        for (uint32_t d = 0; d < N; d++) {
-            // the root scores itself with its own mutations applied, so its enter
-            // events are never flagged EV_LEAF (single-node tree)
-            bool leaf = (f.nstat[d] & NS_LEAF) && d != 0;
-            uint32_t off = d - f.blk_node0[blk_of[d]];
-            for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
-                uint32_t e = fill[d]++;
-                f.ev_word[e] = f.words[w];
-                f.ev_meta[e] = (uint8_t)(off | (leaf ? EV_LEAF : 0));
+        std::vector<uint32_t> blk_of(N);
+        {
+            uint32_t b = 0;
+            for (uint32_t d = 0; d < N; d++) {
+                while (f.blk_node0[b + 1] <= d) b++;
+                blk_of[d] = b;
             }
+        }
+        // fill[x] = next free event slot for position x
+        std::vector<uint32_t> fill(N, 0);
+        {
+            uint32_t b = 0;
+            uint32_t cur = 0;
+            for (uint32_t d = 0; d < N; d++) {
+                if (blk_of[d] != b || d == 0) { b = blk_of[d]; cur = f.blk_eoff[b]; }
+                fill[d] = cur;
+                cur += evcnt[d];
+            }
+        }
+        // pass 1: exit events (reserve the first slots of each position)
+        for (uint32_t d = 0; d < N; d++) {
             if (!(f.nstat[d] & NS_LEAF) && f.dfs_end[d] + 1 < N) {
                 uint32_t x = f.dfs_end[d] + 1;
                 uint32_t xoff = x - f.blk_node0[blk_of[x]];
                 for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
                     uint32_t e = fill[x]++;
-                    f.ev_word[e] = f.words[w];
-                    f.ev_meta[e] = (uint8_t)(xoff | EV_EXIT);
+                    f.ev_word[e] = f.words[w] | W_EXIT;
+                    f.ev_meta[e] = (uint8_t)xoff;
                 }
             }
         }
+        // pass 2: enter events
+        for (uint32_t d = 0; d < N; d++) {
+            // the root scores itself with its own mutations applied, so its enter
+            // events are never flagged W_LEAF (single-node tree)
+            bool leaf = (f.nstat[d] & NS_LEAF) && d != 0;
+            uint32_t off = d - f.blk_node0[blk_of[d]];
+            for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
+                uint32_t e = fill[d]++;
+                f.ev_word[e] = f.words[w] | (leaf ? W_LEAF : 0);
+                f.ev_meta[e] = (uint8_t)off;
+            }
+        }
     }
-    // block summaries over statically eligible nodes
-    f.blk_sum.assign(f.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, 0});
+    // block summaries
+    f.blk_sum.assign(f.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF});
     for (uint32_t b = 0; b < f.NB; b++) {
-        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, 0};
+        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF};
         for (uint32_t d = f.blk_node0[b]; d < f.blk_node0[b + 1]; d++) {
-            if (!(f.nstat[d] & NS_ELIG0)) continue;
             int32_t bs = (int32_t)(f.nkey[d] >> 32);
             uint32_t rk = (uint32_t)(f.nkey[d] & 0xFFFFFFFFll);
+            s.min_all = std::min(s.min_all, bs);
+            if (!(f.nstat[d] & NS_ELIG0)) continue;
             if (bs < s.base) { s.base = bs; s.rank = rk; s.cnt = 1; }
             else if (bs == s.base) { s.cnt++; s.rank = std::min(s.rank, rk); }
         }

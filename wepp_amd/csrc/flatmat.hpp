@@ -16,15 +16,24 @@
 
 namespace wepp {
 
-// ---- packed tree mutation word: pos:20 | ref:4 | par:4 | mut:4 -------------
-// `par` is the TRUE allele state of the parent genotype at this position
-// (0 = no mutation above on the root path), recomputed by the flattener;
-// Mutation::par_nuc of the reference (mutation_annotated_tree.hpp:48) is never
-// read by the scorer.
+// ---- packed tree mutation word: pos:20 | ref:2 | par:4 | mut:4 | exit | leaf --
+// `ref` is the INDEX (0..3) of the one-hot reference nucleotide (the loader
+// builds ref_nuc as 1 << idx, mutation_annotated_tree.cpp:572).  `par` is the
+// TRUE allele state of the parent genotype at this position (0 = no mutation
+// above on the root path), recomputed by the flattener; Mutation::par_nuc of
+// the reference (mutation_annotated_tree.hpp:48) is never read by the scorer.
+// The two flag bits are only set on sweep-stream events.
 constexpr uint32_t W_POS_MASK = 0xFFFFFu;
-inline uint32_t w_pack(uint32_t pos, uint32_t ref, uint32_t par, uint32_t mut) {
-    return (pos & W_POS_MASK) | ((ref & 15u) << 20) | ((par & 15u) << 24) | ((mut & 15u) << 28);
+constexpr uint32_t W_EXIT = 1u << 30;   // event closes the subtree of the node that carries the word
+constexpr uint32_t W_LEAF = 1u << 31;   // enter event of a leaf: no other node sees the allele
+constexpr uint32_t W_PAD = 0x000FFFFFu; // padding event (position 0xFFFFF is reserved)
+inline uint32_t w_pack(uint32_t pos, uint32_t ref_idx, uint32_t par, uint32_t mut) {
+    return (pos & W_POS_MASK) | ((ref_idx & 3u) << 20) | ((par & 15u) << 22) | ((mut & 15u) << 26);
 }
+inline uint32_t w_pos(uint32_t w) { return w & W_POS_MASK; }
+inline uint32_t w_refmask(uint32_t w) { return 1u << ((w >> 20) & 3u); }
+inline uint32_t w_par(uint32_t w) { return (w >> 22) & 15u; }
+inline uint32_t w_mut(uint32_t w) { return (w >> 26) & 15u; }
 
 // ---- per-node static word ---------------------------------------------------
 // nmut:14 | ncommon0:14 | leaf | masked | elig0 | root
@@ -32,17 +41,17 @@ constexpr uint32_t NS_CNT_MASK = 0x3FFFu;
 constexpr uint32_t NS_LEAF = 1u << 28, NS_MASKED = 1u << 29, NS_ELIG0 = 1u << 30, NS_ROOT = 1u << 31;
 constexpr int32_t SCORE_INF = 0x3FFFFFFF;
 
-// ---- sweep-stream event meta byte: off:6 | exit | leaf ----------------------
-constexpr uint8_t EV_OFF_MASK = 63, EV_EXIT = 64, EV_LEAF = 128;
+// ---- sweep-stream event meta byte: offset of the event's node in its block ---
+constexpr uint8_t EV_OFF_MASK = 63;
 
 constexpr uint32_t BLK_MAX_NODES = 64;    // one node per lane on the slow path
-constexpr uint32_t BLK_MAX_EVENTS = 128;  // two event words per lane per load
+constexpr uint32_t BLK_MAX_EVENTS = 128;  // two event words per lane per load (blocks are padded to an even count)
 
 struct BlkSum {          // read-independent summary of one sweep block
     int32_t base;        // min static score over statically eligible nodes (SCORE_INF if none)
     uint32_t rank;       // tie-break rank of that minimum
     uint32_t cnt;        // number of statically eligible nodes attaining `base`
-    uint32_t pad;
+    int32_t min_all;     // min static score over ALL nodes of the block (pruning bound)
 };
 
 struct FlatMAT {

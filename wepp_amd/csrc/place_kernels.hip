@@ -31,10 +31,12 @@ namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 // ---- word field helpers ------------------------------------------------------
+// tree / event word: pos:20 | ref idx:2 | par:4 | mut:4 | exit | leaf (flatmat.hpp)
+// read word:         pos:20 | ref:4 | mut:4 | missing           (wepp_place.h)
 __device__ __forceinline__ uint32_t w_pos(uint32_t w) { return w & 0xFFFFFu; }
-__device__ __forceinline__ uint32_t tw_ref(uint32_t w) { return (w >> 20) & 15u; }
-__device__ __forceinline__ uint32_t tw_par(uint32_t w) { return (w >> 24) & 15u; }
-__device__ __forceinline__ uint32_t tw_mut(uint32_t w) { return (w >> 28) & 15u; }
+__device__ __forceinline__ uint32_t tw_ref(uint32_t w) { return 1u << ((w >> 20) & 3u); }
+__device__ __forceinline__ uint32_t tw_par(uint32_t w) { return (w >> 22) & 15u; }
+__device__ __forceinline__ uint32_t tw_mut(uint32_t w) { return (w >> 26) & 15u; }
 __device__ __forceinline__ uint32_t rw_ref(uint32_t w) { return (w >> 20) & 15u; }
 __device__ __forceinline__ uint32_t rw_mut(uint32_t w) { return (w >> 24) & 15u; }
 __device__ __forceinline__ uint32_t rw_missing(uint32_t w) { return (w >> 28) & 1u; }
@@ -197,124 +199,154 @@ __global__ __launch_bounds__(64) void k_sweep(DevMAT m, const uint32_t* __restri
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
 
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t e0 = m.blk_eoff[b], e1 = m.blk_eoff[b + 1];
+    // ---- node-by-node evaluation of block b for read r (lane = node) ----------
+    auto heavy_eval = [&](uint32_t b, uint32_t e0, uint32_t e1, int r) {
         const uint32_t n0 = m.blk_node0[b];
         const uint32_t nn = m.blk_node0[b + 1] - n0;
-
-        // ---- does any read of the tile list a position mutated in this block? --
-        bool anyhit = false;
-        for (uint32_t e = e0; e < e1; e += 128) {
-            const bool v0 = e + lane < e1, v1 = e + 64 + lane < e1;
-            const uint32_t w0 = v0 ? m.ev_word[e + lane] : 0;
-            const uint32_t w1 = v1 ? m.ev_word[e + 64 + lane] : 0;
-            const bool h = (v0 && bit(w_pos(w0))) || (v1 && bit(w_pos(w1)));
-            if (__ballot(h)) anyhit = true;
-        }
-
-        unsigned long long slow = 0;
-        if (anyhit) {
-            // which reads: every lane looks the hit positions up in its own read
-            for (uint32_t e = e0; e < e1; e += 64) {
-                const bool valid = e + lane < e1;
-                const uint32_t w = valid ? m.ev_word[e + lane] : 0;
-                unsigned long long hm = __ballot(valid && bit(w_pos(w)));
-                while (hm) {
-                    const int l = __builtin_ctzll(hm);
-                    hm &= hm - 1;
-                    const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-                    const bool found = have && (find_entry(S, my_off, my_k, w_pos(wl)) != NONE);
-                    slow |= __ballot(found);
-                }
-            }
-        }
-
-        // ---- summary update for every read without an event in this block ------
-        {
-            const BlkSum sum = m.blk_sum[b];
-            if (sum.base != SCORE_INF_DEV && !((slow >> lane) & 1ull)) {
-                const int s = sum.base + c;
-                if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
-                else if (s == bs) { cnt += sum.cnt; br = min(br, sum.rank); }
-            }
-        }
-
-        // ---- node-by-node evaluation for the reads with events -----------------
-        while (slow) {
-            const int r = __builtin_ctzll(slow);
-            slow &= slow - 1;
-            const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
-            const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
-            const int c_r = __builtin_amdgcn_readlane(c, r);
-            const int bs_r = __builtin_amdgcn_readlane(bs, r);
-
-            const bool nvalid = lane < nn;
-            const int64_t key = nvalid ? m.nkey[n0 + lane] : 0;
-            const uint32_t st = nvalid ? m.nstat[n0 + lane] : 0;
-            int cadd = 0, adj = 0, dcom = 0, net = 0;
-            bool touched = false;
-
-            for (uint32_t e = e0; e < e1; e += 64) {
-                const bool valid = e + lane < e1;
-                const uint32_t w = valid ? m.ev_word[e + lane] : 0;
-                const uint32_t mt = valid ? (uint32_t)m.ev_meta[e + lane] : 0;
-                const uint32_t sw = (valid && bit(w_pos(w))) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
-                unsigned long long hm = __ballot(sw != NONE);
-                while (hm) {
-                    const int l = __builtin_ctzll(hm);
-                    hm &= hm - 1;
-                    const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-                    const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mt, l);
-                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)sw, l);
-                    const int delta = enter_delta(wl, sl);
-                    const uint32_t o = ml & EV_OFF_MASK_DEV;
-                    if (ml & EV_EXIT_DEV) {
-                        // the subtree that carried wl ended just before node o
-                        cadd += (lane >= o) ? -delta : 0;
-                        net -= delta;
-                    } else {
-                        if (!(ml & EV_LEAF_DEV)) {
-                            // descendants of node o see the new allele; the root also
-                            // scores itself with its own mutations applied (usher_mapper.cpp:266-271)
-                            const bool is_root = (n0 + o) == 0;
-                            cadd += (lane > o || (is_root && lane == o)) ? delta : 0;
-                            net += delta;
-                        }
-                        if (lane == o) {
-                            touched = true;
-                            own_adjust(wl, sl, adj, dcom);
-                        }
+        const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
+        const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
+        const int c_r = __builtin_amdgcn_readlane(c, r);
+        const int bs_r = __builtin_amdgcn_readlane(bs, r);
+        const bool nvalid = lane < nn;
+        const int64_t key = nvalid ? m.nkey[n0 + lane] : 0;
+        const uint32_t st = nvalid ? m.nstat[n0 + lane] : 0;
+        int cadd = 0, adj = 0, dcom = 0;
+        bool touched = false;
+        for (uint32_t e = e0; e < e1; e += 64) {
+            const bool valid = e + lane < e1;
+            const uint32_t w = valid ? m.ev_word[e + lane] : W_PAD_DEV;
+            const uint32_t mt = valid ? (uint32_t)m.ev_meta[e + lane] : 0;
+            const uint32_t sw = bit(w_pos(w)) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
+            unsigned long long hm = __ballot(sw != NONE);
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mt, l) & EV_OFF_MASK_DEV;
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)sw, l);
+                const int delta = enter_delta(wl, sl);
+                if (wl & W_EXIT_DEV) {
+                    // the subtree that carried wl ended just before node o
+                    cadd += (lane >= o) ? -delta : 0;
+                } else {
+                    if (!(wl & W_LEAF_DEV)) {
+                        // descendants of node o see the new allele; the root also scores
+                        // itself with its own mutations applied (usher_mapper.cpp:266-271)
+                        const bool is_root = (n0 + o) == 0;
+                        cadd += (lane > o || (is_root && lane == o)) ? delta : 0;
+                    }
+                    if (lane == o) {
+                        touched = true;
+                        own_adjust(wl, sl, adj, dcom);
                     }
                 }
             }
-
-            const int base = (int)(key >> 32);
-            const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
-            const uint32_t nmut = st & NS_CNT_MASK_DEV;
-            const uint32_t ncom0 = (st >> 14) & NS_CNT_MASK_DEV;
-            const bool leaf = st & NS_LEAF_DEV, masked = st & NS_MASKED_DEV, root = st & NS_ROOT_DEV;
-            bool elig;
-            int score = base + c_r + cadd;
-            if (root) elig = true;
-            else if (masked) elig = false;
-            else if (touched) {
-                score += adj;
-                const int ncom = (int)ncom0 + dcom;
-                elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
-            } else elig = st & NS_ELIG0_DEV;
-            elig = elig && nvalid;
-
-            if (__ballot(elig && score <= bs_r)) {
-                const int smin = wave_min_i32(elig ? score : 0x7FFFFFFF);
-                const bool at_min = elig && score == smin;
-                const uint32_t cntb = (uint32_t)__popcll(__ballot(at_min));
-                const uint32_t rmin = wave_min_u32(at_min ? rank : 0xFFFFFFFFu);
-                if (lane == (uint32_t)r) {
-                    if (smin < bs) { bs = smin; br = rmin; cnt = cntb; }
-                    else if (smin == bs) { cnt += cntb; br = min(br, rmin); }
-                }
+        }
+        const int base = (int)(key >> 32);
+        const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
+        const uint32_t nmut = st & NS_CNT_MASK_DEV;
+        const uint32_t ncom0 = (st >> 14) & NS_CNT_MASK_DEV;
+        const bool leaf = st & NS_LEAF_DEV, masked = st & NS_MASKED_DEV, root = st & NS_ROOT_DEV;
+        bool elig;
+        int score = base + c_r + cadd;
+        if (root) elig = true;
+        else if (masked) elig = false;
+        else if (touched) {
+            score += adj;
+            const int ncom = (int)ncom0 + dcom;
+            elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
+        } else elig = st & NS_ELIG0_DEV;
+        elig = elig && nvalid;
+        if (__ballot(elig && score <= bs_r)) {
+            const int smin = wave_min_i32(elig ? score : 0x7FFFFFFF);
+            const bool at_min = elig && score == smin;
+            const uint32_t cntb = (uint32_t)__popcll(__ballot(at_min));
+            const uint32_t rmin = wave_min_u32(at_min ? rank : 0xFFFFFFFFu);
+            if (lane == (uint32_t)r) {
+                if (smin < bs) { bs = smin; br = rmin; cnt = cntb; }
+                else if (smin == bs) { cnt += cntb; br = min(br, rmin); }
             }
-            if (lane == (uint32_t)r) c += net;
+        }
+    };
+
+    // ---- one block: lane = read ----------------------------------------------------
+    // w0/w1 = this lane's two words of the block's first 128 events (W_PAD beyond e1)
+    auto process_block = [&](uint32_t b, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, const BlkSum sum) {
+        int net = 0, H = 0;
+        bool touched = false;
+        // for a hit event, every read looks the position up in its own entries
+        auto light_hit = [&](uint32_t wl) {
+            const uint32_t s = have ? find_entry(S, my_off, my_k, w_pos(wl)) : NONE;
+            if (s != NONE) {
+                const int d = enter_delta(wl, s);
+                const int ad = d < 0 ? -d : d;
+                touched = true;
+                if (wl & W_EXIT_DEV) { net -= d; H += ad; }
+                else if (wl & W_LEAF_DEV) { H += 1; }
+                else { net += d; H += ad + 1; }
+            }
+        };
+        unsigned long long hm = __ballot(bit(w_pos(w0)));
+        while (hm) {
+            const int l = __builtin_ctzll(hm);
+            hm &= hm - 1;
+            light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l));
+        }
+        hm = __ballot(bit(w_pos(w1)));
+        while (hm) {
+            const int l = __builtin_ctzll(hm);
+            hm &= hm - 1;
+            light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l));
+        }
+        for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
+            const uint32_t w = (e + lane < e1) ? m.ev_word[e + lane] : W_PAD_DEV;
+            hm = __ballot(bit(w_pos(w)));
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w, l));
+            }
+        }
+        // reads without an event in this block: one summary update
+        if (!touched && sum.base != SCORE_INF_DEV) {
+            const int s = sum.base + c;
+            if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
+            else if (s == bs) { cnt += sum.cnt; br = min(br, sum.rank); }
+        }
+        // reads with events: no node of the block can reach the current best unless
+        // min_all + c - H does (|delta| per event bounds c, -1 per enter bounds the
+        // node's own adjustment); otherwise evaluate node by node
+        const bool heavy = touched && (sum.min_all + c - H <= bs);
+        unsigned long long hv = __ballot(heavy);
+        while (hv) {
+            const int r = __builtin_ctzll(hv);
+            hv &= hv - 1;
+            heavy_eval(b, e0, e1, r);
+        }
+        if (touched) c += net;
+    };
+
+    // ---- the sweep: groups of 60 blocks (their 61 event offsets sit in one
+    // vector register), four blocks' loads issued together ----------------------
+    for (uint32_t bb = b0; bb < b1; bb += 60) {
+        const uint32_t ng = min(60u, b1 - bb);
+        const uint32_t eo_vec = (lane <= ng) ? m.blk_eoff[bb + lane] : 0;
+        for (uint32_t j = 0; j < ng; j += 4) {
+            uint32_t e[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) e[q] = (uint32_t)__builtin_amdgcn_readlane((int)eo_vec, (int)min(j + q, ng));
+            uint2 ww[4];
+            BlkSum sm[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t idx = e[q] + 2 * lane;
+                ww[q] = make_uint2(W_PAD_DEV, W_PAD_DEV);
+                if (idx < e[q + 1]) ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idx);
+                sm[q] = m.blk_sum[min(bb + j + q, m.NB - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (j + q < ng) process_block(bb + j + q, e[q], e[q + 1], ww[q].x, ww[q].y, sm[q]);
         }
     }
 
