@@ -1,0 +1,196 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the
+oracle on the same inputs (bit-exact: integer work), against the committed
+golden fixtures, and -- at BASELINE.json's full size -- through
+size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fuzz_trees as ft
+import wepp_amd as w
+from wepp_amd import A, C, G, T, N, Reads, Tree
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def assert_same(res, want, ctx=""):
+    for name, got, exp in (("score", res.score, want["score"]), ("best_bfs_j", res.best_bfs_j, want["best_j"]),
+                           ("num_best", res.num_best, want["num_best"]),
+                           ("has_unique", res.has_unique, want["has_unique"])):
+        bad = np.flatnonzero(np.asarray(got) != np.asarray(exp))
+        assert bad.size == 0, f"{ctx}: {name} differs at reads {bad[:10].tolist()} (gpu {np.asarray(got)[bad[:5]]}, oracle {np.asarray(exp)[bad[:5]]})"
+
+
+def test_golden_fixtures_through_the_c_abi():
+    cases = json.load(open(os.path.join(HERE, "golden", "mapper2_cases.json")))["cases"]
+    for case in cases:
+        t = case["tree"]
+        tree = Tree(t["parent"], t["mut_off"], t["mut_pos"], t["mut_ref"], t["mut_mut"], t["mut_par"])
+        reads = Reads.from_lists([r["sample"] for r in case["results"]])
+        mat = w.Mat(tree)
+        assert mat.bfs_order().tolist() == case["bfs_ids"]
+        res = mat.place_batch(reads)
+        want = {k: np.array([r[k] for r in case["results"]]) for k in ("score", "num_best", "best_j", "has_unique")}
+        assert_same(res, want, case["name"])
+        mat.close()
+
+
+@pytest.mark.parametrize("tile", [1, 5, 64])
+def test_fuzz_trees_vs_oracle(oracle, tile):
+    rng = np.random.default_rng(100 + tile)
+    for it in range(60):
+        tree, ref = ft.random_tree(rng)
+        reads = ft.reads_from_samples([ft.random_sample(rng, ref) for _ in range(int(rng.integers(1, 150)))])
+        mat = w.Mat(tree)
+        mat.set_tile_reads(tile)
+        res = mat.place_batch(reads)
+        assert_same(res, oracle.OracleTree(tree).place_batch(reads, 8), f"fuzz {it} tile {tile}")
+        mat.close()
+
+
+def test_config1_rsv_like(oracle):
+    """BASELINE.json configs[0] substitute: RSV-A-like MAT, 150 bp reads."""
+    g = w.generate_tree(1, 50000, genome_len=15225, p_ambiguous=0.002, p_masked_node=0.0005, root_mutations=1)
+    reads = g.reads(2, 3000, p_iupac=0.05)
+    mat = w.Mat(g.tree)
+    assert_same(mat.place_batch(reads), oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count()), "config1")
+    mat.close()
+
+
+def test_config2_100k_nodes(oracle):
+    """BASELINE.json configs[1]: N=1e5, 1e5 ARTIC-like reads on the GPU; the
+    oracle checks a 1500-read subsample, the rest through tile invariance."""
+    g = w.generate_tree(11, 100000)
+    reads = g.reads(12, 100000)
+    mat = w.Mat(g.tree)
+    res = mat.place_batch(reads)
+    sub = reads.slice(0, 1500)
+    want = oracle.OracleTree(g.tree).place_batch(sub, os.cpu_count())
+    for k, arr in (("score", res.score), ("best_j", res.best_bfs_j), ("num_best", res.num_best),
+                   ("has_unique", res.has_unique)):
+        assert (arr[:1500] == want[k]).all(), k
+    mat.set_tile_reads(7)
+    res7 = mat.place_batch(reads)
+    assert (res7.score == res.score).all() and (res7.best_bfs_j == res.best_bfs_j).all()
+    assert (res7.num_best == res.num_best).all() and (res7.flags == res.flags).all()
+    mat.close()
+
+
+def test_config5_long_reads(oracle):
+    """BASELINE.json configs[4] shape: ~1.2 kb reads, 3 % substitutions, 2 % N (40-70 entries per read)."""
+    g = w.generate_tree(11, 100000)
+    reads = g.reads(24, 600, read_len=1200, amplicon_len=1200, amplicon_step=1000, p_substitution=0.03, p_n=0.02)
+    assert np.diff(reads.read_off).mean() > 30
+    mat = w.Mat(g.tree)
+    assert_same(mat.place_batch(reads), oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count()), "config5")
+    mat.close()
+
+
+def test_ambiguous_masked_root_mutations(oracle):
+    g = w.generate_tree(41, 20000, genome_len=3000, p_ambiguous=0.03, p_masked_node=0.01, root_mutations=5,
+                        p_back_mutation=0.2)
+    reads = g.reads(42, 2000, p_substitution=0.01, p_n=0.02, p_iupac=0.3)
+    mat = w.Mat(g.tree)
+    assert_same(mat.place_batch(reads), oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count()), "ambig")
+    mat.close()
+
+
+def test_edge_batches(oracle):
+    g = w.generate_tree(43, 5000, genome_len=2000)
+    mat = w.Mat(g.tree)
+    ot = oracle.OracleTree(g.tree)
+    # all reads empty, a single read, reads with positions the tree never mutates / beyond max_position
+    for reads in (Reads.from_lists([[] for _ in range(130)]),
+                  Reads.from_lists([[(5, A, C, 0)]]),
+                  Reads.from_lists([[(1999, A, N, 1), (2000, C, T, 0)], [(100000, G, A, 0)], []])):
+        assert_same(mat.place_batch(reads), ot.place_batch(reads, 2), "edge")
+    # zero reads is a no-op
+    res = mat.place_batch(Reads(np.zeros(1, np.uint32), np.zeros(0, np.uint32)))
+    assert res.score.size == 0
+    mat.close()
+
+
+def test_big_tile_falls_back_to_global_read_words(oracle):
+    """Tiles whose read words exceed the LDS budget take the S-in-global variant."""
+    g = w.generate_tree(45, 30000)
+    reads = g.reads(46, 256, read_len=5000, amplicon_len=5000, amplicon_step=4000, p_substitution=0.04, p_n=0.03)
+    assert np.diff(reads.read_off).max() * 64 > 16384
+    mat = w.Mat(g.tree)
+    assert_same(mat.place_batch(reads), oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count()), "bigtile")
+    mat.close()
+
+
+def test_rejects_unsorted_or_duplicate_read_positions():
+    g = w.generate_tree(47, 1000)
+    mat = w.Mat(g.tree)
+    with pytest.raises(w.WeppError) as ei:
+        mat.place_batch(Reads.from_lists([[(20, A, C, 0), (10, G, T, 0)]]))
+    assert ei.value.code == 1
+    with pytest.raises(w.WeppError):
+        mat.place_batch(Reads.from_lists([[(10, A, C, 0), (10, A, G, 0)]]))
+    mat.close()
+
+
+def test_device_pointer_entry_point(oracle):
+    import torch
+    g = w.generate_tree(49, 40000)
+    reads = g.reads(50, 5000)
+    mat = w.Mat(g.tree)
+    dev = torch.device("cuda", 0)
+    d_off = torch.from_numpy(reads.read_off.astype(np.int32)).to(dev)
+    d_word = torch.from_numpy(reads.read_word.astype(np.int32)).to(dev)
+    outs = [torch.zeros(reads.n_reads, dtype=torch.int32, device=dev) for _ in range(4)]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        mat.place_batch_device(d_off.data_ptr(), d_word.data_ptr(), reads.n_reads, int(reads.read_off[-1]),
+                               outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+                               stream.cuda_stream)
+    stream.synchronize()
+    want = oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count())
+    assert (outs[0].cpu().numpy().view(np.uint32) == want["best_j"]).all()
+    assert (outs[1].cpu().numpy() == want["score"]).all()
+    assert (outs[2].cpu().numpy().view(np.uint32) == want["num_best"]).all()
+    assert ((outs[3].cpu().numpy() & 1) == want["has_unique"]).all()
+    ms, n, passes, bpp = mat.last_timing()
+    assert ms > 0 and n == 1 and passes == (reads.n_reads + 63) // 64 and bpp == mat.stats.stream_bytes
+    mat.close()
+
+
+def test_full_size_properties(oracle):
+    """BASELINE.json configs[2] size (16M nodes): properties that need no
+    oracle run over the whole batch, plus the oracle on a handful of reads.
+      - tile-size invariance (T=64 vs T=16) and batch-permutation invariance,
+      - every score lies in [0, root placement score] and num_best >= 1."""
+    g = w.generate_tree(21, 16_000_000)
+    reads = g.reads(22, 200_000)
+    mat = w.Mat(g.tree)
+    res = mat.place_batch(reads)
+    mat.set_tile_reads(16)
+    sub = reads.slice(0, 20000)
+    r16 = mat.place_batch(sub)
+    assert (r16.score == res.score[:20000]).all() and (r16.best_bfs_j == res.best_bfs_j[:20000]).all()
+    assert (r16.num_best == res.num_best[:20000]).all() and (r16.flags == res.flags[:20000]).all()
+    mat.set_tile_reads(64)
+    # permutation invariance
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(20000)
+    lists = []
+    for q in perm:
+        p, rf, a, ms = sub.entries(int(q))
+        lists.append([(int(p[i]), int(rf[i]), int(a[i]), int(ms[i])) for i in range(len(p))])
+    rp = mat.place_batch(Reads.from_lists(lists))
+    assert (rp.score == res.score[perm]).all() and (rp.best_bfs_j == res.best_bfs_j[perm]).all()
+    assert (rp.num_best == res.num_best[perm]).all()
+    # scores are bounded by the root placement: len(non-missing S) (root has no mutations here)
+    cs = np.concatenate([[0], np.cumsum(((reads.read_word >> 28) & 1) == 0)])
+    k_nm = cs[reads.read_off[1:].astype(np.int64)] - cs[reads.read_off[:-1].astype(np.int64)]
+    assert (res.score <= k_nm).all() and (res.score >= 0).all() and (res.num_best >= 1).all()
+    # oracle on a few reads (node range split over all host threads)
+    few = reads.slice(0, 6)
+    want = oracle.OracleTree(g.tree).place_batch(few, os.cpu_count(), node_parallel=True)
+    assert (res.score[:6] == want["score"]).all() and (res.best_bfs_j[:6] == want["best_j"]).all()
+    assert (res.num_best[:6] == want["num_best"]).all() and (res.has_unique[:6] == want["has_unique"]).all()
+    mat.close()

@@ -1,0 +1,73 @@
+"""N>1 path on CPU: two gloo processes each place their contiguous shard of the
+reads (with the Python model of the sweep standing in for the GPU, which this
+container lacks) and rank 0 concatenates; the result must equal the unsharded
+oracle run.  Covers wepp_amd/sharding.py, the only multi-GPU logic there is
+(the path has no collective)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import wepp_amd as w
+from wepp_amd.sharding import shard_bounds
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import sweep_model as sm
+    from wepp_amd.sharding import gather_results, shard_reads
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = w.generate_tree(31, 1500, genome_len=800, p_ambiguous=0.01, root_mutations=1)
+    reads = g.reads(32, 41, p_substitution=0.004, p_n=0.01)
+    mine = shard_reads(reads, rank, world)
+    fm = sm.FlatModel(w.FlatView(g.tree))
+
+    class Local:
+        pass
+    loc = Local()
+    res = []
+    for r in range(mine.n_reads):
+        p, rf, a, ms = mine.entries(r)
+        S = [(int(p[i]), int(rf[i]), int(a[i]), int(ms[i])) for i in range(len(p))]
+        res.append(fm.place_full(S, nchunks=2))
+    loc.best_bfs_j = np.array([x["best_j"] for x in res], np.uint32)
+    loc.score = np.array([x["score"] for x in res], np.int32)
+    loc.num_best = np.array([x["num_best"] for x in res], np.uint32)
+    loc.flags = np.array([x["has_unique"] for x in res], np.uint32)
+    full = gather_results(loc, dist)
+    if rank == 0:
+        np.savez(out_path, **full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_placement_equals_unsharded(tmp_path, oracle):
+    out = str(tmp_path / "gathered.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    g = w.generate_tree(31, 1500, genome_len=800, p_ambiguous=0.01, root_mutations=1)
+    reads = g.reads(32, 41, p_substitution=0.004, p_n=0.01)
+    want = oracle.OracleTree(g.tree).place_batch(reads, 2)
+    assert (got["score"] == want["score"]).all()
+    assert (got["best_bfs_j"] == want["best_j"]).all()
+    assert (got["num_best"] == want["num_best"]).all()
+    assert (got["flags"] == want["has_unique"]).all()
