@@ -17,6 +17,16 @@ if not os.path.exists(LIB_PATH):
         "wepp_amd has no CPU fallback."
     )
 
+# libwepp_place.so and PyTorch both need libamdhip64.so.7.  PyTorch bundles its
+# own copy; if ours (from /opt/rocm) were loaded first, torch would later be
+# bound to a runtime it was not built with and report "No HIP GPUs".  Loading
+# torch first makes the whole process share torch's HIP runtime.  A C/C++ host
+# that links the library directly is not concerned.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 lib = ctypes.CDLL(LIB_PATH)
 
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
