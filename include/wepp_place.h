@@ -89,8 +89,14 @@ typedef struct {
     uint64_t n_leaves;
     uint32_t max_depth;        /* root = 0                                      */
     uint32_t max_position;     /* largest mutated position                      */
-    uint64_t stream_bytes;     /* bytes one sweep of the event stream reads     */
+    uint64_t stream_bytes;     /* bytes one sweep of the whole-tree stream reads */
     uint64_t device_bytes;     /* total HBM held by the handle                  */
+    /* sweep streams: crowns {static score <= tau} closed under ancestors, in
+     * increasing tau; the last one is the whole tree (tau = INT32_MAX) */
+    uint32_t n_streams;
+    int32_t  stream_tau[8];
+    uint64_t stream_nodes[8];
+    uint64_t stream_bytes_of[8];
 } wepp_mat_stats;
 
 /* Per-read result flags (out parameter `flags`). */
@@ -136,16 +142,20 @@ int wepp_place_batch_device(wepp_mat_t *mat, const uint32_t *d_read_off, const u
 /* Tuning knob: reads that share one sweep of the event stream (1..64,
  * default 64).  Affects speed only, never results. */
 int wepp_mat_set_tile_reads(wepp_mat_t *mat, uint32_t reads_per_tile);
+/* Work skipping on (default) / off: when off every read sweeps the whole-tree
+ * stream.  Affects speed only, never results. */
+int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
 
-/* Timing of the dominant kernel (the sweep), measured with HIP events recorded
- * on the launch stream around every sweep launch since the handle was created
- * or wepp_mat_timing_reset() was called (the most recent 64 launches are kept).
- * Blocks until those launches have finished.  mean_sweep_ms = mean duration of
- * one sweep launch; passes = event-stream sweeps one launch performs (= tiles);
- * bytes_per_pass = algorithmic bytes of one sweep (wepp_mat_stats.stream_bytes). */
+/* Timing of the dominant kernel (k_sweep), measured with HIP events recorded on
+ * the launch stream around the sweep launches of every placement call since the
+ * handle was created or wepp_mat_timing_reset() was called (the most recent 64
+ * calls are kept).  Blocks until those launches have finished.
+ * mean_sweep_ms = mean duration of the sweep launches of one call; passes =
+ * event-stream sweeps of the last call (one per tile); algorithmic_bytes =
+ * bytes those sweeps read (sum over tiles of their stream's size). */
 int wepp_mat_timing_reset(wepp_mat_t *mat);
-int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_launches, uint64_t *passes,
-                         uint64_t *bytes_per_pass);
+int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_calls, uint64_t *passes,
+                         uint64_t *algorithmic_bytes);
 
 const char *wepp_last_error(void);
 
@@ -193,6 +203,8 @@ int wepp_gen_reads_destroy(wepp_gen_reads_t *r);
  * constants, event stream) against the oracle.  `name` is one of: node_woff,
  * words, nkey, nstat, rank2dfs, dfs2bfs, bfs2id, dfs2id, parent_dfs, dfs_end,
  * num_leaves, blk_node0, blk_eoff, blk_sum, ev_word, ev_meta, cp_off, cp_word.
+ * Stream fields (nkey, nstat, blk_*, ev_*, cp_*) take an optional "<i>:" prefix
+ * selecting sweep stream i (default: the whole-tree stream).
  * The returned pointer is borrowed from the handle; *elem_bytes is the element
  * size and *count the number of elements. */
 typedef struct wepp_flat wepp_flat_t;

@@ -43,14 +43,20 @@ def own_adjust(w, s):
 
 
 class FlatModel:
-    def __init__(self, flat):
+    """Model of one sweep stream (default: the whole tree) of a flattened MAT."""
+
+    def __init__(self, flat, stream=None):
         self.f = flat
-        for name in ("node_woff", "words", "nkey", "nstat", "rank2dfs", "dfs2bfs", "blk_node0", "blk_eoff",
-                     "blk_sum", "ev_word", "ev_meta", "cp_off", "cp_word", "dfs2id", "bfs2id"):
+        self.stream = flat.n_streams - 1 if stream is None else stream
+        for name in ("node_woff", "words", "rank2dfs", "dfs2bfs", "dfs2id", "bfs2id"):
             setattr(self, name, flat.get(name))
-        self.NB = int(flat.stats.n_blocks)
-        self.N = int(flat.stats.n_nodes)
-        self.cp_stride = flat.cp_stride
+        self.gnstat = flat.get("nstat")            # whole-tree stream == global DFS order
+        for name in ("nkey", "nstat", "blk_node0", "blk_eoff", "blk_sum", "ev_word", "ev_meta", "cp_off", "cp_word"):
+            setattr(self, name, flat.get(name, self.stream))
+        self.NB = len(self.blk_node0) - 1
+        self.N = len(self.nkey)
+        self.tau = int(flat.stats.stream_tau[self.stream])
+        self.cp_stride = max(1, (self.NB + 255) // 256)
 
     def _c_none(self, S):
         return sum(1 for (_, sref, a, missing) in S if not missing and (a & sref) == 0)
@@ -164,7 +170,7 @@ class FlatModel:
 
     def has_unique(self, S, rank):
         d = int(self.rank2dfs[rank])
-        st = int(self.nstat[d])
+        st = int(self.gnstat[d])
         if st & NS_ROOT:
             return 0
         if st & NS_MASKED:
@@ -195,3 +201,35 @@ class FlatModel:
             b += bpc
         d = int(self.rank2dfs[br])
         return dict(score=bs, num_best=cnt, best_j=int(self.dfs2bfs[d]), has_unique=self.has_unique(S, br))
+
+
+def theta(flat, S):
+    """score(root) + |S|: no node whose static score exceeds it can win or tie
+    (k_route in place_kernels.hip)."""
+    words, woff = flat.get("words"), flat.get("node_woff")
+    root_base = int(flat.get("nkey")[0]) >> 32
+    Sd = {s[0]: s for s in S}
+    c = sum(1 for (_, sref, a, missing) in S if not missing and (a & sref) == 0)
+    for w in range(int(woff[0]), int(woff[1])):
+        s = Sd.get(int(words[w]) & 0xFFFFF)
+        if s is not None:
+            c += enter_delta(words[w], s)
+    return root_base + c + len(S)
+
+
+class TieredModel:
+    """Routes a read to the smallest crown stream covering theta, like k_route."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.models = [FlatModel(flat, i) for i in range(flat.n_streams)]
+
+    def route(self, S):
+        th = theta(self.flat, S)
+        for i, m in enumerate(self.models[:-1]):
+            if th <= m.tau:
+                return i
+        return len(self.models) - 1
+
+    def place_full(self, S, nchunks=1):
+        return self.models[self.route(S)].place_full(S, nchunks)

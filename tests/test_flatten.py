@@ -161,3 +161,39 @@ def test_true_parent_allele_is_recomputed():
     bad = Tree.from_lists([-1, 0, 1], [[(10, A, T, C)], [(10, A, A, G)], [(10, A, T, A)]])
     assert (w.FlatView(good).get("words") == w.FlatView(bad).get("words")).all()
     assert ((w.FlatView(good).get("words") >> 22) & 15).tolist() == [0, C, G]
+
+
+def test_crown_streams_give_the_same_answer_as_the_whole_tree(oracle):
+    """Work skipping: a read routed to a crown stream (k_route's theta bound)
+    must be placed exactly as on the whole-tree stream and as by the oracle."""
+    rng = np.random.default_rng(4)
+    routed = np.zeros(8, int)
+    for _ in range(120):
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(1, 400)), genome=int(rng.choice([60, 200, 1000])),
+                                   max_muts=int(rng.choice([2, 4])))
+        ot = oracle.OracleTree(tree)
+        fv = w.FlatView(tree)
+        tm = sm.TieredModel(fv)
+        for _ in range(4):
+            S = ft.random_sample(rng, ref, genome=max(ref), max_k=int(rng.choice([2, 4, 7])))
+            o = ot.place_sample(*_cols(S))
+            routed[tm.route(S)] += 1
+            got = tm.place_full(S, nchunks=int(rng.integers(1, 4)))
+            assert (got["score"], got["num_best"], got["best_j"], got["has_unique"]) == \
+                (o["score"], o["num_best"], o["best_j"], o["has_unique"])
+    assert (routed[:3] > 20).all(), routed
+
+
+def test_crown_is_ancestor_closed_and_covers_low_scores():
+    g = w.generate_tree(13, 50000)
+    fv = w.FlatView(g.tree)
+    assert fv.n_streams >= 3 and fv.stats.stream_tau[fv.n_streams - 1] == 2**31 - 1
+    base = (fv.get("nkey") >> 32)
+    for i in range(fv.n_streams - 1):
+        tau = fv.stats.stream_tau[i]
+        keys = fv.get("nkey", i)
+        # every node with base <= tau is in the crown (matched through its unique global rank)
+        want = set((fv.get("nkey")[base <= tau] & 0xFFFFFFFF).tolist())
+        have = set((keys & 0xFFFFFFFF).tolist())
+        assert want <= have
+        assert len(have) == fv.stats.stream_nodes[i] < 50000

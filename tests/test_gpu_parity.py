@@ -79,6 +79,25 @@ def test_config2_100k_nodes(oracle):
     mat.close()
 
 
+def test_crowns_on_and_off_agree(oracle):
+    """Work skipping (crown streams) never changes a result."""
+    g = w.generate_tree(51, 300000, p_ambiguous=0.002, root_mutations=1)
+    reads = g.reads(52, 30000, p_iupac=0.02)
+    mat = w.Mat(g.tree)
+    assert mat.stats.n_streams >= 3
+    on = mat.place_batch(reads)
+    mat.set_use_crowns(False)
+    off = mat.place_batch(reads)
+    for a, b in ((on.score, off.score), (on.best_bfs_j, off.best_bfs_j), (on.num_best, off.num_best),
+                 (on.flags, off.flags)):
+        assert (a == b).all()
+    sub = reads.slice(0, 800)
+    want = oracle.OracleTree(g.tree).place_batch(sub, os.cpu_count())
+    assert (on.score[:800] == want["score"]).all() and (on.best_bfs_j[:800] == want["best_j"]).all()
+    assert (on.num_best[:800] == want["num_best"]).all() and (on.has_unique[:800] == want["has_unique"]).all()
+    mat.close()
+
+
 def test_config5_long_reads(oracle):
     """BASELINE.json configs[4] shape: ~1.2 kb reads, 3 % substitutions, 2 % N (40-70 entries per read)."""
     g = w.generate_tree(11, 100000)
@@ -154,15 +173,26 @@ def test_device_pointer_entry_point(oracle):
     assert (outs[1].cpu().numpy() == want["score"]).all()
     assert (outs[2].cpu().numpy().view(np.uint32) == want["num_best"]).all()
     assert ((outs[3].cpu().numpy() & 1) == want["has_unique"]).all()
-    ms, n, passes, bpp = mat.last_timing()
-    assert ms > 0 and n == 1 and passes == (reads.n_reads + 63) // 64 and bpp == mat.stats.stream_bytes
+    ms, n, passes, nbytes = mat.last_timing()
+    assert ms > 0 and n == 1 and passes >= (reads.n_reads + 63) // 64 and nbytes > 0
+    # with work skipping off every tile sweeps the whole-tree stream exactly once
+    mat.set_use_crowns(False)
+    mat.timing_reset()
+    with torch.cuda.stream(stream):
+        mat.place_batch_device(d_off.data_ptr(), d_word.data_ptr(), reads.n_reads, int(reads.read_off[-1]),
+                               outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+                               stream.cuda_stream)
+    stream.synchronize()
+    ms, n, passes, nbytes = mat.last_timing()
+    assert passes == (reads.n_reads + 63) // 64 and nbytes == passes * mat.stats.stream_bytes
+    assert (outs[1].cpu().numpy() == want["score"]).all()
     mat.close()
 
 
 def test_full_size_properties(oracle):
     """BASELINE.json configs[2] size (16M nodes): properties that need no
     oracle run over the whole batch, plus the oracle on a handful of reads.
-      - tile-size invariance (T=64 vs T=16) and batch-permutation invariance,
+      - tile-size invariance (T=64 vs T=16), work skipping on/off, batch-permutation invariance,
       - every score lies in [0, root placement score] and num_best >= 1."""
     g = w.generate_tree(21, 16_000_000)
     reads = g.reads(22, 200_000)
@@ -174,6 +204,11 @@ def test_full_size_properties(oracle):
     assert (r16.score == res.score[:20000]).all() and (r16.best_bfs_j == res.best_bfs_j[:20000]).all()
     assert (r16.num_best == res.num_best[:20000]).all() and (r16.flags == res.flags[:20000]).all()
     mat.set_tile_reads(64)
+    mat.set_use_crowns(False)
+    roff = mat.place_batch(sub)
+    mat.set_use_crowns(True)
+    assert (roff.score == res.score[:20000]).all() and (roff.best_bfs_j == res.best_bfs_j[:20000]).all()
+    assert (roff.num_best == res.num_best[:20000]).all() and (roff.flags == res.flags[:20000]).all()
     # permutation invariance
     rng = np.random.default_rng(0)
     perm = rng.permutation(20000)

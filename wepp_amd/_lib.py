@@ -58,6 +58,10 @@ class MatStats(ctypes.Structure):
         ("max_position", ctypes.c_uint32),
         ("stream_bytes", ctypes.c_uint64),
         ("device_bytes", ctypes.c_uint64),
+        ("n_streams", ctypes.c_uint32),
+        ("stream_tau", ctypes.c_int32 * 8),
+        ("stream_nodes", ctypes.c_uint64 * 8),
+        ("stream_bytes_of", ctypes.c_uint64 * 8),
     ]
 
 
@@ -102,6 +106,7 @@ _SIGS = {
         [_V, _V, _V, ctypes.c_uint32, ctypes.c_uint64, _V, _V, _V, _V, _V],
     ),
     "wepp_mat_set_tile_reads": (ctypes.c_int, [_V, ctypes.c_uint32]),
+    "wepp_mat_set_use_crowns": (ctypes.c_int, [_V, ctypes.c_int]),
     "wepp_mat_timing_reset": (ctypes.c_int, [_V]),
     "wepp_mat_last_timing": (
         ctypes.c_int,

@@ -187,17 +187,25 @@ class FlatView:
         self.stats = st
         self.cp_stride = cs.value
 
-    def get(self, name):
+    @property
+    def n_streams(self):
+        return int(self.stats.n_streams)
+
+    def get(self, name, stream=None):
+        """Host array `name`; stream fields take stream=i (default: whole-tree stream)."""
+        base = name
+        if stream is not None:
+            name = f"{int(stream)}:{name}"
         data = ctypes.c_void_p()
         cnt = ctypes.c_uint64()
         eb = ctypes.c_uint32()
         check(lib.wepp_flat_get(self._h, name.encode(), ctypes.byref(data), ctypes.byref(cnt), ctypes.byref(eb)))
         if cnt.value == 0:
             return np.zeros(0, np.uint32)
-        if name == "blk_sum":
+        if base == "blk_sum":
             raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 4,)).copy()
             return raw.reshape(-1, 4)
-        dt = self._DT.get(name, np.uint32)
+        dt = self._DT.get(base, np.uint32)
         cptr = ctypes.cast(data, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt)))
         return np.ctypeslib.as_array(cptr, shape=(cnt.value,)).copy()
 
@@ -247,6 +255,10 @@ class Mat:
     def set_tile_reads(self, t):
         check(lib.wepp_mat_set_tile_reads(self._h, int(t)))
 
+    def set_use_crowns(self, enable):
+        """Work skipping on (default) / off; speed only, never results."""
+        check(lib.wepp_mat_set_use_crowns(self._h, 1 if enable else 0))
+
     def place_batch(self, reads, per_node_scores=False):
         """Host buffers in/out: wepp_place_batch."""
         n = reads.n_reads
@@ -273,7 +285,8 @@ class Mat:
         check(lib.wepp_mat_timing_reset(self._h))
 
     def last_timing(self):
-        """(mean sweep-kernel ms per launch, launches averaged, passes per launch, bytes per pass)."""
+        """(mean k_sweep ms per placement call, calls averaged, stream sweeps and
+        algorithmic bytes of the last call)."""
         ms = ctypes.c_float()
         nl = ctypes.c_uint32()
         passes = ctypes.c_uint64()

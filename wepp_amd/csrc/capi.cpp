@@ -21,20 +21,22 @@ using namespace wepp;
 struct wepp_mat {
     int device = 0;
     DevMAT dev{};
+    std::vector<DevStream> streams;
+    std::vector<uint64_t> stream_bytes;
     wepp_mat_stats stats{};
     std::vector<uint32_t> bfs2id;
     std::vector<void*> allocs;
     uint32_t tile_reads = 64;
-    uint32_t ncp = 1;
-    // grow-only workspace for the per-(chunk, read) partial results
+    int use_crowns = 1;
+    // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    uint32_t* d_max = nullptr;
-    uint32_t* h_max = nullptr;   // pinned
+    uint32_t* d_info = nullptr;       // tier_info (TI_WORDS) followed by blk_counts
+    uint32_t* h_info = nullptr;       // pinned copy of tier_info
     static constexpr uint32_t kRing = 64;
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
-    uint64_t n_timed = 0;   // sweep launches since the last timing reset
-    uint64_t last_passes = 0;
+    uint64_t n_timed = 0;             // placement calls since the last timing reset
+    uint64_t last_passes = 0, last_bytes = 0;
 };
 
 namespace {
@@ -67,8 +69,8 @@ void release(wepp_mat* h) {
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
-    if (h->d_max) (void)hipFree(h->d_max);
-    if (h->h_max) (void)hipHostFree(h->h_max);
+    if (h->d_info) (void)hipFree(h->d_info);
+    if (h->h_info) (void)hipHostFree(h->h_info);
     for (uint32_t i = 0; i < wepp_mat::kRing; i++) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
         if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
@@ -103,28 +105,45 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     h->stats.n_nodes = f.N;
     h->stats.n_mutations = f.M;
     h->stats.n_masked = f.n_masked;
-    h->stats.n_events = f.E;
-    h->stats.n_blocks = f.NB;
+    h->stats.n_events = f.full().E;
+    h->stats.n_blocks = f.full().NB;
     h->stats.n_leaves = f.n_leaves;
     h->stats.max_depth = f.max_depth;
     h->stats.max_position = f.max_pos;
-    // one sweep reads every event word plus the per-block event offset and summary
-    h->stats.stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(BlkSum) + 4);
-    h->ncp = (uint32_t)f.cp_off.size() - 1;
+    h->stats.stream_bytes = f.full().stream_bytes();
+    h->stats.n_streams = (uint32_t)f.streams.size();
 
     DevMAT& d = h->dev;
     d.N = f.N;
-    d.NB = f.NB;
-    d.cp_stride = f.cp_stride;
     d.max_pos = f.max_pos;
-    d.bm_words = (f.max_pos >> 5) + 1;
+    d.bm_words = 1;
+    while (d.bm_words < (f.max_pos >> 5) + 1) d.bm_words <<= 1;   // power of two (k_sweep masks the index)
+    d.n_streams = (uint32_t)f.streams.size();
+    d.root_base = f.root_base;
     int rc;
-#define UP(field) if ((rc = upload(h, f.field, &d.field)) != WEPP_OK) { release(h); return rc; }
-    UP(node_woff) UP(words) UP(nkey) UP(nstat) UP(rank2dfs) UP(dfs2bfs)
-    UP(blk_node0) UP(blk_eoff) UP(blk_sum) UP(ev_word) UP(ev_meta) UP(cp_off) UP(cp_word)
+#define UP(dst, vec) if ((rc = upload(h, vec, &dst)) != WEPP_OK) { release(h); return rc; }
+    UP(d.node_woff, f.node_woff) UP(d.words, f.words) UP(d.nstat, f.nstat) UP(d.rank2dfs, f.rank2dfs)
+    UP(d.dfs2bfs, f.dfs2bfs)
+    for (size_t i = 0; i < f.streams.size(); i++) {
+        const Stream& st = f.streams[i];
+        DevStream ds{};
+        ds.n = st.n;
+        ds.NB = st.NB;
+        ds.cp_stride = st.cp_stride;
+        ds.ncp = (uint32_t)st.cp_off.size() - 1;
+        UP(ds.nkey, st.nkey) UP(ds.nstat, st.nstat) UP(ds.blk_node0, st.blk_node0) UP(ds.blk_eoff, st.blk_eoff)
+        UP(ds.blk_sum, st.blk_sum) UP(ds.ev_word, st.ev_word) UP(ds.ev_meta, st.ev_meta) UP(ds.cp_off, st.cp_off)
+        UP(ds.cp_word, st.cp_word)
+        h->streams.push_back(ds);
+        h->stream_bytes.push_back(st.stream_bytes());
+        d.tau[i] = st.tau;
+        h->stats.stream_tau[i] = st.tau;
+        h->stats.stream_nodes[i] = st.n;
+        h->stats.stream_bytes_of[i] = st.stream_bytes();
+    }
 #undef UP
-    e = hipMalloc((void**)&h->d_max, 16);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_max, 16, hipHostMallocDefault);
+    e = hipMalloc((void**)&h->d_info, (TI_WORDS + ROUTE_BLOCKS * MAX_STREAMS) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_info, TI_WORDS * sizeof(uint32_t), hipHostMallocDefault);
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
@@ -159,6 +178,12 @@ extern "C" int wepp_mat_set_tile_reads(wepp_mat_t* mat, uint32_t reads_per_tile)
     return WEPP_OK;
 }
 
+extern "C" int wepp_mat_set_use_crowns(wepp_mat_t* mat, int enable) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    mat->use_crowns = enable ? 1 : 0;
+    return WEPP_OK;
+}
+
 extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word,
                                        uint32_t n_reads, uint64_t n_read_words, uint32_t* d_best_bfs_j,
                                        int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags,
@@ -169,49 +194,111 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     hipStream_t stream = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(mat->device));
     const uint32_t T = mat->tile_reads;
-    const uint32_t ntiles = (n_reads + T - 1) / T;
+    const uint32_t ns = mat->dev.n_streams;
 
-    // largest tile (read words) decides how much LDS a workgroup asks for
-    HIP_TRY(hipMemsetAsync(mat->d_max, 0, 4, stream));
-    HIP_TRY(launch_tile_max_entries(d_read_off, n_reads, T, mat->d_max, stream));
-    HIP_TRY(hipMemcpyAsync(mat->h_max, mat->d_max, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const uint32_t max_ent = *mat->h_max;
-    const uint32_t bm_bytes = mat->dev.bm_words * 4;
-    uint32_t cap = (max_ent + 63) & ~63u;
-    bool s_in_lds = true;
-    uint32_t lds_bytes = bm_bytes + cap * 4;
-    if (lds_bytes > 64 * 1024) { s_in_lds = false; lds_bytes = bm_bytes; }
-    if (lds_bytes > 160 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
-
-    // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
-    const uint32_t target_waves = 8192;
-    uint32_t nchunks = std::max<uint32_t>(1, (target_waves + ntiles - 1) / ntiles);
-    nchunks = std::min(nchunks, mat->ncp);
-    const uint32_t cps_per_chunk = (mat->ncp + nchunks - 1) / nchunks;
-    const uint32_t bpc = cps_per_chunk * mat->dev.cp_stride;
-    nchunks = (mat->dev.NB + bpc - 1) / bpc;
-
-    const size_t need = (size_t)nchunks * n_reads * 12;
-    if (need > mat->ws_bytes) {
+    // ---- workspace: [tier_of R bytes][list R][partials: sum over tiers of nchunks*count*12] ----
+    // The partials are sized for the worst case once the per-tier counts are known.
+    auto grow = [&](size_t need) -> int {
+        if (need <= mat->ws_bytes) return WEPP_OK;
         if (mat->ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(mat->ws); mat->ws = nullptr; mat->ws_bytes = 0; }
+        need += need / 4;
         hipError_t e = hipMalloc(&mat->ws, need);
         if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
         mat->ws_bytes = need;
+        return WEPP_OK;
+    };
+    const size_t tier_bytes = ((size_t)n_reads + 255) & ~(size_t)255;
+    const size_t list_bytes = (((size_t)n_reads * 4) + 255) & ~(size_t)255;
+    {
+        // before routing only the first two regions are needed; reserve a typical partial size too
+        int rc = grow(tier_bytes + list_bytes + (size_t)n_reads * 12 * 2);
+        if (rc != WEPP_OK) return rc;
     }
-    int32_t* part_score = (int32_t*)mat->ws;
-    uint32_t* part_rank = (uint32_t*)(part_score + (size_t)nchunks * n_reads);
-    uint32_t* part_cnt = part_rank + (size_t)nchunks * n_reads;
+    uint8_t* tier_of = (uint8_t*)mat->ws;
+    uint32_t* list = (uint32_t*)((char*)mat->ws + tier_bytes);
+    uint32_t* tier_info = mat->d_info;
+    uint32_t* blk_counts = mat->d_info + TI_WORDS;
 
+    // ---- route the reads to streams ------------------------------------------------
+    HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
+    HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, blk_counts, tier_info,
+                         stream));
+    HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
+    HIP_TRY(hipMemcpyAsync(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint32_t* info = mat->h_info;
+
+    // ---- plan the launches ---------------------------------------------------------
+    struct Plan { uint32_t t, count, off, ntiles, nchunks, bpc, lds_bytes; bool s_in_lds; size_t part_off; };
+    Plan plans[MAX_STREAMS];
+    uint32_t np = 0;
+    size_t part_total = 0;
+    const uint32_t bm_bytes = mat->dev.bm_words * 4;
+    if (bm_bytes > 128 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
+    for (uint32_t t = 0; t < ns; t++) {
+        const uint32_t count = info[TI_COUNT + t];
+        if (!count) continue;
+        Plan& p = plans[np++];
+        p.t = t;
+        p.count = count;
+        p.off = info[TI_OFF + t];
+        p.ntiles = (count + T - 1) / T;
+        // largest tile (read words) decides how much LDS a workgroup asks for
+        const uint64_t cap = ((uint64_t)std::min<uint32_t>(T, count) * info[TI_MAXK + t] + 63) & ~63ull;
+        p.s_in_lds = bm_bytes + cap * 4 <= 64 * 1024;
+        p.lds_bytes = p.s_in_lds ? (uint32_t)(bm_bytes + cap * 4) : bm_bytes;
+        // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
+        const DevStream& st = mat->streams[t];
+        const uint32_t target_waves = 8192;
+        uint32_t nchunks = std::max<uint32_t>(1, (target_waves + p.ntiles - 1) / p.ntiles);
+        nchunks = std::min(nchunks, st.ncp);
+        const uint32_t cps_per_chunk = (st.ncp + nchunks - 1) / nchunks;
+        p.bpc = cps_per_chunk * st.cp_stride;
+        p.nchunks = (st.NB + p.bpc - 1) / p.bpc;
+        p.part_off = part_total;
+        part_total += (size_t)p.nchunks * count * 12;
+    }
+    {
+        int rc = grow(tier_bytes + list_bytes + part_total);
+        if (rc != WEPP_OK) return rc;
+        tier_of = (uint8_t*)mat->ws;
+        if ((uint32_t*)((char*)mat->ws + tier_bytes) != list) {
+            // the workspace moved: redo the (cheap) routing into the new buffer
+            list = (uint32_t*)((char*)mat->ws + tier_bytes);
+            HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
+            HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, blk_counts,
+                                 tier_info, stream));
+            HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
+        }
+    }
+    char* part_base = (char*)mat->ws + tier_bytes + list_bytes;
+
+    // ---- sweeps (timed as a group), then finalizes ----------------------------------
     const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
     HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
-    HIP_TRY(launch_sweep(mat->dev, d_read_off, d_read_word, n_reads, T, ntiles, nchunks, bpc, s_in_lds, lds_bytes,
-                         part_score, part_rank, part_cnt, stream));
+    uint64_t passes = 0, bytes = 0;
+    for (uint32_t i = 0; i < np; i++) {
+        const Plan& p = plans[i];
+        int32_t* ps = (int32_t*)(part_base + p.part_off);
+        uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
+        uint32_t* pc = pr + (size_t)p.nchunks * p.count;
+        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, T, p.ntiles,
+                             p.nchunks, p.bpc, p.s_in_lds, p.lds_bytes, ps, pr, pc, stream));
+        passes += p.ntiles;                                   // every tile sweeps its stream once
+        bytes += (uint64_t)p.ntiles * mat->stream_bytes[p.t];
+    }
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
     mat->n_timed++;
-    mat->last_passes = (uint64_t)ntiles;   // every tile sweeps the whole stream once (split over its chunks)
-    HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, n_reads, nchunks, part_score, part_rank, part_cnt,
-                            d_best_bfs_j, d_score, d_num_best, d_flags, stream));
+    mat->last_passes = passes;
+    mat->last_bytes = bytes;
+    for (uint32_t i = 0; i < np; i++) {
+        const Plan& p = plans[i];
+        int32_t* ps = (int32_t*)(part_base + p.part_off);
+        uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
+        uint32_t* pc = pr + (size_t)p.nchunks * p.count;
+        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,
+                                d_best_bfs_j, d_score, d_num_best, d_flags, stream));
+    }
     return WEPP_OK;
 }
 
@@ -221,8 +308,8 @@ extern "C" int wepp_mat_timing_reset(wepp_mat_t* mat) {
     return WEPP_OK;
 }
 
-extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint32_t* n_launches, uint64_t* passes,
-                                    uint64_t* bytes_per_pass) {
+extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint32_t* n_calls, uint64_t* passes,
+                                    uint64_t* algorithmic_bytes) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
     if (mat->n_timed == 0) return set_error(WEPP_EINVAL, "no placement has been launched on this handle since the last reset");
     HIP_TRY(hipSetDevice(mat->device));
@@ -236,9 +323,9 @@ extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint3
         sum += ms;
     }
     if (mean_sweep_ms) *mean_sweep_ms = (float)(sum / n);
-    if (n_launches) *n_launches = n;
+    if (n_calls) *n_calls = n;
     if (passes) *passes = mat->last_passes;
-    if (bytes_per_pass) *bytes_per_pass = mat->stats.stream_bytes;
+    if (algorithmic_bytes) *algorithmic_bytes = mat->last_bytes;
     return WEPP_OK;
 }
 

@@ -16,14 +16,11 @@ constexpr uint32_t EV_OFF_MASK_DEV = EV_OFF_MASK;
 constexpr uint32_t W_EXIT_DEV = W_EXIT, W_LEAF_DEV = W_LEAF, W_PAD_DEV = W_PAD;
 constexpr uint32_t WEPP_FLAG_HAS_UNIQUE_DEV = WEPP_FLAG_HAS_UNIQUE;
 
-struct DevMAT {
-    uint32_t N, NB, cp_stride, bm_words, max_pos;
-    const uint32_t* node_woff;
-    const uint32_t* words;
+// one sweep stream (a crown or the whole tree), see flatmat.hpp
+struct DevStream {
+    uint32_t n, NB, cp_stride, ncp;
     const int64_t* nkey;
     const uint32_t* nstat;
-    const uint32_t* rank2dfs;
-    const uint32_t* dfs2bfs;
     const uint32_t* blk_node0;
     const uint32_t* blk_eoff;
     const BlkSum* blk_sum;
@@ -33,16 +30,40 @@ struct DevMAT {
     const uint32_t* cp_word;
 };
 
-hipError_t launch_tile_max_entries(const uint32_t* d_read_off, uint32_t n_reads, uint32_t T,
-                                   uint32_t* d_out_max, hipStream_t stream);
-hipError_t launch_sweep(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
-                        uint32_t n_reads, uint32_t T, uint32_t ntiles, uint32_t nchunks,
-                        uint32_t blocks_per_chunk, bool s_in_lds, uint32_t lds_bytes, int32_t* part_score,
-                        uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream);
+// tree-wide arrays (global DFS indices)
+struct DevMAT {
+    uint32_t N, bm_words, max_pos, n_streams;
+    int32_t root_base;
+    int32_t tau[MAX_STREAMS];
+    const uint32_t* node_woff;
+    const uint32_t* words;
+    const uint32_t* nstat;
+    const uint32_t* rank2dfs;
+    const uint32_t* dfs2bfs;
+};
+
+constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (grid-stride over the reads)
+constexpr uint32_t ROUTE_THREADS = 256;
+
+// route: tier of every read + per-(block, tier) counts and per-tier max entries
+hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
+                        int use_crowns, uint8_t* tier_of, uint32_t* blk_counts, uint32_t* tier_info,
+                        hipStream_t stream);
+// scatter: read indices grouped by tier into `list` (tier t occupies [tier_off[t], tier_off[t+1]))
+hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32_t* blk_counts, uint32_t* tier_info,
+                          uint32_t* list, hipStream_t stream);
+hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
+                        const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
+                        uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds,
+                        uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
+                        hipStream_t stream);
 hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
-                           uint32_t n_reads, uint32_t nchunks, const int32_t* part_score,
+                           const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
 hipError_t sweep_set_max_lds(uint32_t bytes);
+
+// layout of tier_info (uint32): [0..8) counts, [8..16) max entries of one read, [16..25) offsets into the list
+constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_STREAMS, TI_OFF = 2 * MAX_STREAMS, TI_WORDS = 3 * MAX_STREAMS + 1;
 
 }  // namespace wepp

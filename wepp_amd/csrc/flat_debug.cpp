@@ -33,16 +33,25 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
                              uint32_t* elem_bytes) {
     if (!flat || !name || !data || !count || !elem_bytes) return wepp::set_error(WEPP_EINVAL, "null argument");
     const wepp::FlatMAT& f = flat->f;
-#define FIELD(n)                                                        \
+#define FIELD(obj, n)                                                   \
     if (std::strcmp(name, #n) == 0) {                                   \
-        *data = f.n.data();                                             \
-        *count = f.n.size();                                            \
-        *elem_bytes = (uint32_t)sizeof(f.n[0]);                         \
+        *data = obj.n.data();                                           \
+        *count = obj.n.size();                                          \
+        *elem_bytes = (uint32_t)sizeof(obj.n[0]);                       \
         return WEPP_OK;                                                 \
     }
-    FIELD(node_woff) FIELD(words) FIELD(nkey) FIELD(nstat) FIELD(rank2dfs) FIELD(dfs2bfs) FIELD(bfs2id)
-    FIELD(dfs2id) FIELD(parent_dfs) FIELD(dfs_end) FIELD(num_leaves) FIELD(blk_node0) FIELD(blk_eoff)
-    FIELD(blk_sum) FIELD(ev_word) FIELD(ev_meta) FIELD(cp_off) FIELD(cp_word)
+    size_t si = f.streams.size() - 1;
+    if (name[0] >= '0' && name[0] <= '9' && name[1] == ':') {
+        si = (size_t)(name[0] - '0');
+        name += 2;
+        if (si >= f.streams.size()) return wepp::set_error(WEPP_EINVAL, "stream index out of range");
+    } else {
+        FIELD(f, node_woff) FIELD(f, words) FIELD(f, rank2dfs) FIELD(f, dfs2bfs) FIELD(f, bfs2id) FIELD(f, dfs2id)
+        FIELD(f, parent_dfs) FIELD(f, dfs_end) FIELD(f, num_leaves)
+    }
+    const wepp::Stream& st = f.streams[si];
+    FIELD(st, nkey) FIELD(st, nstat) FIELD(st, blk_node0) FIELD(st, blk_eoff) FIELD(st, blk_sum) FIELD(st, ev_word)
+    FIELD(st, ev_meta) FIELD(st, cp_off) FIELD(st, cp_word)
 #undef FIELD
     return wepp::set_error(WEPP_EINVAL, std::string("unknown flat field: ") + name);
 }
@@ -55,14 +64,20 @@ extern "C" int wepp_flat_scalars(const wepp_flat_t* flat, wepp_mat_stats* stats,
         stats->n_nodes = f.N;
         stats->n_mutations = f.M;
         stats->n_masked = f.n_masked;
-        stats->n_events = f.E;
-        stats->n_blocks = f.NB;
+        stats->n_events = f.full().E;
+        stats->n_blocks = f.full().NB;
         stats->n_leaves = f.n_leaves;
         stats->max_depth = f.max_depth;
         stats->max_position = f.max_pos;
-        stats->stream_bytes = 4ull * f.E + (uint64_t)f.NB * (sizeof(wepp::BlkSum) + 4);
+        stats->stream_bytes = f.full().stream_bytes();
+        stats->n_streams = (uint32_t)f.streams.size();
+        for (size_t i = 0; i < f.streams.size(); i++) {
+            stats->stream_tau[i] = f.streams[i].tau;
+            stats->stream_nodes[i] = f.streams[i].n;
+            stats->stream_bytes_of[i] = f.streams[i].stream_bytes();
+        }
     }
-    if (cp_stride) *cp_stride = f.cp_stride;
+    if (cp_stride) *cp_stride = f.full().cp_stride;
     return WEPP_OK;
 }
 

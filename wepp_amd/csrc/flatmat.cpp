@@ -26,6 +26,149 @@ namespace wepp {
 namespace {
 inline uint32_t cost0(uint32_t x, uint32_t ref) { return (x != 0 && x != ref) ? 1u : 0u; }
 }  // namespace
+namespace {
+
+// Builds the sweep stream of the ancestor-closed node subset `sel` (sorted
+// global DFS indices, sel[0] == 0).
+int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err) {
+    const uint32_t n = (uint32_t)sel.size();
+    const uint32_t N = f.N;
+    st.n = n;
+    // local index of a global node / number of selected nodes with global index <= g
+    std::vector<uint32_t> upto(N);
+    {
+        uint32_t c = 0, k = 0;
+        for (uint32_t g = 0; g < N; g++) {
+            if (k < n && sel[k] == g) { c++; k++; }
+            upto[g] = c;
+        }
+    }
+    auto local_of = [&](uint32_t g) { return upto[g] - 1; };
+    st.nkey.resize(n);
+    st.nstat.resize(n);
+    std::vector<uint32_t> lend(n), lpar(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t g = sel[i];
+        st.nkey[i] = f.nkey[g];
+        st.nstat[i] = f.nstat[g];
+        lend[i] = upto[f.dfs_end[g]] - 1;          // last selected node of the subtree
+        lpar[i] = i ? local_of(f.parent_dfs[g]) : 0;
+    }
+    // events at local position x: enter words of node x, and exit words of every
+    // node a with selected descendants whose subtree ends at x-1.  A node without
+    // selected descendants emits no exit; its enter is flagged W_LEAF (it changes
+    // no other node's state) -- except the root, which scores itself with its own
+    // mutations applied.
+    std::vector<uint32_t> evcnt((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t g = sel[i];
+        const uint32_t nm = f.node_woff[g + 1] - f.node_woff[g];
+        evcnt[i] += nm;
+        if (lend[i] > i && lend[i] + 1 < n) evcnt[lend[i] + 1] += nm;
+    }
+    st.blk_node0.clear();
+    st.blk_eoff.clear();
+    {
+        uint32_t d = 0;
+        uint64_t eoff = 0;
+        while (d < n) {
+            st.blk_node0.push_back(d);
+            st.blk_eoff.push_back((uint32_t)eoff);
+            uint32_t nn = 0;
+            uint64_t ne = 0;
+            while (d < n && nn < BLK_MAX_NODES && (nn == 0 || ne + evcnt[d] <= BLK_MAX_EVENTS)) {
+                ne += evcnt[d];
+                nn++;
+                d++;
+            }
+            eoff += ne + (ne & 1);   // even: every lane fetches two words with one 8-byte load
+            if (eoff >= 0xFFFFFFF0ull) { err = "too many sweep events"; return WEPP_ELIMIT; }
+        }
+        st.NB = (uint32_t)st.blk_node0.size();
+        st.blk_node0.push_back(n);
+        st.blk_eoff.push_back((uint32_t)eoff);
+        st.E = eoff;
+    }
+    {
+        st.ev_word.assign(st.E, W_PAD);
+        st.ev_meta.assign(st.E, 0);
+        std::vector<uint32_t> blk_of(n), fill(n, 0);
+        {
+            uint32_t b = 0, cur = 0;
+            for (uint32_t d = 0; d < n; d++) {
+                while (st.blk_node0[b + 1] <= d) b++;
+                if (d == st.blk_node0[b]) cur = st.blk_eoff[b];
+                blk_of[d] = b;
+                fill[d] = cur;
+                cur += evcnt[d];
+            }
+        }
+        for (uint32_t i = 0; i < n; i++) {           // exits take the first slots of a position
+            if (lend[i] > i && lend[i] + 1 < n) {
+                const uint32_t g = sel[i], x = lend[i] + 1;
+                const uint32_t xoff = x - st.blk_node0[blk_of[x]];
+                for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+                    const uint32_t e = fill[x]++;
+                    st.ev_word[e] = f.words[w] | W_EXIT;
+                    st.ev_meta[e] = (uint8_t)xoff;
+                }
+            }
+        }
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t g = sel[i];
+            const bool leaf = (lend[i] == i) && i != 0;
+            const uint32_t off = i - st.blk_node0[blk_of[i]];
+            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+                const uint32_t e = fill[i]++;
+                st.ev_word[e] = f.words[w] | (leaf ? W_LEAF : 0);
+                st.ev_meta[e] = (uint8_t)off;
+            }
+        }
+    }
+    st.blk_sum.assign(st.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF});
+    for (uint32_t b = 0; b < st.NB; b++) {
+        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF};
+        for (uint32_t d = st.blk_node0[b]; d < st.blk_node0[b + 1]; d++) {
+            const int32_t bs = (int32_t)(st.nkey[d] >> 32);
+            const uint32_t rk = (uint32_t)(st.nkey[d] & 0xFFFFFFFFll);
+            s.min_all = std::min(s.min_all, bs);
+            if (!(st.nstat[d] & NS_ELIG0)) continue;
+            if (bs < s.base) { s.base = bs; s.rank = rk; s.cnt = 1; }
+            else if (bs == s.base) { s.cnt++; s.rank = std::min(s.rank, rk); }
+        }
+        st.blk_sum[b] = s;
+    }
+    // checkpoints
+    st.cp_stride = std::max<uint32_t>(1, (st.NB + 255) / 256);
+    {
+        const uint32_t ncp = (st.NB + st.cp_stride - 1) / st.cp_stride;
+        st.cp_off.assign(ncp + 1, 0);
+        st.cp_word.clear();
+        std::vector<uint32_t> path;
+        for (uint32_t i = 0; i < ncp; i++) {
+            st.cp_off[i] = (uint32_t)st.cp_word.size();
+            // Running state of a sequential sweep when it reaches block b: the
+            // enter words of every node still open after local node x-1, i.e. x-1
+            // itself (if it has selected descendants) and all its ancestors.
+            // Subtrees ending exactly at x-1 are closed by exit events INSIDE block b.
+            const uint32_t x = st.blk_node0[i * st.cp_stride];
+            path.clear();
+            if (x > 0) {
+                uint32_t a = x - 1;
+                if (lend[a] > a) path.push_back(a);
+                while (a != 0) { a = lpar[a]; path.push_back(a); }
+            }
+            for (size_t k = path.size(); k-- > 0;) {
+                const uint32_t g = sel[path[k]];
+                for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) st.cp_word.push_back(f.words[w]);
+            }
+        }
+        st.cp_off[ncp] = (uint32_t)st.cp_word.size();
+    }
+    return WEPP_OK;
+}
+
+}  // namespace
 
 int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
     const uint32_t N = t.n_nodes;
@@ -230,130 +373,39 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
         f.nkey[d] = ((int64_t)base[d] << 32) | (int64_t)r;
     }
 
-    // ---- sweep stream ---------------------------------------------------------
-    // events at DFS position x: enter words of node x, and exit words of every
-    // internal node a with dfs_end[a] + 1 == x.  Leaves emit no exit (their
-    // enter is flagged EV_LEAF and changes no other node's state).
-    std::vector<uint32_t> evcnt(N + 1, 0);
-    for (uint32_t d = 0; d < N; d++) {
-        uint32_t nm = f.node_woff[d + 1] - f.node_woff[d];
-        evcnt[d] += nm;
-        if (!(f.nstat[d] & NS_LEAF) && f.dfs_end[d] + 1 < N) evcnt[f.dfs_end[d] + 1] += nm;
-    }
-    // blocks: <=64 nodes and <=128 events; the event count of a block is padded
-    // to an even number so that every lane can fetch two words with one 8-byte load
-    f.blk_node0.clear();
-    f.blk_eoff.clear();
-    {
-        uint32_t d = 0;
-        uint64_t eoff = 0;
-        while (d < N) {
-            f.blk_node0.push_back(d);
-            f.blk_eoff.push_back((uint32_t)eoff);
-            uint32_t nn = 0;
-            uint64_t ne = 0;
-            while (d < N && nn < BLK_MAX_NODES && (nn == 0 || ne + evcnt[d] <= BLK_MAX_EVENTS)) {
-                ne += evcnt[d];
-                nn++;
-                d++;
-            }
-            eoff += ne + (ne & 1);
-            if (eoff >= 0xFFFFFFF0ull) { err = "too many sweep events"; return WEPP_ELIMIT; }
-        }
-        f.NB = (uint32_t)f.blk_node0.size();
-        f.blk_node0.push_back(N);
-        f.blk_eoff.push_back((uint32_t)eoff);
-        f.E = eoff;
-    }
-    // fill: events of a block in DFS-position order (exits of a position first)
-    {
-        f.ev_word.assign(f.E, W_PAD);
-        f.ev_meta.assign(f.E, 0);
-        std::vector<uint32_t> blk_of(N);
-        {
-            uint32_t b = 0;
-            for (uint32_t d = 0; d < N; d++) {
-                while (f.blk_node0[b + 1] <= d) b++;
-                blk_of[d] = b;
-            }
-        }
-        // fill[x] = next free event slot for position x
-        std::vector<uint32_t> fill(N, 0);
-        {
-            uint32_t b = 0;
-            uint32_t cur = 0;
-            for (uint32_t d = 0; d < N; d++) {
-                if (blk_of[d] != b || d == 0) { b = blk_of[d]; cur = f.blk_eoff[b]; }
-                fill[d] = cur;
-                cur += evcnt[d];
-            }
-        }
-        // pass 1: exit events (reserve the first slots of each position)
-        for (uint32_t d = 0; d < N; d++) {
-            if (!(f.nstat[d] & NS_LEAF) && f.dfs_end[d] + 1 < N) {
-                uint32_t x = f.dfs_end[d] + 1;
-                uint32_t xoff = x - f.blk_node0[blk_of[x]];
-                for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
-                    uint32_t e = fill[x]++;
-                    f.ev_word[e] = f.words[w] | W_EXIT;
-                    f.ev_meta[e] = (uint8_t)xoff;
-                }
-            }
-        }
-        // pass 2: enter events
-        for (uint32_t d = 0; d < N; d++) {
-            // the root scores itself with its own mutations applied, so its enter
-            // events are never flagged W_LEAF (single-node tree)
-            bool leaf = (f.nstat[d] & NS_LEAF) && d != 0;
-            uint32_t off = d - f.blk_node0[blk_of[d]];
-            for (uint32_t w = f.node_woff[d]; w < f.node_woff[d + 1]; w++) {
-                uint32_t e = fill[d]++;
-                f.ev_word[e] = f.words[w] | (leaf ? W_LEAF : 0);
-                f.ev_meta[e] = (uint8_t)off;
-            }
-        }
-    }
-    // block summaries
-    f.blk_sum.assign(f.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF});
-    for (uint32_t b = 0; b < f.NB; b++) {
-        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF};
-        for (uint32_t d = f.blk_node0[b]; d < f.blk_node0[b + 1]; d++) {
-            int32_t bs = (int32_t)(f.nkey[d] >> 32);
-            uint32_t rk = (uint32_t)(f.nkey[d] & 0xFFFFFFFFll);
-            s.min_all = std::min(s.min_all, bs);
-            if (!(f.nstat[d] & NS_ELIG0)) continue;
-            if (bs < s.base) { s.base = bs; s.rank = rk; s.cnt = 1; }
-            else if (bs == s.base) { s.cnt++; s.rank = std::min(s.rank, rk); }
-        }
-        f.blk_sum[b] = s;
-    }
+    f.root_base = base[0];
 
-    // ---- checkpoints ------------------------------------------------------------
-    f.cp_stride = std::max<uint32_t>(1, (f.NB + 255) / 256);
+    // ---- sweep streams: crowns of increasing tau, then the whole tree ------------
+    // A node with static score base(n) can never reach a read's best score if
+    // base(n) > theta(read), so a read only needs the
+    // crown {base <= theta} closed under ancestors.
     {
-        uint32_t ncp = (f.NB + f.cp_stride - 1) / f.cp_stride;
-        f.cp_off.assign(ncp + 1, 0);
-        f.cp_word.clear();
-        std::vector<uint32_t> path;
-        for (uint32_t i = 0; i < ncp; i++) {
-            f.cp_off[i] = (uint32_t)f.cp_word.size();
-            // Running state of a sequential sweep when it reaches block b: the
-            // enter words of every non-leaf node still open after node g-1, i.e.
-            // g-1 itself (unless it is a leaf) and all its ancestors.  Subtrees
-            // ending exactly at g-1 are closed by exit events INSIDE block b.
-            uint32_t g = f.blk_node0[i * f.cp_stride];
-            path.clear();
-            if (g > 0) {
-                uint32_t a = g - 1;
-                if (!(f.nstat[a] & NS_LEAF)) path.push_back(a);
-                while (a != 0) { a = f.parent_dfs[a]; path.push_back(a); }
-            }
-            for (size_t k = path.size(); k-- > 0;) {
-                uint32_t x = path[k];
-                for (uint32_t w = f.node_woff[x]; w < f.node_woff[x + 1]; w++) f.cp_word.push_back(f.words[w]);
-            }
+        static const int32_t taus[] = {2, 4, 6, 9, 13, 19, 27};
+        std::vector<uint8_t> keep(N);
+        std::vector<uint32_t> sel;
+        size_t prev = 0;
+        for (int32_t tau : taus) {
+            if (f.streams.size() + 1 >= MAX_STREAMS) break;
+            for (uint32_t d = 0; d < N; d++) keep[d] = base[d] <= tau;
+            keep[0] = 1;
+            for (uint32_t d = N; d-- > 1;)
+                if (keep[d]) keep[f.parent_dfs[d]] = 1;
+            sel.clear();
+            for (uint32_t d = 0; d < N; d++)
+                if (keep[d]) sel.push_back(d);
+            if (sel.size() * 2 > N) break;                       // not worth a separate stream
+            if (prev && sel.size() < prev + prev / 2) continue;  // too close to the previous crown
+            f.streams.emplace_back();
+            f.streams.back().tau = tau;
+            int rc = build_stream(f, sel, f.streams.back(), err);
+            if (rc != WEPP_OK) return rc;
+            prev = sel.size();
         }
-        f.cp_off[ncp] = (uint32_t)f.cp_word.size();
+        sel.resize(N);
+        std::iota(sel.begin(), sel.end(), 0u);
+        f.streams.emplace_back();
+        int rc = build_stream(f, sel, f.streams.back(), err);
+        if (rc != WEPP_OK) return rc;
     }
     return WEPP_OK;
 }

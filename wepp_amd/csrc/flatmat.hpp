@@ -54,10 +54,32 @@ struct BlkSum {          // read-independent summary of one sweep block
     int32_t min_all;     // min static score over ALL nodes of the block (pruning bound)
 };
 
+// One sweep stream: the events of an ancestor-closed subset of the nodes (a
+// "crown": every node whose static score is <= tau, plus all their ancestors),
+// or of the whole tree.  Node indices inside a stream are local (0..n-1, DFS
+// order of the subset); nkey keeps the GLOBAL tie-break rank.
+struct Stream {
+    int32_t tau = 0x7FFFFFFF;          // reads with theta <= tau may use this stream
+    uint32_t n = 0, NB = 0, cp_stride = 1;
+    uint64_t E = 0;
+    std::vector<int64_t> nkey;         // [n]  (base << 32) | global rank
+    std::vector<uint32_t> nstat;       // [n]  (NS_ROOT only on local node 0 = the root)
+    std::vector<uint32_t> blk_node0;   // [NB+1] blocks of <=64 consecutive nodes with <=128 events
+    std::vector<uint32_t> blk_eoff;    // [NB+1] (event counts padded even)
+    std::vector<BlkSum> blk_sum;       // [NB]
+    std::vector<uint32_t> ev_word;     // [E]
+    std::vector<uint8_t> ev_meta;      // [E]
+    // checkpoints: enter words of every node still open when a sequential sweep
+    // reaches block i*cp_stride (node blk_node0[..]-1 unless it closes there, and its ancestors)
+    std::vector<uint32_t> cp_off;      // [ncp+1]
+    std::vector<uint32_t> cp_word;
+    uint64_t stream_bytes() const { return 4ull * E + (uint64_t)NB * (sizeof(BlkSum) + 4); }
+};
+
 struct FlatMAT {
     uint32_t N = 0, n_leaves = 0, max_depth = 0, max_pos = 0;
-    uint64_t M = 0, E = 0, n_masked = 0;
-    uint32_t NB = 0;
+    uint64_t M = 0, n_masked = 0;
+    int32_t root_base = 0;             // static score of the root (D0(root) + masked-root cost)
     // node-major CSR in DFS pre-order (depth_first_expansion order,
     // mutation_annotated_tree.cpp:1143-1163 == .pb node_mutations order)
     std::vector<uint32_t> node_woff;   // [N+1]
@@ -71,18 +93,12 @@ struct FlatMAT {
     std::vector<uint32_t> parent_dfs;  // [N] DFS index of parent (root: 0)  (host only)
     std::vector<uint32_t> dfs_end;     // [N] last DFS index of the subtree  (host only)
     std::vector<uint32_t> num_leaves;  // [N]                                (host only)
-    // sweep stream: blocks of <=64 consecutive DFS nodes with <=128 events
-    std::vector<uint32_t> blk_node0;   // [NB+1]
-    std::vector<uint32_t> blk_eoff;    // [NB+1]
-    std::vector<BlkSum> blk_sum;       // [NB]
-    std::vector<uint32_t> ev_word;     // [E]
-    std::vector<uint8_t> ev_meta;      // [E]
-    // checkpoints: enter words of every node still open when a sequential sweep
-    // reaches block i*cp_stride (node blk_node0[..]-1 unless a leaf, and its ancestors)
-    uint32_t cp_stride = 1;
-    std::vector<uint32_t> cp_off;      // [ncp+1]
-    std::vector<uint32_t> cp_word;
+    // streams[0 .. n-2] = crowns of increasing tau, streams.back() = whole tree
+    std::vector<Stream> streams;
+    const Stream& full() const { return streams.back(); }
 };
+
+constexpr uint32_t MAX_STREAMS = 8;
 
 // Returns WEPP_OK or an error code; `err` receives the message.
 int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err);

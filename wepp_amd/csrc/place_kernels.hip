@@ -18,6 +18,13 @@
 // read cost that read one summary update; blocks with events are re-evaluated
 // node by node (lane = node) for just the reads concerned.
 //
+// Work skipping (exact): score(n) >= base(n) - |S| for every node, and the best
+// score is <= the root's score, so a read with theta = score(root) + |S| only
+// needs the "crown" of nodes with base <= theta (plus ancestors).  k_route
+// computes theta per read, k_scatter groups the reads by the smallest crown
+// stream that covers them, and k_sweep runs once per non-empty group on that
+// stream (the whole tree being the last one).
+//
 // Integer work only: no MFMA.  The bound is the event stream (HBM/L2 bytes).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -79,11 +86,6 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o < v ? o : v; }
     return v;
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o > v ? o : v; }
-    return v;
-}
 
 // lower_bound over a position-sorted slice of read words; returns the entry
 // with exactly `pos` or NONE.
@@ -105,19 +107,80 @@ __device__ __forceinline__ uint32_t find_entry(SPtr S, uint32_t off, uint32_t k,
 }  // namespace
 
 // -----------------------------------------------------------------------------
-// tile_max_entries: largest number of read words any tile brings into LDS.
+// k_route: theta(read) = score(root) + |S| -> index of the smallest stream whose
+// tau covers it.  Per-(block, tier) counts go to blk_counts, per-tier totals and
+// the largest read of each tier to tier_info.
 // -----------------------------------------------------------------------------
-__global__ void k_tile_max_entries(const uint32_t* __restrict__ read_off, uint32_t n_reads, uint32_t T,
-                                   uint32_t* __restrict__ out_max) {
-    uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ntiles = (n_reads + T - 1) / T;
-    uint32_t v = 0;
-    if (tile < ntiles) {
-        uint32_t r0 = tile * T, r1 = min(n_reads, r0 + T);
-        v = read_off[r1] - read_off[r0];
+__global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_t* __restrict__ read_off,
+                                                          const uint32_t* __restrict__ read_word, uint32_t n_reads,
+                                                          int use_crowns, uint8_t* __restrict__ tier_of,
+                                                          uint32_t* __restrict__ blk_counts,
+                                                          uint32_t* __restrict__ tier_info) {
+    __shared__ uint32_t cnt[MAX_STREAMS], mx[MAX_STREAMS];
+    if (threadIdx.x < MAX_STREAMS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
+    __syncthreads();
+    const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
+    for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+        const uint32_t so = read_off[r], k = read_off[r + 1] - so;
+        int c = 0;
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t sw = read_word[so + j];
+            if (!rw_missing(sw)) c += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0;
+        }
+        for (uint32_t w = m.node_woff[0]; w < m.node_woff[1]; w++) {   // the root's own mutations
+            const uint32_t tw = m.words[w];
+            const uint32_t sw = find_entry(read_word, so, k, w_pos(tw));
+            if (sw != NONE) c += enter_delta(tw, sw);
+        }
+        const int theta = m.root_base + c + (int)k;
+        uint32_t t = m.n_streams - 1;
+        if (use_crowns)
+            for (uint32_t i = 0; i + 1 < m.n_streams; i++)
+                if (theta <= m.tau[i]) { t = i; break; }
+        tier_of[r] = (uint8_t)t;
+        atomicAdd(&cnt[t], 1u);
+        atomicMax(&mx[t], k);
     }
-    v = wave_max_u32(v);
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
+    __syncthreads();
+    if (threadIdx.x < MAX_STREAMS) {
+        blk_counts[blockIdx.x * MAX_STREAMS + threadIdx.x] = cnt[threadIdx.x];
+        if (cnt[threadIdx.x]) {
+            atomicAdd(&tier_info[TI_COUNT + threadIdx.x], cnt[threadIdx.x]);
+            atomicMax(&tier_info[TI_MAXK + threadIdx.x], mx[threadIdx.x]);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// k_scatter: list[] = read indices grouped by tier (same block decomposition as
+// k_route; a block's reads of one tier occupy a contiguous range).
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __restrict__ tier_of, uint32_t n_reads,
+                                                            const uint32_t* __restrict__ blk_counts,
+                                                            uint32_t* __restrict__ tier_info,
+                                                            uint32_t* __restrict__ list) {
+    __shared__ uint32_t base[MAX_STREAMS], cur[MAX_STREAMS];
+    if (threadIdx.x < MAX_STREAMS) {
+        const uint32_t t = threadIdx.x;
+        uint32_t off = 0;                       // start of tier t in the list
+        for (uint32_t i = 0; i < t; i++) off += tier_info[TI_COUNT + i];
+        uint32_t before = 0;                    // reads of tier t in earlier blocks
+        for (uint32_t b = 0; b < blockIdx.x; b++) before += blk_counts[b * MAX_STREAMS + t];
+        base[t] = off + before;
+        cur[t] = 0;
+        if (blockIdx.x == 0) {
+            tier_info[TI_OFF + t] = off;
+            if (t == MAX_STREAMS - 1) tier_info[TI_OFF + MAX_STREAMS] = off + tier_info[TI_COUNT + t];
+        }
+    }
+    __syncthreads();
+    const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
+    for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+        const uint32_t t = tier_of[r];
+        list[base[t] + atomicAdd(&cur[t], 1u)] = r;
+    }
 }
 
 // -----------------------------------------------------------------------------
@@ -126,45 +189,55 @@ __global__ void k_tile_max_entries(const uint32_t* __restrict__ read_off, uint32
 // words.  part_* receive one (score, rank, count) per (chunk, read).
 // -----------------------------------------------------------------------------
 template <bool S_IN_LDS>
-__global__ __launch_bounds__(64) void k_sweep(DevMAT m, const uint32_t* __restrict__ read_off,
-                                              const uint32_t* __restrict__ read_word, uint32_t n_reads,
+__global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, uint32_t max_pos,
+                                              const uint32_t* __restrict__ read_off,
+                                              const uint32_t* __restrict__ read_word,
+                                              const uint32_t* __restrict__ list, uint32_t n_list,
                                               uint32_t T, uint32_t ntiles, uint32_t blocks_per_chunk,
                                               int32_t* __restrict__ part_score,
                                               uint32_t* __restrict__ part_rank,
                                               uint32_t* __restrict__ part_cnt) {
     extern __shared__ uint32_t lds[];
     uint32_t* bitmap = lds;
-    uint32_t* S_lds = lds + m.bm_words;
+    uint32_t* S_lds = lds + bm_words;
 
     const uint32_t lane = threadIdx.x;
     const uint32_t tile = blockIdx.x % ntiles;
     const uint32_t chunk = blockIdx.x / ntiles;
-    const uint32_t r0 = tile * T;
-    const uint32_t nr = min(T, n_reads - r0);
+    const uint32_t r0 = tile * T;                   // first list slot of the tile
+    const uint32_t nr = min(T, n_list - r0);
     const bool have = lane < nr;
+    const uint32_t rd = have ? list[r0 + lane] : 0;   // this lane's read
+    const uint32_t so = have ? read_off[rd] : 0;
+    const uint32_t my_k = have ? read_off[rd + 1] - so : 0;
 
-    const uint32_t sbeg = read_off[r0];
-    const uint32_t send = read_off[r0 + nr];
-    const uint32_t so = have ? read_off[r0 + lane] : sbeg;
-    const uint32_t se = have ? read_off[r0 + lane + 1] : sbeg;
-    const uint32_t n_ent = send - sbeg;
+    // exclusive prefix sum of the entry counts: where this lane's read sits in LDS
+    uint32_t incl = my_k;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    const uint32_t lds_off = incl - my_k;
 
-    for (uint32_t i = lane; i < m.bm_words; i += 64) bitmap[i] = 0;
+    for (uint32_t i = lane; i < bm_words; i += 64) bitmap[i] = 0;
     __syncthreads();
-    for (uint32_t i = lane; i < n_ent; i += 64) {
-        uint32_t w = read_word[sbeg + i];
-        if (S_IN_LDS) S_lds[i] = w;
-        uint32_t p = w_pos(w);
-        if (p <= m.max_pos) atomicOr(&bitmap[p >> 5], 1u << (p & 31));
+    // bm_words is a power of two >= (max_pos >> 5) + 1: positions beyond the tree's
+    // last mutated site (and the padding word) alias into the map; a false positive
+    // only costs a failed lookup in the reads.
+    const uint32_t bm_mask = bm_words - 1;
+    for (uint32_t j = 0; j < my_k; j++) {
+        const uint32_t w = read_word[so + j];
+        if (S_IN_LDS) S_lds[lds_off + j] = w;
+        const uint32_t p = w_pos(w);
+        if (p <= max_pos) atomicOr(&bitmap[(p >> 5) & bm_mask], 1u << (p & 31));
     }
     __syncthreads();
 
     // Slice of this lane's read inside S (LDS copy or the global array).
-    const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : (read_word + sbeg);
-    const uint32_t my_off = so - sbeg;
-    const uint32_t my_k = se - so;
-
-    auto bit = [&](uint32_t pos) -> bool { return (pos <= m.max_pos) && ((bitmap[pos >> 5] >> (pos & 31)) & 1u); };
+    const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : read_word;
+    const uint32_t my_off = S_IN_LDS ? lds_off : so;
+    auto bit = [&](uint32_t pos) -> bool { return (bitmap[(pos >> 5) & bm_mask] >> (pos & 31)) & 1u; };
 
     // c for "no mutation anywhere on the path": every non-missing entry is
     // compared with its own reference allele (usher_mapper.cpp:302-305,342).
@@ -351,7 +424,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevMAT m, const uint32_t* __restri
     }
 
     if (have) {
-        const size_t o = (size_t)chunk * n_reads + r0 + lane;
+        const size_t o = (size_t)chunk * n_list + r0 + lane;
         part_score[o] = bs;
         part_rank[o] = br;
         part_cnt[o] = cnt;
@@ -364,17 +437,18 @@ __global__ __launch_bounds__(64) void k_sweep(DevMAT m, const uint32_t* __restri
 // (usher_mapper.cpp:184,199,262,472,492).
 // -----------------------------------------------------------------------------
 __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
-                           const uint32_t* __restrict__ read_word, uint32_t n_reads, uint32_t nchunks,
-                           const int32_t* __restrict__ part_score, const uint32_t* __restrict__ part_rank,
-                           const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ best_bfs_j,
-                           int32_t* __restrict__ score, uint32_t* __restrict__ num_best,
-                           uint32_t* __restrict__ flags) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+                           const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
+                           uint32_t n_list, uint32_t nchunks, const int32_t* __restrict__ part_score,
+                           const uint32_t* __restrict__ part_rank, const uint32_t* __restrict__ part_cnt,
+                           uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
+                           uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+    const uint32_t r = list[i];
     int bs = 0x7FFFFFFF;
     uint32_t br = 0xFFFFFFFFu, cnt = 0;
     for (uint32_t ch = 0; ch < nchunks; ch++) {
-        const size_t o = (size_t)ch * n_reads + r;
+        const size_t o = (size_t)ch * n_list + i;
         const int s = part_score[o];
         if (s < bs) { bs = s; br = part_rank[o]; cnt = part_cnt[o]; }
         else if (s == bs) { cnt += part_cnt[o]; br = min(br, part_rank[o]); }
@@ -405,34 +479,42 @@ __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
 // -----------------------------------------------------------------------------
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
-hipError_t launch_tile_max_entries(const uint32_t* d_read_off, uint32_t n_reads, uint32_t T,
-                                   uint32_t* d_out_max, hipStream_t stream) {
-    uint32_t ntiles = (n_reads + T - 1) / T;
-    uint32_t blocks = (ntiles + 255) / 256;
-    hipLaunchKernelGGL(k_tile_max_entries, dim3(blocks), dim3(256), 0, stream, d_read_off, n_reads, T, d_out_max);
+hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
+                        int use_crowns, uint8_t* tier_of, uint32_t* blk_counts, uint32_t* tier_info,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
+                       n_reads, use_crowns, tier_of, blk_counts, tier_info);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
-                        uint32_t n_reads, uint32_t T, uint32_t ntiles, uint32_t nchunks,
-                        uint32_t blocks_per_chunk, bool s_in_lds, uint32_t lds_bytes, int32_t* part_score,
-                        uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream) {
+hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32_t* blk_counts, uint32_t* tier_info,
+                          uint32_t* list, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scatter, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, tier_of, n_reads, blk_counts,
+                       tier_info, list);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
+                        const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
+                        uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds,
+                        uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
+                        hipStream_t stream) {
     const dim3 grid(ntiles * nchunks), block(64);
     if (s_in_lds)
-        hipLaunchKernelGGL(k_sweep<true>, grid, block, lds_bytes, stream, m, d_read_off, d_read_word, n_reads, T,
-                           ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+        hipLaunchKernelGGL(k_sweep<true>, grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, d_read_off,
+                           d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
     else
-        hipLaunchKernelGGL(k_sweep<false>, grid, block, lds_bytes, stream, m, d_read_off, d_read_word, n_reads, T,
-                           ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+        hipLaunchKernelGGL(k_sweep<false>, grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, d_read_off,
+                           d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
     return hipGetLastError();
 }
 
 hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
-                           uint32_t n_reads, uint32_t nchunks, const int32_t* part_score,
+                           const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
-    const uint32_t blocks = (n_reads + 255) / 256;
-    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, m, d_read_off, d_read_word, n_reads,
+    const uint32_t blocks = (n_list + 255) / 256;
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, m, d_read_off, d_read_word, list, n_list,
                        nchunks, part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags);
     return hipGetLastError();
 }
