@@ -147,7 +147,9 @@ int wepp_mat_set_tile_reads(wepp_mat_t *mat, uint32_t reads_per_tile);
 int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
 
 /* Timing of the dominant kernel (k_sweep), measured with HIP events recorded on
- * the launch stream around the sweep launches of every placement call since the
+ * the launch stream around the sweep (+ the 10-80 us finalize) launches of every
+ * placement call -- they run concurrently on internal side streams forked from
+ * and joined into the launch stream -- since the
  * handle was created or wepp_mat_timing_reset() was called (the most recent 64
  * calls are kept).  Blocks until those launches have finished.
  * mean_sweep_ms = mean duration of the sweep launches of one call; passes =

@@ -56,7 +56,7 @@ class FlatModel:
         self.NB = len(self.blk_node0) - 1
         self.N = len(self.nkey)
         self.tau = int(flat.stats.stream_tau[self.stream])
-        self.cp_stride = max(1, (self.NB + 255) // 256)
+        self.cp_stride = max(1, (self.NB + 1023) // 1024)
 
     def _c_none(self, S):
         return sum(1 for (_, sref, a, missing) in S if not missing and (a & sref) == 0)
@@ -92,7 +92,7 @@ class FlatModel:
             n0 = int(self.blk_node0[b])
             nn = int(self.blk_node0[b + 1]) - n0
             hits = [e for e in range(e0, e1) if (int(self.ev_word[e]) & 0xFFFFF) in Sd]
-            base, rank, sc, min_all = (int(x) for x in self.blk_sum[b])
+            base, rank, sc, min_all = (int(x) for x in self.blk_sum[b][:4])
             if min_all >= 0x80000000:
                 min_all -= 1 << 32
             if not hits and node_scores is None:

@@ -203,8 +203,8 @@ class FlatView:
         if cnt.value == 0:
             return np.zeros(0, np.uint32)
         if base == "blk_sum":
-            raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 4,)).copy()
-            return raw.reshape(-1, 4)
+            raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 8,)).copy()
+            return raw.reshape(-1, 8)   # base, rank, cnt, min_all, node0, nn, pad, pad
         dt = self._DT.get(base, np.uint32)
         cptr = ctypes.cast(data, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt)))
         return np.ctypeslib.as_array(cptr, shape=(cnt.value,)).copy()

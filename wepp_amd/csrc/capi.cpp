@@ -33,6 +33,9 @@ struct wepp_mat {
     size_t ws_bytes = 0;
     uint32_t* d_info = nullptr;       // tier_info (TI_WORDS) followed by blk_counts
     uint32_t* h_info = nullptr;       // pinned copy of tier_info
+    // the sweeps of different streams are independent: they run concurrently on side streams
+    hipStream_t side[MAX_STREAMS] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
     static constexpr uint32_t kRing = 64;
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_timed = 0;             // placement calls since the last timing reset
@@ -75,6 +78,11 @@ void release(wepp_mat* h) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
         if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
     }
+    for (uint32_t i = 0; i < MAX_STREAMS; i++) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
+    }
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     delete h;
 }
 
@@ -148,6 +156,11 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
+    for (uint32_t i = 0; i < MAX_STREAMS && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = sweep_set_max_lds(160 * 1024);
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     *out = h;
@@ -273,32 +286,34 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     }
     char* part_base = (char*)mat->ws + tier_bytes + list_bytes;
 
-    // ---- sweeps (timed as a group), then finalizes ----------------------------------
+    // ---- sweeps (timed as a group) + finalizes; the streams' launches are independent
+    // and run concurrently on side streams forked from / joined into `stream` ------
     const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
     HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
+    HIP_TRY(hipEventRecord(mat->fork_ev, stream));
     uint64_t passes = 0, bytes = 0;
     for (uint32_t i = 0; i < np; i++) {
         const Plan& p = plans[i];
+        hipStream_t q = (np > 1) ? mat->side[i] : stream;
+        if (np > 1) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         int32_t* ps = (int32_t*)(part_base + p.part_off);
         uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
         uint32_t* pc = pr + (size_t)p.nchunks * p.count;
         HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, T, p.ntiles,
-                             p.nchunks, p.bpc, p.s_in_lds, p.lds_bytes, ps, pr, pc, stream));
+                             p.nchunks, p.bpc, p.s_in_lds, p.lds_bytes, ps, pr, pc, q));
         passes += p.ntiles;                                   // every tile sweeps its stream once
         bytes += (uint64_t)p.ntiles * mat->stream_bytes[p.t];
+        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,
+                                d_best_bfs_j, d_score, d_num_best, d_flags, q));
+        if (np > 1) {
+            HIP_TRY(hipEventRecord(mat->join_ev[i], q));
+            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[i], 0));
+        }
     }
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
     mat->n_timed++;
     mat->last_passes = passes;
     mat->last_bytes = bytes;
-    for (uint32_t i = 0; i < np; i++) {
-        const Plan& p = plans[i];
-        int32_t* ps = (int32_t*)(part_base + p.part_off);
-        uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
-        uint32_t* pc = pr + (size_t)p.nchunks * p.count;
-        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,
-                                d_best_bfs_j, d_score, d_num_best, d_flags, stream));
-    }
     return WEPP_OK;
 }
 

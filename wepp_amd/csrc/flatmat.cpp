@@ -125,9 +125,9 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
             }
         }
     }
-    st.blk_sum.assign(st.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF});
+    st.blk_sum.assign(st.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF, 0, 0, 0, 0});
     for (uint32_t b = 0; b < st.NB; b++) {
-        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF};
+        BlkSum s{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF, st.blk_node0[b], st.blk_node0[b + 1] - st.blk_node0[b], 0, 0};
         for (uint32_t d = st.blk_node0[b]; d < st.blk_node0[b + 1]; d++) {
             const int32_t bs = (int32_t)(st.nkey[d] >> 32);
             const uint32_t rk = (uint32_t)(st.nkey[d] & 0xFFFFFFFFll);
@@ -139,7 +139,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
         st.blk_sum[b] = s;
     }
     // checkpoints
-    st.cp_stride = std::max<uint32_t>(1, (st.NB + 255) / 256);
+    st.cp_stride = std::max<uint32_t>(1, (st.NB + 1023) / 1024);   // <= 1024 places where a sweep may start
     {
         const uint32_t ncp = (st.NB + st.cp_stride - 1) / st.cp_stride;
         st.cp_off.assign(ncp + 1, 0);

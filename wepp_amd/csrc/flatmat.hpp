@@ -52,6 +52,8 @@ struct BlkSum {          // read-independent summary of one sweep block
     uint32_t rank;       // tie-break rank of that minimum
     uint32_t cnt;        // number of statically eligible nodes attaining `base`
     int32_t min_all;     // min static score over ALL nodes of the block (pruning bound)
+    uint32_t node0, nn;  // first node / node count of the block (heavy path)
+    uint32_t pad0, pad1; // 32-byte records: one s_load_dwordx8 per block
 };
 
 // One sweep stream: the events of an ancestor-closed subset of the nodes (a

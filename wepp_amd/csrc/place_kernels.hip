@@ -272,23 +272,20 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
 
-    // ---- node-by-node evaluation of block b for read r (lane = node) ----------
-    auto heavy_eval = [&](uint32_t b, uint32_t e0, uint32_t e1, int r) {
-        const uint32_t n0 = m.blk_node0[b];
-        const uint32_t nn = m.blk_node0[b + 1] - n0;
+    // ---- node-by-node evaluation of one block for read r (lane = node) ----------
+    // Everything it needs was fetched when the first hit of the block was seen:
+    // w0/w1 + m0/m1 = this lane's two events and their node offsets, key/st = this
+    // lane's node.
+    auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t m0,
+                          uint32_t m1, int64_t key, uint32_t st, int r) {
+        const uint32_t n0 = sum.node0;
         const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
         const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
         const int c_r = __builtin_amdgcn_readlane(c, r);
         const int bs_r = __builtin_amdgcn_readlane(bs, r);
-        const bool nvalid = lane < nn;
-        const int64_t key = nvalid ? m.nkey[n0 + lane] : 0;
-        const uint32_t st = nvalid ? m.nstat[n0 + lane] : 0;
         int cadd = 0, adj = 0, dcom = 0;
         bool touched = false;
-        for (uint32_t e = e0; e < e1; e += 64) {
-            const bool valid = e + lane < e1;
-            const uint32_t w = valid ? m.ev_word[e + lane] : W_PAD_DEV;
-            const uint32_t mt = valid ? (uint32_t)m.ev_meta[e + lane] : 0;
+        auto apply = [&](uint32_t w, uint32_t mt) {
             const uint32_t sw = bit(w_pos(w)) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
             unsigned long long hm = __ballot(sw != NONE);
             while (hm) {
@@ -314,6 +311,12 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
                     }
                 }
             }
+        };
+        apply(w0, m0);
+        apply(w1, m1);
+        for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
+            const bool valid = e + lane < e1;
+            apply(valid ? m.ev_word[e + lane] : W_PAD_DEV, valid ? (uint32_t)m.ev_meta[e + lane] : 0u);
         }
         const int base = (int)(key >> 32);
         const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             const int ncom = (int)ncom0 + dcom;
             elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
         } else elig = st & NS_ELIG0_DEV;
-        elig = elig && nvalid;
+        elig = elig && (lane < sum.nn);
         if (__ballot(elig && score <= bs_r)) {
             const int smin = wave_min_i32(elig ? score : 0x7FFFFFFF);
             const bool at_min = elig && score == smin;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
 
     // ---- one block: lane = read ----------------------------------------------------
     // w0/w1 = this lane's two words of the block's first 128 events (W_PAD beyond e1)
-    auto process_block = [&](uint32_t b, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, const BlkSum sum) {
+    auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, const BlkSum sum) {
         int net = 0, H = 0;
         bool touched = false;
         // for a hit event, every read looks the position up in its own entries
@@ -359,13 +362,26 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
                 else { net += d; H += ad + 1; }
             }
         };
-        unsigned long long hm = __ballot(bit(w_pos(w0)));
+        const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
+        // a block with a hit may need the node-by-node evaluation: fetch what it reads
+        // now, so that the loads overlap the lookups below
+        uint32_t m0 = 0, m1 = 0, st = 0;
+        int64_t key = 0;
+        if ((hm0 | hm1) || e1 - e0 > 128) {
+            if (e0 + 2 * lane < e1) {
+                const uint32_t mm = *reinterpret_cast<const uint16_t*>(m.ev_meta + e0 + 2 * lane);
+                m0 = mm & 0xFFu;
+                m1 = mm >> 8;
+            }
+            if (lane < sum.nn) { key = m.nkey[sum.node0 + lane]; st = m.nstat[sum.node0 + lane]; }
+        }
+        unsigned long long hm = hm0;
         while (hm) {
             const int l = __builtin_ctzll(hm);
             hm &= hm - 1;
             light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l));
         }
-        hm = __ballot(bit(w_pos(w1)));
+        hm = hm1;
         while (hm) {
             const int l = __builtin_ctzll(hm);
             hm &= hm - 1;
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
         while (hv) {
             const int r = __builtin_ctzll(hv);
             hv &= hv - 1;
-            heavy_eval(b, e0, e1, r);
+            heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r);
         }
         if (touched) c += net;
     };
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             }
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (j + q < ng) process_block(bb + j + q, e[q], e[q + 1], ww[q].x, ww[q].y, sm[q]);
+                if (j + q < ng) process_block(e[q], e[q + 1], ww[q].x, ww[q].y, sm[q]);
         }
     }
 
@@ -436,23 +452,39 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
 // reference's BFS index and recompute its has_unique flag
 // (usher_mapper.cpp:184,199,262,472,492).
 // -----------------------------------------------------------------------------
+template <bool WAVE_PER_READ>
 __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
                            const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
                            uint32_t n_list, uint32_t nchunks, const int32_t* __restrict__ part_score,
                            const uint32_t* __restrict__ part_rank, const uint32_t* __restrict__ part_cnt,
                            uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
                            uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // few chunks: one thread per list entry; many chunks (small batches): one wave
+    // per entry, lanes stride over the chunks, then a wave reduction
+    const uint32_t lane = WAVE_PER_READ ? (threadIdx.x & 63) : 0;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = WAVE_PER_READ ? (gid >> 6) : gid;
     if (i >= n_list) return;
     const uint32_t r = list[i];
     int bs = 0x7FFFFFFF;
     uint32_t br = 0xFFFFFFFFu, cnt = 0;
-    for (uint32_t ch = 0; ch < nchunks; ch++) {
+    for (uint32_t ch = lane; ch < nchunks; ch += (WAVE_PER_READ ? 64 : 1)) {
         const size_t o = (size_t)ch * n_list + i;
         const int s = part_score[o];
         if (s < bs) { bs = s; br = part_rank[o]; cnt = part_cnt[o]; }
         else if (s == bs) { cnt += part_cnt[o]; br = min(br, part_rank[o]); }
     }
+    if (WAVE_PER_READ) {
+        const int smin = wave_min_i32(bs);
+        const bool at = (bs == smin) && cnt > 0;
+        br = wave_min_u32(at ? br : 0xFFFFFFFFu);
+        uint32_t csum = at ? cnt : 0;
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) csum += (uint32_t)__shfl_xor((int)csum, msk, 64);
+        bs = smin;
+        cnt = csum;
+    }
+    if (lane != 0) return;
     const uint32_t d = m.rank2dfs[br];
     const uint32_t st = m.nstat[d];
     uint32_t hu = 0;
@@ -513,9 +545,13 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
-    const uint32_t blocks = (n_list + 255) / 256;
-    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, m, d_read_off, d_read_word, list, n_list,
-                       nchunks, part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags);
+    if (nchunks > 8)
+        hipLaunchKernelGGL(k_finalize<true>, dim3((n_list + 3) / 4), dim3(256), 0, stream, m, d_read_off, d_read_word,
+                           list, n_list, nchunks, part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags);
+    else
+        hipLaunchKernelGGL(k_finalize<false>, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, d_read_off,
+                           d_read_word, list, n_list, nchunks, part_score, part_rank, part_cnt, best_bfs_j, score,
+                           num_best, flags);
     return hipGetLastError();
 }
 
