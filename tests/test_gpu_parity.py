@@ -32,9 +32,11 @@ def test_golden_fixtures_through_the_c_abi():
         reads = Reads.from_lists([r["sample"] for r in case["results"]])
         mat = w.Mat(tree)
         assert mat.bfs_order().tolist() == case["bfs_ids"]
-        res = mat.place_batch(reads)
+        res = mat.place_batch(reads, per_node_scores=True)
         want = {k: np.array([r[k] for r in case["results"]]) for k in ("score", "num_best", "best_j", "has_unique")}
         assert_same(res, want, case["name"])
+        # -p mode: every node's value in BFS order (incl. the +1 of non-competing nodes)
+        assert res.per_node_scores.tolist() == [r["node_scores"] for r in case["results"]], case["name"]
         mat.close()
 
 
@@ -49,6 +51,31 @@ def test_fuzz_trees_vs_oracle(oracle, tile):
         res = mat.place_batch(reads)
         assert_same(res, oracle.OracleTree(tree).place_batch(reads, 8), f"fuzz {it} tile {tile}")
         mat.close()
+
+
+def test_per_node_scores_mode_vs_oracle(oracle):
+    """--write-parsimony-scores-per-node: all N values per read (usher_common.cpp:403-409)."""
+    rng = np.random.default_rng(321)
+    for it in range(25):
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(1, 500)), genome=int(rng.choice([60, 300])),
+                                   max_muts=int(rng.choice([2, 5])))
+        samples = [ft.random_sample(rng, ref, genome=max(ref)) for _ in range(int(rng.integers(1, 12)))]
+        mat = w.Mat(tree)
+        res = mat.place_batch(ft.reads_from_samples(samples), per_node_scores=True)
+        ot = oracle.OracleTree(tree)
+        for q, S in enumerate(samples):
+            cols = list(zip(*S)) if S else ([], [], [], [])
+            assert (res.per_node_scores[q] == ot.place_sample(*cols, per_node_scores=True)["node_scores"]).all(), (it, q)
+        mat.close()
+    g = w.generate_tree(61, 30000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=2)
+    reads = g.reads(62, 12, p_iupac=0.1)
+    mat = w.Mat(g.tree)
+    res = mat.place_batch(reads, per_node_scores=True)
+    ot = oracle.OracleTree(g.tree)
+    for q in range(reads.n_reads):
+        p, rf, a, ms = reads.entries(q)
+        assert (res.per_node_scores[q] == ot.place_sample(p, rf, a, ms, per_node_scores=True)["node_scores"]).all()
+    mat.close()
 
 
 def test_config1_rsv_like(oracle):

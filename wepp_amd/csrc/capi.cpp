@@ -348,7 +348,8 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
                                 uint32_t n_reads, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
                                 uint32_t* flags, int32_t* per_node_scores) {
     if (!mat || !read_off) return set_error(WEPP_EINVAL, "null argument");
-    if (per_node_scores) return set_error(WEPP_EINVAL, "per_node_scores is not implemented yet");
+    if (per_node_scores && (uint64_t)n_reads * mat->dev.N > (1ull << 31))
+        return set_error(WEPP_ELIMIT, "per_node_scores: n_reads * n_nodes exceeds 2^31 values; split the batch");
     if (n_reads == 0) return WEPP_OK;
     if (read_off[0] != 0) return set_error(WEPP_EINVAL, "read_off[0] must be 0");
     const uint64_t nw = read_off[n_reads];
@@ -365,6 +366,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     }
     HIP_TRY(hipSetDevice(mat->device));
     uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
+    int32_t* d_pns = nullptr;
     int rc = WEPP_OK;
     hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
@@ -376,6 +378,14 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     rc = wepp_place_batch_device(mat, d_off, d_word, n_reads, nw, d_out, (int32_t*)(d_out + n_reads),
                                  d_out + 2 * (size_t)n_reads, d_out + 3 * (size_t)n_reads, nullptr);
     if (rc != WEPP_OK) goto done;
+    if (per_node_scores) {
+        const size_t nb = (size_t)n_reads * mat->dev.N * sizeof(int32_t);
+        e = hipMalloc((void**)&d_pns, nb);
+        if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc per_node_scores: ") + hipGetErrorString(e)); goto done; }
+        e = launch_scores(mat->dev, mat->streams.back(), d_off, d_word, n_reads, d_pns, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(per_node_scores, d_pns, nb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = hip_fail(e, "per-node score kernel"); goto done; }
+    }
     e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess && best_bfs_j) e = hipMemcpy(best_bfs_j, d_out, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && score) e = hipMemcpy(score, d_out + n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
@@ -386,5 +396,6 @@ done:
     if (d_off) (void)hipFree(d_off);
     if (d_word) (void)hipFree(d_word);
     if (d_out) (void)hipFree(d_out);
+    if (d_pns) (void)hipFree(d_pns);
     return rc;
 }

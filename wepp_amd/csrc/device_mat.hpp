@@ -61,6 +61,8 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
+hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t* d_read_off,
+                         const uint32_t* d_read_word, uint32_t n_reads, int32_t* d_out, hipStream_t stream);
 hipError_t sweep_set_max_lds(uint32_t bytes);
 
 // layout of tier_info (uint32): [0..8) counts, [8..16) max entries of one read, [16..25) offsets into the list

@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_mat.hpp"
 
 namespace wepp {
@@ -509,6 +511,98 @@ __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
 }
 
 // -----------------------------------------------------------------------------
+// k_scores: the -p mode (--write-parsimony-scores-per-node): node_set_difference
+// of EVERY node for every read, in BFS order, +1 for nodes that do not compete
+// (usher_common.cpp:403-409, usher_mapper.cpp:449-451,500-505).  One wave per
+// (read, chunk of the whole-tree stream), lane = node; an R x N output only makes
+// sense for small batches, so no tiling and no pruning here.
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_scores(DevStream m, const uint32_t* __restrict__ dfs2bfs,
+                                               const uint32_t* __restrict__ read_off,
+                                               const uint32_t* __restrict__ read_word, uint32_t n_reads,
+                                               uint32_t blocks_per_chunk, int32_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t r = blockIdx.x % n_reads;
+    const uint32_t chunk = blockIdx.x / n_reads;
+    const uint32_t so = read_off[r], k = read_off[r + 1] - so;
+    int c = 0;                                    // wave-uniform running c_S
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t sw = read_word[so + j];
+        if (!rw_missing(sw)) c += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0;
+    }
+    const uint32_t b0 = chunk * blocks_per_chunk;
+    const uint32_t b1 = min(m.NB, b0 + blocks_per_chunk);
+    {
+        const uint32_t cpi = b0 / m.cp_stride;
+        const uint32_t e0 = m.cp_off[cpi], e1 = m.cp_off[cpi + 1];
+        for (uint32_t e = e0; e < e1; e += 64) {
+            int d = 0;
+            if (e + lane < e1) {
+                const uint32_t w = m.cp_word[e + lane];
+                const uint32_t sw = find_entry(read_word, so, k, w_pos(w));
+                if (sw != NONE) d = enter_delta(w, sw);
+            }
+#pragma unroll
+            for (int msk = 32; msk >= 1; msk >>= 1) d += __shfl_xor(d, msk, 64);
+            c += d;
+        }
+    }
+    for (uint32_t b = b0; b < b1; b++) {
+        const BlkSum sum = m.blk_sum[b];
+        const uint32_t e0 = m.blk_eoff[b], e1 = m.blk_eoff[b + 1];
+        const bool nvalid = lane < sum.nn;
+        const int64_t key = nvalid ? m.nkey[sum.node0 + lane] : 0;
+        const uint32_t st = nvalid ? m.nstat[sum.node0 + lane] : 0;
+        int cadd = 0, adj = 0, dcom = 0, net = 0;
+        bool touched = false;
+        for (uint32_t e = e0; e < e1; e += 64) {
+            const bool valid = e + lane < e1;
+            const uint32_t w = valid ? m.ev_word[e + lane] : W_PAD_DEV;
+            const uint32_t mt = valid ? (uint32_t)m.ev_meta[e + lane] : 0;
+            const uint32_t sw = (valid && w != W_PAD_DEV) ? find_entry(read_word, so, k, w_pos(w)) : NONE;
+            unsigned long long hm = __ballot(sw != NONE);
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mt, l) & EV_OFF_MASK_DEV;
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)sw, l);
+                const int delta = enter_delta(wl, sl);
+                if (wl & W_EXIT_DEV) {
+                    cadd += (lane >= o) ? -delta : 0;
+                    net -= delta;
+                } else {
+                    if (!(wl & W_LEAF_DEV)) {
+                        const bool is_root = (sum.node0 + o) == 0;
+                        cadd += (lane > o || (is_root && lane == o)) ? delta : 0;
+                        net += delta;
+                    }
+                    if (lane == o) {
+                        touched = true;
+                        own_adjust(wl, sl, adj, dcom);
+                    }
+                }
+            }
+        }
+        const int base = (int)(key >> 32);
+        const uint32_t nmut = st & NS_CNT_MASK_DEV;
+        const uint32_t ncom0 = (st >> 14) & NS_CNT_MASK_DEV;
+        const bool leaf = st & NS_LEAF_DEV, masked = st & NS_MASKED_DEV, root = st & NS_ROOT_DEV;
+        bool elig;
+        int score = base + c + cadd;
+        if (root) elig = true;
+        else if (masked) elig = false;
+        else if (touched) {
+            score += adj;
+            const int ncom = (int)ncom0 + dcom;
+            elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);
+        } else elig = st & NS_ELIG0_DEV;
+        if (nvalid) out[(size_t)r * m.n + dfs2bfs[sum.node0 + lane]] = elig ? score : score + 1;
+        c += net;
+    }
+}
+
+// -----------------------------------------------------------------------------
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
@@ -552,6 +646,18 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
         hipLaunchKernelGGL(k_finalize<false>, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, d_read_off,
                            d_read_word, list, n_list, nchunks, part_score, part_rank, part_cnt, best_bfs_j, score,
                            num_best, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t* d_read_off,
+                         const uint32_t* d_read_word, uint32_t n_reads, int32_t* d_out, hipStream_t stream) {
+    // enough waves to fill the chip, cut at checkpoints
+    uint32_t nchunks = std::max<uint32_t>(1, (8192 + n_reads - 1) / n_reads);
+    nchunks = std::min(nchunks, full.ncp);
+    const uint32_t bpc = ((full.ncp + nchunks - 1) / nchunks) * full.cp_stride;
+    nchunks = (full.NB + bpc - 1) / bpc;
+    hipLaunchKernelGGL(k_scores, dim3(n_reads * nchunks), dim3(64), 0, stream, full, m.dfs2bfs, d_read_off,
+                       d_read_word, n_reads, bpc, d_out);
     return hipGetLastError();
 }
 
