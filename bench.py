@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0,
                     help="target wall time of the CPU baseline sample (0 disables it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=2,
+                    help="extra untimed-for-value steps with work skipping off (whole-tree streaming roofline)")
     ap.add_argument("--no-crowns", action="store_true",
                     help="disable work skipping: every read sweeps the whole-tree stream (roofline run)")
     return ap.parse_args()
@@ -95,6 +97,18 @@ def cpu_baseline(tree, reads, gpu_res, target_s):
                   f"(like tbb::parallel_for over nodes), {dt:.1f} s; probe read {t1:.2f} s",
         "sample_matches_gpu": ok,
     }
+
+
+def pmc_traffic(mode):
+    """HBM-side bytes per step of k_sweep from the committed rocprofv3 PMC profile of
+    this same command (profiles/pmc_traffic.json, written by tools/summarize_profile.py);
+    None when no profile is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            t = json.load(fh)[mode]
+        return t["traffic_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -169,6 +183,24 @@ def main():
 
     sweep_ms, n_launch, passes, alg_bytes = mat.last_timing()
 
+    # ---- the "HBM-roofline run" of configs[2]: same batch, work skipping off, so that
+    # every tile streams the whole-tree event stream once (not part of `value`) ----
+    whole = None
+    if not args.no_crowns and args.roofline_steps > 0:
+        ref_out = [t.clone() for t in (d_best, d_score, d_nbest, d_flags)]
+        mat.set_use_crowns(False)
+        step()
+        fence()
+        mat.timing_reset()
+        for _ in range(args.roofline_steps):
+            step()
+        fence()
+        w_ms, w_n, w_passes, w_bytes = mat.last_timing()
+        same = all(bool((a == b).all()) for a, b in zip(ref_out, (d_best, d_score, d_nbest, d_flags)))
+        mat.set_use_crowns(True)
+        whole = {"kernel_ms_per_step": w_ms, "steps_timed": w_n, "stream_sweeps_per_step": w_passes,
+                 "algorithmic_bytes_per_step": w_bytes, "results_identical_to_timed_run": same}
+
     if rank == 0:
         gpu_res = {"score": d_score.cpu().numpy(), "best": d_best.cpu().numpy().view(np.uint32),
                    "num_best": d_nbest.cpu().numpy().view(np.uint32), "flags": d_flags.cpu().numpy().view(np.uint32)}
@@ -209,7 +241,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("work_skipping_off" if args.no_crowns else "work_skipping_on"),
+                "traffic_note": "bytes per step leaving the L2s, (2*FETCH_SIZE+WRITE_SIZE)*1024 from a separate "
+                                "rocprofv3 --pmc run of this command (profiles/); Infinity-Cache hits included",
                 "algorithmic_bytes_per_step": alg_bytes,
                 "stream_sweeps_per_step": passes,
                 "kernel_ms_per_step": sweep_ms,
@@ -219,6 +253,14 @@ def main():
                              "bytes": int(st.stream_bytes_of[i])} for i in range(st.n_streams)],
             },
         }
+        if whole is not None:
+            a = whole["algorithmic_bytes_per_step"] / (whole["kernel_ms_per_step"] * 1e-3) / 1e9
+            out["roofline_whole_tree"] = {
+                "what": "same batch with work skipping off: every 64-read tile streams the whole-tree event "
+                        "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`",
+                "bound": "hbm", "kernel": "k_sweep", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic("work_skipping_off"),
+                "reads_per_s": R / (whole["kernel_ms_per_step"] * 1e-3), **whole}
         if world == 1 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(g.tree, reads, gpu_res, args.cpu_baseline_seconds)
         else:

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 "$@" > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 echo "trace rc=$?"
 cat "$OUT"/trace/*/*_kernel_stats.csv
 python3 - "$OUT" <<'PY'

@@ -19,6 +19,7 @@ constexpr uint32_t WEPP_FLAG_HAS_UNIQUE_DEV = WEPP_FLAG_HAS_UNIQUE;
 // one sweep stream (a crown or the whole tree), see flatmat.hpp
 struct DevStream {
     uint32_t n, NB, cp_stride, ncp;
+    uint32_t eager;   // 1 on crown streams: fetch node data as soon as a block has a hit
     const int64_t* nkey;
     const uint32_t* nstat;
     const uint32_t* blk_node0;

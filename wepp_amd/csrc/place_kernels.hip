@@ -369,14 +369,20 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
         // now, so that the loads overlap the lookups below
         uint32_t m0 = 0, m1 = 0, st = 0;
         int64_t key = 0;
-        if ((hm0 | hm1) || e1 - e0 > 128) {
+        bool fetched = false;
+        auto fetch_nodes = [&]() {
             if (e0 + 2 * lane < e1) {
                 const uint32_t mm = *reinterpret_cast<const uint16_t*>(m.ev_meta + e0 + 2 * lane);
                 m0 = mm & 0xFFu;
                 m1 = mm >> 8;
             }
             if (lane < sum.nn) { key = m.nkey[sum.node0 + lane]; st = m.nstat[sum.node0 + lane]; }
-        }
+            fetched = true;
+        };
+        // crown streams hold only low-score nodes, so a hit nearly always ends in the
+        // node-by-node path: start its loads before the lookups.  On the whole-tree
+        // stream the bound prunes ~95 % of the hits and the loads are issued on demand.
+        if (m.eager && (hm0 | hm1)) fetch_nodes();
         unsigned long long hm = hm0;
         while (hm) {
             const int l = __builtin_ctzll(hm);
@@ -412,6 +418,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
         while (hv) {
             const int r = __builtin_ctzll(hv);
             hv &= hv - 1;
+            if (!fetched) fetch_nodes();
             heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r);
         }
         if (touched) c += net;
