@@ -1,0 +1,161 @@
+"""The C++ host mirror of the reference interface (wepp_amd/host): .pb / VCF
+loaders on the CPU, and the usher-compatible driver `wepp-usher` end to end on
+the GPU against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fuzz_trees as ft
+import pb_fixture as pbf
+import wepp_amd as w
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "wepp_amd", "wepp-usher")
+
+
+def _names(parent):
+    n = len(parent)
+    has_child = [False] * n
+    for p in parent:
+        if p >= 0:
+            has_child[p] = True
+    return [f"label{i}" if has_child[i] else f"leaf_{i}|x/2021" for i in range(n)]
+
+
+def _tree_lists(tree):
+    muts = []
+    for i in range(tree.n_nodes):
+        a, b = int(tree.mut_off[i]), int(tree.mut_off[i + 1])
+        muts.append([(int(tree.mut_pos[k]), int(tree.mut_ref[k]), int(tree.mut_par[k]), int(tree.mut_mut[k]))
+                     for k in range(a, b)])
+    return tree.parent.tolist(), muts
+
+
+def _expected_dump(parent, names, muts, dfs):
+    """What the loader must produce: internal nodes renamed node_<k> in order of
+    appearance in the Newick (= DFS order), mutations with mut == par dropped,
+    masked mutations zeroed."""
+    newname = {}
+    k = 0
+    has_child = [False] * len(parent)
+    for p in parent:
+        if p >= 0:
+            has_child[p] = True
+    for i in dfs:
+        if has_child[i]:
+            k += 1
+            newname[i] = f"node_{k}"
+        else:
+            newname[i] = names[i]
+    return newname
+
+
+def _as_vcf_reader_sees(e):
+    """An allele that decodes to N -- 'N' itself, or 'V' through upstream's
+    fall-through (mutation_annotated_tree.cpp:65-71) -- is read back as missing (:2105-2111)."""
+    p, r, a, ms = e
+    if a in (15, 7):
+        return (p, r, 15, 1)
+    return (p, r, a, 1 if ms else 0)
+
+
+def _run_dump(pb, vcf):
+    out = subprocess.run([CLI, "-i", pb, "-v", vcf, "--dump"], check=True, capture_output=True, text=True).stdout
+    nodes, samples = {}, {}
+    for line in out.splitlines():
+        f = line.split()
+        if f[0] == "node":
+            nodes[f[1]] = (f[3], [tuple(int(x) for x in t.split(":")) for t in f[5:]])
+        elif f[0] == "sample":
+            samples[f[1]] = [tuple(int(x) for x in t.split(":")) for t in f[2:]]
+    return nodes, samples
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_pb_and_vcf_loaders(tmp_path, compress):
+    rng = np.random.default_rng(5 + compress)
+    for it in range(12):
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(2, 80)), p_root_masked=0.2)
+        parent, muts = _tree_lists(tree)
+        names = _names(parent)
+        # add a no-op mutation (mut == par) that the loader must drop (mutation_annotated_tree.cpp:580-582)
+        muts[-1] = muts[-1] + [(61, 1, 2, 2)]
+        samples = [ft.random_sample(rng, ref) for _ in range(5)]
+        snames = [f"sample_{i}" for i in range(5)]
+        pb = str(tmp_path / f"t{it}.pb") + (".gz" if compress else "")
+        vcf = str(tmp_path / f"s{it}.vcf") + (".gz" if compress else "")
+        dfs = pbf.write_pb(pb, parent, names, muts, compress=compress)
+        pbf.write_vcf(vcf, snames, samples, compress=compress)
+        nodes, got_samples = _run_dump(pb, vcf)
+        newname = _expected_dump(parent, names, muts, dfs)
+        assert len(nodes) == len(parent)
+        for i in range(len(parent)):
+            par_name, got = nodes[newname[i]]
+            assert par_name == (newname[parent[i]] if parent[i] >= 0 else "-")
+            # the .pb stores par_nuc as ONE nucleotide index, so an ambiguous parent allele is
+            # read back as its highest base (the scorer never reads par_nuc anyway)
+            lp = lambda pa: 1 << (pa.bit_length() - 1)
+            want = [(p, r, lp(pa), mu) if p >= 0 else (p, 0, 0, 0) for (p, r, pa, mu) in muts[i]
+                    if p < 0 or mu != lp(pa)]
+            assert got == sorted(want, key=lambda t: t[0]), (it, i)
+        for s, ents in zip(snames, samples):
+            # an ambiguity code that happens to be N is read back as missing (mutation_annotated_tree.cpp:2108-2111)
+            want = [_as_vcf_reader_sees(e) for e in ents]
+            assert got_samples[s] == want, (it, s)
+
+
+def test_samples_already_in_tree_are_ignored(tmp_path):
+    parent = [-1, 0, 0]
+    names = ["r", "A", "B"]
+    pb, vcf = str(tmp_path / "t.pb"), str(tmp_path / "s.vcf")
+    pbf.write_pb(pb, parent, names, [[], [(10, 1, 1, 2)], []])
+    pbf.write_vcf(vcf, ["A", "new1"], [[(10, 1, 2, 0)], [(10, 1, 2, 0)]])
+    nodes, samples = _run_dump(pb, vcf)
+    assert list(samples) == ["new1"] and set(nodes) == {"node_1", "A", "B"}
+
+
+def test_loader_errors_do_not_crash(tmp_path):
+    r = subprocess.run([CLI, "-i", str(tmp_path / "missing.pb"), "-v", str(tmp_path / "x.vcf"), "--dump"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_wepp_usher_end_to_end(tmp_path, oracle):
+    """usher -i tree.pb -v samples.vcf -n -d out [-p]: files and values as the reference writes them."""
+    rng = np.random.default_rng(99)
+    tree, ref = ft.random_tree(rng, n_nodes=300, genome=200, p_root_masked=0.0)
+    parent, muts = _tree_lists(tree)
+    names = _names(parent)
+    samples = [ft.random_sample(rng, ref, genome=200) for _ in range(40)]
+    snames = [f"s{i}" for i in range(40)]
+    pb, vcf = str(tmp_path / "t.pb.gz"), str(tmp_path / "s.vcf")
+    dfs = pbf.write_pb(pb, parent, names, muts, compress=True)
+    pbf.write_vcf(vcf, snames, samples)
+    out1, out2 = tmp_path / "o1", tmp_path / "o2"
+    out1.mkdir(); out2.mkdir()
+    r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-d", str(out1)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ot = oracle.OracleTree(tree)
+    newname = _expected_dump(parent, names, muts, dfs)
+    bfs = ot.bfs_ids()
+    rows = [l.split("\t") for l in open(out1 / "placement_stats.tsv").read().splitlines()]
+    assert len(rows) == 40
+    for q, S in enumerate(samples):
+        S = [_as_vcf_reader_sees(e) for e in S]
+        o = ot.place_sample(*(list(zip(*S)) if S else ([], [], [], [])))
+        assert rows[q][0] == snames[q] and int(rows[q][1]) == o["score"] and int(rows[q][2]) == o["num_best"]
+        assert f"Sample name: {snames[q]}\tParsimony score: {o['score']}\tNumber of parsimony-optimal placements: {o['num_best']}" in r.stderr
+    r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-p", "-d", str(out2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(out2 / "parsimony-scores.tsv").read().splitlines()
+    assert lines[0].startswith("#Sample\tTree node\tParsimony score")
+    assert len(lines) == 1 + 40 * 300
+    S = [_as_vcf_reader_sees(e) for e in samples[3]]
+    o = ot.place_sample(*(list(zip(*S)) if S else ([], [], [], [])), per_node_scores=True)
+    block = [l.split("\t") for l in lines[1 + 3 * 300: 1 + 4 * 300]]
+    assert [int(b[2]) for b in block] == o["node_scores"].tolist()
+    assert [b[1] for b in block] == [newname[int(i)] for i in bfs]
+    assert all((b[4] == "y") == (int(b[2]) == o["score"]) for b in block)

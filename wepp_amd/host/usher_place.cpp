@@ -1,0 +1,136 @@
+// usher_place.cpp -- see usher_place.hpp (citations: /root/reference/src/usher_common.cpp).
+#include "usher_place.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <unordered_map>
+
+#include "../../include/wepp_place.h"
+
+namespace {
+struct FileCloser {
+    FILE* f = nullptr;
+    ~FileCloser() { if (f) fclose(f); }
+};
+}  // namespace
+
+int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t max_parsimony,
+                        bool print_parsimony_scores, std::vector<Missing_Sample>& missing_samples,
+                        std::vector<std::string>& low_confidence_samples, MAT::Tree* T,
+                        std::vector<usher_place_result>* results, int device) {
+    if (!T || !T->root) {
+        fprintf(stderr, "ERROR: empty tree!\n");
+        return 1;
+    }
+    // BFS order once (the reference re-expands per sample, :339); node id = BFS
+    // index, so ascending id under a parent is the stored child order.
+    std::vector<MAT::Node*> bfs = T->breadth_first_expansion();
+    const size_t total_nodes = bfs.size();
+    std::unordered_map<const MAT::Node*, int32_t> id;
+    id.reserve(total_nodes * 2);
+    for (size_t k = 0; k < total_nodes; k++) id[bfs[k]] = (int32_t)k;
+    std::vector<int32_t> parent(total_nodes), mut_pos;
+    std::vector<uint32_t> mut_off(total_nodes + 1, 0);
+    std::vector<uint8_t> mut_ref, mut_par, mut_mut;
+    for (size_t k = 0; k < total_nodes; k++) {
+        parent[k] = bfs[k]->parent ? id[bfs[k]->parent] : -1;
+        for (auto& m : bfs[k]->mutations) {
+            mut_pos.push_back(m.position);
+            mut_ref.push_back((uint8_t)m.ref_nuc);
+            mut_par.push_back((uint8_t)m.par_nuc);
+            mut_mut.push_back((uint8_t)m.mut_nuc);
+        }
+        mut_off[k + 1] = (uint32_t)mut_pos.size();
+    }
+    wepp_tree_desc desc{(uint32_t)total_nodes, parent.data(), mut_off.data(), mut_pos.data(),
+                        mut_ref.data(), mut_par.data(), mut_mut.data()};
+    wepp_mat_t* mat = nullptr;
+    if (wepp_mat_create(&desc, device, &mat) != WEPP_OK) {
+        fprintf(stderr, "ERROR: %s\n", wepp_last_error());
+        return 1;
+    }
+
+    // samples already in the tree are skipped with the reference's warning (:323-326)
+    std::vector<size_t> todo;
+    for (size_t s = 0; s < missing_samples.size(); s++) {
+        if (T->get_node(missing_samples[s].name) != nullptr)
+            fprintf(stderr, "WARNING: Sample %s already in the tree! Ignoring.\n\n", missing_samples[s].name.c_str());
+        else todo.push_back(s);
+    }
+    std::vector<uint32_t> read_off(1, 0), read_word;
+    for (size_t s : todo) {
+        auto& muts = missing_samples[s].mutations;
+        std::sort(muts.begin(), muts.end());                      // :200
+        for (auto& m : muts)
+            read_word.push_back(wepp_pack_read_word((uint32_t)m.position, (uint32_t)m.ref_nuc, (uint32_t)m.mut_nuc,
+                                                    m.is_missing ? 1u : 0u));
+        read_off.push_back((uint32_t)read_word.size());
+    }
+    const uint32_t R = (uint32_t)todo.size();
+    std::vector<uint32_t> best_j(R), num_best(R), flags(R);
+    std::vector<int32_t> best_sd(R), node_sd;
+    if (print_parsimony_scores) node_sd.resize((size_t)R * total_nodes);
+    if (wepp_place_batch(mat, read_off.data(), read_word.data(), R, best_j.data(), best_sd.data(), num_best.data(),
+                         flags.data(), print_parsimony_scores ? node_sd.data() : nullptr) != WEPP_OK) {
+        fprintf(stderr, "ERROR: %s\n", wepp_last_error());
+        wepp_mat_destroy(mat);
+        return 1;
+    }
+    wepp_mat_destroy(mat);
+
+    FileCloser stats, scores;
+    if (!outdir.empty()) {
+        stats.f = fopen((outdir + "/placement_stats.tsv").c_str(), "w");                      // :303-304
+        if (!stats.f) {
+            fprintf(stderr, "ERROR: cannot write to %s\n", outdir.c_str());
+            return 1;
+        }
+    }
+    if (results) results->clear();
+    for (uint32_t q = 0; q < R; q++) {
+        const std::string& sample = missing_samples[todo[q]].name;
+        if (print_parsimony_scores && !outdir.empty() && q == 0) {
+            std::string fn = outdir + "/parsimony-scores.tsv";                                 // :329-336
+            fprintf(stderr, "\nNow computing branch parsimony scores for adding the missing samples at each of the %zu nodes in the existing tree without modifying the tree.\n", total_nodes);
+            fprintf(stderr, "The branch parsimony scores will be written to file %s\n\n", fn.c_str());
+            scores.f = fopen(fn.c_str(), "w");
+            if (scores.f)
+                fprintf(scores.f, "#Sample\tTree node\tParsimony score\tOptimal (y/n)\tParsimony-increasing mutations (for optimal nodes)\n");
+        }
+        const int best_set_difference = best_sd[q];
+        const size_t nb = num_best[q];
+        if (!print_parsimony_scores) {
+            fprintf(stderr, "Current tree size (#nodes): %zu\tSample name: %s\tParsimony score: %d\tNumber of parsimony-optimal placements: %zu\n",
+                    total_nodes, sample.c_str(), best_set_difference, nb);                    // :448-449
+            if (stats.f) fprintf(stats.f, "%s\t%d\t%zu\t", sample.c_str(), best_set_difference, nb);   // :450
+            if (nb > 1) {                                                                      // :453-462
+                low_confidence_samples.emplace_back(sample);
+                if (nb > max_uncertainty)
+                    fprintf(stderr, "WARNING: Number of parsimony-optimal placements exceeds maximum allowed value (%u). Ignoring sample %s.\n", max_uncertainty, sample.c_str());
+                else if (best_set_difference <= (int)max_parsimony)
+                    fprintf(stderr, "WARNING: Multiple parsimony-optimal placements found. Placement done without high confidence.\n");
+            }
+            if (best_set_difference > (int)max_parsimony)                                      // :464-466
+                fprintf(stderr, "WARNING: Parsimony score of the most parsimonious placement exceeds the maximum allowed value (%u). Ignoring sample %s.\n", max_parsimony, sample.c_str());
+        } else {
+            fprintf(stderr, "Missing sample: %s\t Best parsimony score: %d\tNumber of parsimony-optimal placements: %zu\n",
+                    sample.c_str(), best_set_difference, nb);                                  // :468-469
+            if (scores.f) {
+                const int32_t* nsd = node_sd.data() + (size_t)q * total_nodes;
+                for (size_t k = 0; k < total_nodes; k++) {                                     // :555-574
+                    const bool optimal = nsd[k] == best_set_difference;
+                    fprintf(scores.f, "%s\t%s\t%d\t\t%c\t", sample.c_str(), bfs[k]->identifier.c_str(), nsd[k], optimal ? 'y' : 'n');
+                    if (!optimal) fprintf(scores.f, "N/A");
+                    else if (nsd[k] == 0) fprintf(scores.f, "*");
+                    // the mutation list of a non-zero optimal node needs the pass-2 vectors (not produced yet)
+                    fprintf(scores.f, "\n");
+                }
+            }
+        }
+        if (stats.f) fputc('\n', stats.f);   // column 4 (imputed mutations) needs the pass-2 vectors; :785
+        if (results)
+            results->push_back({best_set_difference, nb, (size_t)best_j[q], bfs[best_j[q]],
+                                (flags[q] & WEPP_FLAG_HAS_UNIQUE) != 0});
+    }
+    return 0;
+}

@@ -1,0 +1,34 @@
+// usher_place.hpp -- the placement half of `usher_common` on the GPU.
+//
+// Mirrors /root/reference/src/usher_common.hpp:18-22 for the --no-add path
+// (the tree is not modified, usher_common.cpp:649): same argument names and
+// meaning for the ones that matter here, same files written into `outdir`
+// (placement_stats.tsv, and parsimony-scores.tsv with print_parsimony_scores),
+// same stderr lines, same return convention (0 ok, 1 error after printing).
+// Everything between is one wepp_place_batch call (include/wepp_place.h).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mat.hpp"
+
+struct usher_place_result {       // what the reference keeps in locals per sample
+    int best_set_difference;      // usher_common.cpp:371
+    size_t num_best;              // :380
+    size_t best_j;                // :373  (index into breadth_first_expansion())
+    MAT::Node* best_node;         // :381
+    bool best_node_has_unique;    // :374
+};
+
+// Places every sample of `missing_samples` (in order) on `T`.
+//   outdir                   directory for the TSV files ("" = write none)
+//   max_uncertainty / max_parsimony   thresholds of the warnings at :453-466
+//   print_parsimony_scores   the -p mode (:328-336, :403-409, :555-574)
+//   low_confidence_samples   receives the samples with >1 optimal placement (:453-456)
+//   results                  optional, one entry per sample
+//   device                   HIP device index
+int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t max_parsimony,
+                        bool print_parsimony_scores, std::vector<Missing_Sample>& missing_samples,
+                        std::vector<std::string>& low_confidence_samples, MAT::Tree* T,
+                        std::vector<usher_place_result>* results = nullptr, int device = 0);

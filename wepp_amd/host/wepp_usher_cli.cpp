@@ -1,0 +1,64 @@
+// wepp-usher: `usher -i tree.pb[.gz] -v samples.vcf[.gz] -n -d outdir [-p]` on the GPU
+// (the placement-only invocation of /root/reference/src/usher.cpp:141-183).
+// A thin driver around usher_place_samples; also `--dump` prints what the loaders
+// parsed (used by the CPU tests, needs no GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "usher_place.hpp"
+
+static void usage() {
+    fprintf(stderr, "usage: wepp-usher -i <mat.pb[.gz]> -v <samples.vcf[.gz]> [-d <outdir>] [-p] [-e max_uncertainty] "
+                    "[-E max_parsimony] [--device N] [--dump]\n");
+}
+
+int main(int argc, char** argv) {
+    std::string pb, vcf, outdir = ".";
+    bool print_scores = false, dump = false;
+    uint32_t max_uncertainty = 1000000, max_parsimony = 1000000;   // usher.cpp:77-80 defaults
+    int device = 0;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
+        if (a == "-i" || a == "--load-mutation-annotated-tree") pb = next();
+        else if (a == "-v" || a == "--vcf") vcf = next();
+        else if (a == "-d" || a == "--outdir") outdir = next();
+        else if (a == "-p" || a == "--write-parsimony-scores-per-node") print_scores = true;
+        else if (a == "-e" || a == "--max-uncertainty-per-sample") max_uncertainty = (uint32_t)atoi(next());
+        else if (a == "-E" || a == "--max-parsimony-per-sample") max_parsimony = (uint32_t)atoi(next());
+        else if (a == "-n" || a == "--no-add") {}
+        else if (a == "--device") device = atoi(next());
+        else if (a == "--dump") dump = true;
+        else { usage(); return 1; }
+    }
+    if (pb.empty() || vcf.empty()) { usage(); return 1; }
+    try {
+        MAT::Tree T = MAT::load_mutation_annotated_tree(pb);
+        std::vector<Missing_Sample> missing_samples;
+        MAT::read_vcf(&T, vcf, missing_samples);
+        if (dump) {
+            auto bfs = T.breadth_first_expansion();
+            printf("nodes %zu\n", bfs.size());
+            for (auto n : bfs) {
+                printf("node %s parent %s muts", n->identifier.c_str(), n->parent ? n->parent->identifier.c_str() : "-");
+                for (auto& m : n->mutations) printf(" %d:%d:%d:%d", m.position, m.ref_nuc, m.par_nuc, m.mut_nuc);
+                printf("\n");
+            }
+            for (auto& s : missing_samples) {
+                printf("sample %s", s.name.c_str());
+                for (auto& m : s.mutations) printf(" %d:%d:%d:%d", m.position, m.ref_nuc, m.mut_nuc, (int)m.is_missing);
+                printf("\n");
+            }
+            return 0;
+        }
+        std::vector<std::string> low_conf;
+        return usher_place_samples(outdir, max_uncertainty, max_parsimony, print_scores, missing_samples, low_conf, &T,
+                                   nullptr, device);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
