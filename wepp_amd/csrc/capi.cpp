@@ -243,7 +243,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t* info = mat->h_info;
 
     // ---- plan the launches ---------------------------------------------------------
-    struct Plan { uint32_t t, count, off, ntiles, nchunks, bpc, lds_bytes; bool s_in_lds; size_t part_off; };
+    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; };
     Plan plans[MAX_STREAMS];
     uint32_t np = 0;
     size_t part_total = 0;
@@ -256,11 +256,22 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         p.t = t;
         p.count = count;
         p.off = info[TI_OFF + t];
-        p.ntiles = (count + T - 1) / T;
-        // largest tile (read words) decides how much LDS a workgroup asks for
-        const uint64_t cap = ((uint64_t)std::min<uint32_t>(T, count) * info[TI_MAXK + t] + 63) & ~63ull;
-        p.s_in_lds = bm_bytes + cap * 4 <= 64 * 1024;
-        p.lds_bytes = p.s_in_lds ? (uint32_t)(bm_bytes + cap * 4) : bm_bytes;
+        // reads per tile: at most MAX_TILE_ENTRIES read words per tile (long reads share a
+        // sweep between fewer reads), a power of two, never more than the knob
+        const uint32_t maxk = std::max<uint32_t>(1, info[TI_MAXK + t]);
+        uint32_t Tp = T;
+        while (Tp > 1 && (uint64_t)Tp * maxk > MAX_TILE_ENTRIES) Tp >>= 1;
+        p.T = Tp;
+        p.ntiles = (count + Tp - 1) / Tp;
+        // a read longer than MAX_TILE_ENTRIES words is swept alone with its words left in global memory
+        p.s_in_lds = maxk <= MAX_TILE_ENTRIES;
+        p.dense = p.s_in_lds && maxk >= DENSE_MIN_READ_WORDS;
+        const uint64_t need = std::min<uint64_t>((uint64_t)std::min(Tp, count) * maxk, MAX_TILE_ENTRIES);
+        uint32_t cap = 64;
+        if (p.dense) while (cap < need) cap <<= 1;          // the bitonic network wants a power of two
+        else cap = (uint32_t)((need + 63) & ~63ull);
+        p.ent_cap = p.s_in_lds ? cap : 0;
+        p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, p.dense) : bm_bytes;
         // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
         const DevStream& st = mat->streams[t];
         const uint32_t target_waves = 8192;
@@ -300,8 +311,8 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         int32_t* ps = (int32_t*)(part_base + p.part_off);
         uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
         uint32_t* pc = pr + (size_t)p.nchunks * p.count;
-        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, T, p.ntiles,
-                             p.nchunks, p.bpc, p.s_in_lds, p.lds_bytes, ps, pr, pc, q));
+        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, p.T, p.ntiles,
+                             p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.lds_bytes, ps, pr, pc, q));
         passes += p.ntiles;                                   // every tile sweeps its stream once
         bytes += (uint64_t)p.ntiles * mat->stream_bytes[p.t];
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,

@@ -38,6 +38,7 @@ namespace wepp {
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int DENSE_MIN_HITS = 3;   // hit events per block from which the lane = event lookup pays
 
 // ---- word field helpers ------------------------------------------------------
 // tree / event word: pos:20 | ref idx:2 | par:4 | mut:4 | exit | leaf (flatmat.hpp)
@@ -190,8 +191,11 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
 // LDS: [bm_words] position bitmap of the tile, then (S_IN_LDS) the tile's read
 // words.  part_* receive one (score, rank, count) per (chunk, read).
 // -----------------------------------------------------------------------------
-template <bool S_IN_LDS>
-__global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, uint32_t max_pos,
+// S_IN_LDS: the tile's read words are staged in LDS (else read from global memory: reads
+// longer than MAX_TILE_ENTRIES words).  DENSE: additionally keep a tile-sorted position
+// index in LDS and resolve blocks with many hit events with lane = event (long reads).
+template <bool S_IN_LDS, bool DENSE>
+__global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
                                               const uint32_t* __restrict__ read_off,
                                               const uint32_t* __restrict__ read_word,
                                               const uint32_t* __restrict__ list, uint32_t n_list,
@@ -199,9 +203,14 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
                                               int32_t* __restrict__ part_score,
                                               uint32_t* __restrict__ part_rank,
                                               uint32_t* __restrict__ part_cnt) {
+    // LDS: [bm_words] bitmap | [ent_cap] read words (tile order) | DENSE only: [ent_cap, pow2]
+    // tile-sorted keys pos:20|idx:12 | [ent_cap] owner lane of each entry (bytes) | [3*64] accumulators
     extern __shared__ uint32_t lds[];
     uint32_t* bitmap = lds;
     uint32_t* S_lds = lds + bm_words;
+    uint32_t* skey = S_lds + ent_cap;
+    uint8_t* owner = reinterpret_cast<uint8_t*>(skey + ent_cap);
+    int* acc = reinterpret_cast<int*>(owner + ent_cap);        // net[64], H[64], cnt[64]
 
     const uint32_t lane = threadIdx.x;
     const uint32_t tile = blockIdx.x % ntiles;
@@ -228,13 +237,40 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
     // last mutated site (and the padding word) alias into the map; a false positive
     // only costs a failed lookup in the reads.
     const uint32_t bm_mask = bm_words - 1;
+    const uint32_t n_ent = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);   // read words of the tile
+    uint32_t n2 = 1;                                   // bitonic network size (power of two >= n_ent)
+    while (n2 < n_ent) n2 <<= 1;
+    if (DENSE) {
+        for (uint32_t i = lane; i < n2; i += 64) skey[i] = 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < 3 * 64; i += 64) acc[i] = 0;
+        __syncthreads();
+    }
     for (uint32_t j = 0; j < my_k; j++) {
         const uint32_t w = read_word[so + j];
-        if (S_IN_LDS) S_lds[lds_off + j] = w;
         const uint32_t p = w_pos(w);
+        if (S_IN_LDS) S_lds[lds_off + j] = w;
+        if (DENSE) {
+            skey[lds_off + j] = (p << 12) | (lds_off + j);
+            owner[lds_off + j] = (uint8_t)lane;
+        }
         if (p <= max_pos) atomicOr(&bitmap[(p >> 5) & bm_mask], 1u << (p & 31));
     }
     __syncthreads();
+    // tile-wide position index: bitonic sort of the keys (once per tile sweep)
+    if (DENSE) {
+        for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
+            for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (uint32_t i = lane; i < n2; i += 64) {
+                    const uint32_t x = i ^ j2;
+                    if (x > i) {
+                        const uint32_t a = skey[i], b = skey[x];
+                        if ((a > b) == ((i & k2) == 0)) { skey[i] = b; skey[x] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
 
     // Slice of this lane's read inside S (LDS copy or the global array).
     const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : read_word;
@@ -383,17 +419,61 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
         // node-by-node path: start its loads before the lookups.  On the whole-tree
         // stream the bound prunes ~95 % of the hits and the loads are issued on demand.
         if (m.eager && (hm0 | hm1)) fetch_nodes();
-        unsigned long long hm = hm0;
-        while (hm) {
-            const int l = __builtin_ctzll(hm);
-            hm &= hm - 1;
-            light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l));
-        }
-        hm = hm1;
-        while (hm) {
-            const int l = __builtin_ctzll(hm);
-            hm &= hm - 1;
-            light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l));
+        unsigned long long hm;
+        if (DENSE && __popcll(hm0) + __popcll(hm1) >= DENSE_MIN_HITS) {
+            // many hit events (long reads): lane = event.  Every lane looks its event up in
+            // the tile-sorted key array and adds its contribution to the owning read's
+            // accumulators in LDS; all events of the block are resolved together.
+            auto dense_half = [&](uint32_t w, bool act) {
+                const uint32_t p = w_pos(w);
+                const uint32_t want = p << 12;
+                uint32_t lo = 0;
+                for (uint32_t step = n2 >> 1; step > 0; step >>= 1)      // lower_bound, n2 is a power of two
+                    if (skey[lo + step - 1] < want) lo += step;
+                uint32_t i = lo;
+                while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 12) == p)) {
+                    const uint32_t kv = skey[min(i, n2 - 1)];
+                    if (act && i < n2 && (kv >> 12) == p) {
+                        const uint32_t idx = kv & 4095u;
+                        const int d = enter_delta(w, S_lds[idx]);
+                        const int ad = d < 0 ? -d : d;
+                        int dn, dh;
+                        if (w & W_EXIT_DEV) { dn = -d; dh = ad; }
+                        else if (w & W_LEAF_DEV) { dn = 0; dh = 1; }
+                        else { dn = d; dh = ad + 1; }
+                        const uint32_t o = owner[idx];
+                        if (dn) atomicAdd(&acc[o], dn);
+                        if (dh) atomicAdd(&acc[64 + o], dh);
+                        atomicAdd(&acc[128 + o], 1);
+                    }
+                    i++;
+                }
+            };
+            dense_half(w0, (hm0 >> lane) & 1ull);
+            dense_half(w1, (hm1 >> lane) & 1ull);
+            __syncthreads();
+            if (acc[128 + lane]) {
+                touched = true;
+                net = acc[lane];
+                H = acc[64 + lane];
+                acc[lane] = 0;
+                acc[64 + lane] = 0;
+                acc[128 + lane] = 0;
+            }
+            __syncthreads();
+        } else {
+            hm = hm0;
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l));
+            }
+            hm = hm1;
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l));
+            }
         }
         for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
             const uint32_t w = (e + lane < e1) ? m.ev_word[e + lane] : W_PAD_DEV;
@@ -629,16 +709,17 @@ hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32
 
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
                         const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
-                        uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds,
-                        uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
-                        hipStream_t stream) {
+                        uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
+                        uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank,
+                        uint32_t* part_cnt, hipStream_t stream) {
     const dim3 grid(ntiles * nchunks), block(64);
-    if (s_in_lds)
-        hipLaunchKernelGGL(k_sweep<true>, grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, d_read_off,
-                           d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
-    else
-        hipLaunchKernelGGL(k_sweep<false>, grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, d_read_off,
-                           d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+#define WEPP_SWEEP(A, B, CAP)                                                                                         \
+    hipLaunchKernelGGL((k_sweep<A, B>), grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, CAP, d_read_off,    \
+                       d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt)
+    if (s_in_lds && dense) WEPP_SWEEP(true, true, ent_cap);
+    else if (s_in_lds) WEPP_SWEEP(true, false, ent_cap);
+    else WEPP_SWEEP(false, false, 0u);
+#undef WEPP_SWEEP
     return hipGetLastError();
 }
 
@@ -669,9 +750,11 @@ hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t*
 }
 
 hipError_t sweep_set_max_lds(uint32_t bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute((const void*)k_sweep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_sweep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace wepp
