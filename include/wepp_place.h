@@ -130,6 +130,19 @@ int wepp_place_batch(wepp_mat_t *mat, const uint32_t *read_off, const uint32_t *
                      uint32_t n_reads, uint32_t *best_bfs_j, int32_t *score, uint32_t *num_best,
                      uint32_t *flags, int32_t *per_node_scores);
 
+/* Imputed mutations of the chosen placement: what pass 2 leaves in
+ * node_imputed_mutations[best_j] (src/usher_mapper.cpp:323-378) and
+ * usher_common prints as column 4 of placement_stats.tsv
+ * (src/usher_common.cpp:764-781).  Every ambiguous (more than one bit set),
+ * non-missing entry of a read yields exactly one imputed mutation, in entry
+ * order; imp_off[r] .. imp_off[r+1] index imp_pos / imp_nuc (nucleotide masks,
+ * one bit set).  best_bfs_j is the placement returned by wepp_place_batch.
+ * capacity = size of imp_pos / imp_nuc; WEPP_ELIMIT if too small (the needed
+ * size is the number of ambiguous non-missing read words). */
+int wepp_imputed_mutations(wepp_mat_t *mat, const uint32_t *read_off, const uint32_t *read_word,
+                           uint32_t n_reads, const uint32_t *best_bfs_j, uint32_t *imp_off,
+                           int32_t *imp_pos, uint8_t *imp_nuc, uint64_t capacity);
+
 /* Same computation with every buffer already resident on the handle's device
  * (device pointers); work is enqueued on `hip_stream` (a hipStream_t, NULL =
  * the default stream) and NOT synchronised on return.  n_read_words =

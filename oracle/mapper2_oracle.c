@@ -194,6 +194,8 @@ typedef struct {
     uint8_t *node_has_unique;
     struct jvec *best_j_vec;    /* std::vector<size_t>* */
     int *has_unique;
+    omut *imputed_mutations;    /* compute_vecs: std::vector<MAT::Mutation>* (capacity >= |S|), or NULL */
+    int *n_imputed;
 } o_mapper2_input;
 
 typedef struct { omut *v; int n, cap; int *pos; } anc_vec;
@@ -328,10 +330,19 @@ static void o_mapper2_body(o_mapper2_input *input, int compute_parsimony_scores,
                 break;
             }
         }
+        const int compute_vecs = input->imputed_mutations != NULL;
         if (found) {
-            /* imputed_mutations only (compute_vecs) :323-336 */
+            if (compute_vecs && ((m1.mut_nuc & (m1.mut_nuc - 1)) != 0)) {           /* :327-335 */
+                omut m;
+                m.position = m1.position; m.ref_nuc = m1.ref_nuc; m.par_nuc = anc_nuc; m.mut_nuc = anc_nuc; m.is_missing = 0;
+                input->imputed_mutations[(*input->n_imputed)++] = m;
+            }
         } else if (!found_pos && has_ref) {
-            /* imputed_mutations only :342-352 */
+            if (compute_vecs && ((m1.mut_nuc & (m1.mut_nuc - 1)) != 0)) {           /* :343-351 */
+                omut m;
+                m.position = m1.position; m.ref_nuc = m1.ref_nuc; m.par_nuc = anc_nuc; m.mut_nuc = m1.ref_nuc; m.is_missing = 0;
+                input->imputed_mutations[(*input->n_imputed)++] = m;
+            }
         } else {
             omut m;                                            /* :357-388 */
             m.position = m1.position;
@@ -345,6 +356,8 @@ static void o_mapper2_body(o_mapper2_input *input, int compute_parsimony_scores,
                     if (((1 << j) & m1.mut_nuc) != 0) { m.mut_nuc = (int8_t)(1 << j); break; }
                 }
             }
+            if (compute_vecs && ((m1.mut_nuc & (m1.mut_nuc - 1)) != 0))            /* :376-378 */
+                input->imputed_mutations[(*input->n_imputed)++] = m;
             if (m.mut_nuc != m.par_nuc) {                      /* :379 */
                 set_difference += 1;
                 if (!compute_parsimony_scores && (set_difference > best_set_difference)) return;
@@ -457,6 +470,8 @@ static void fill_input(o_mapper2_input *inp, const otree *T, o_best_state *st, c
     inp->node_has_unique = st->node_has_unique;
     inp->distance = 0;                                 /* usher_graph.hpp:98-101 */
     inp->best_distance = &inp->distance;
+    inp->imputed_mutations = NULL;
+    inp->n_imputed = NULL;
 }
 
 /* One sample against the whole tree.  print_parsimony_scores != 0 reproduces
@@ -707,4 +722,32 @@ int oracle_place_batch_nodepar(const otree *T, uint32_t n_reads, const uint32_t 
     for (int t = 0; t < nthreads; t++) free(jobs[t].st);
     free(th); free(jobs); free(S_all);
     return 0;
+}
+
+/* node_imputed_mutations[best_j] as pass 2 fills it (usher_common.cpp:423-446 call
+ * mapper2_body with compute_vecs = true): the imputed mutations of sample S at
+ * the node with BFS index j.  out_pos / out_nuc need capacity nS; returns the count. */
+int oracle_imputed_at_node(const otree *T, int nS, const int32_t *s_pos, const uint8_t *s_ref,
+                           const uint8_t *s_mut, const uint8_t *s_missing, uint32_t j,
+                           int32_t *out_pos, uint8_t *out_nuc) {
+    omut *S = (omut *)calloc((size_t)(nS ? nS : 1), sizeof(omut));
+    for (int i = 0; i < nS; i++) {
+        S[i].position = s_pos[i]; S[i].ref_nuc = (int8_t)s_ref[i]; S[i].par_nuc = (int8_t)s_ref[i];
+        S[i].mut_nuc = (int8_t)s_mut[i]; S[i].is_missing = s_missing[i];
+    }
+    o_best_state st;
+    uint8_t *nhu = (uint8_t *)calloc((size_t)T->n, 1);
+    np_state_init(&st, T, nS, nhu);
+    st.best_set_difference = 0x3fffffff;       /* never return early: the node is an optimal one in pass 2 */
+    omut *imp = (omut *)calloc((size_t)(nS ? nS : 1), sizeof(omut));
+    int n_imp = 0;
+    anc_vec scratch = {0, 0, 0, 0};
+    o_mapper2_input inp;
+    fill_input(&inp, T, &st, S, nS, j, NULL);
+    inp.imputed_mutations = imp;
+    inp.n_imputed = &n_imp;
+    o_mapper2_body(&inp, 0, &scratch);
+    for (int i = 0; i < n_imp; i++) { out_pos[i] = imp[i].position; out_nuc[i] = (uint8_t)imp[i].mut_nuc; }
+    free(scratch.v); free(scratch.pos); free(imp); free(nhu); free(st.best_j_vec.v); free(S);
+    return n_imp;
 }

@@ -44,6 +44,8 @@ def lib():
         L.oracle_place_sample.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
             ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(OracleResult), ctypes.c_void_p]
         L.oracle_place_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
+        L.oracle_imputed_at_node.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
+            ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_place_batch_nodepar.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         for f in ("oracle_tree_bfs_ids", "oracle_tree_dfs_ids", "oracle_tree_num_leaves"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -110,6 +112,17 @@ class OracleTree:
         if want_best_vec:
             out["best_j_vec"] = np.sort(bv[: res.num_best])
         return out
+
+    def imputed_at_node(self, pos, ref, mut, missing, bfs_j):
+        """node_imputed_mutations[bfs_j] of pass 2: list of (position, nucleotide mask)."""
+        pos = np.ascontiguousarray(pos, np.int32); ref = np.ascontiguousarray(ref, np.uint8)
+        mut = np.ascontiguousarray(mut, np.uint8); missing = np.ascontiguousarray(missing, np.uint8)
+        n = len(pos)
+        op = np.zeros(max(n, 1), np.int32); on = np.zeros(max(n, 1), np.uint8)
+        z32 = np.zeros(1, np.int32); z8 = np.zeros(1, np.uint8)
+        c = lib().oracle_imputed_at_node(self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8),
+                                         _p(missing if n else z8), int(bfs_j), _p(op), _p(on))
+        return list(zip(op[:c].tolist(), on[:c].tolist()))
 
     def place_batch(self, reads, nthreads=1, node_parallel=False):
         """reads: wepp_amd.Reads.  Returns a structured array.  node_parallel=True

@@ -78,6 +78,27 @@ def test_per_node_scores_mode_vs_oracle(oracle):
     mat.close()
 
 
+def test_imputed_mutations_of_the_chosen_node(oracle):
+    """Column 4 of placement_stats.tsv: node_imputed_mutations[best_j] (usher_common.cpp:764-781)."""
+    rng = np.random.default_rng(654)
+    total = 0
+    for it in range(40):
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(1, 200)), genome=int(rng.choice([60, 300])))
+        samples = [ft.random_sample(rng, ref, genome=max(ref)) for _ in range(int(rng.integers(1, 20)))]
+        reads = ft.reads_from_samples(samples)
+        mat = w.Mat(tree)
+        res = mat.place_batch(reads)
+        got = mat.imputed_mutations(reads, res.best_bfs_j)
+        ot = oracle.OracleTree(tree)
+        for q, S in enumerate(samples):
+            cols = list(zip(*S)) if S else ([], [], [], [])
+            want = ot.imputed_at_node(*cols, res.best_bfs_j[q])
+            assert got[q] == want, (it, q, S)
+            total += len(want)
+        mat.close()
+    assert total > 100
+
+
 def test_config1_rsv_like(oracle):
     """BASELINE.json configs[0] substitute: RSV-A-like MAT, 150 bp reads."""
     g = w.generate_tree(1, 50000, genome_len=15225, p_ambiguous=0.002, p_masked_node=0.0005, root_mutations=1)

@@ -143,11 +143,17 @@ def test_wepp_usher_end_to_end(tmp_path, oracle):
     bfs = ot.bfs_ids()
     rows = [l.split("\t") for l in open(out1 / "placement_stats.tsv").read().splitlines()]
     assert len(rows) == 40
+    n_imputed = 0
     for q, S in enumerate(samples):
         S = [_as_vcf_reader_sees(e) for e in S]
         o = ot.place_sample(*(list(zip(*S)) if S else ([], [], [], [])))
         assert rows[q][0] == snames[q] and int(rows[q][1]) == o["score"] and int(rows[q][2]) == o["num_best"]
+        imp = ot.imputed_at_node(*(list(zip(*S)) if S else ([], [], [], [])), o["best_j"])
+        n_imputed += len(imp)
+        want4 = ";".join(f"{p}:{pbf.NUC.get(n, 'N') if n != 7 else 'V'}" for p, n in imp)
+        assert (rows[q][3] if len(rows[q]) > 3 else "") == want4, (q, rows[q], want4)
         assert f"Sample name: {snames[q]}\tParsimony score: {o['score']}\tNumber of parsimony-optimal placements: {o['num_best']}" in r.stderr
+    assert n_imputed > 5
     r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-p", "-d", str(out2)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     lines = open(out2 / "parsimony-scores.tsv").read().splitlines()

@@ -275,6 +275,21 @@ class Mat:
             res.per_node_scores = pns
         return res
 
+    def imputed_mutations(self, reads, best_bfs_j):
+        """Per read: list of (position, nucleotide mask) imputed for its ambiguous entries at
+        the chosen node (column 4 of placement_stats.tsv): wepp_imputed_mutations."""
+        n = reads.n_reads
+        a = (reads.read_word >> 24) & 15
+        cap = int((((reads.read_word >> 28) & 1) == 0).__and__((a & (a - 1)) != 0).sum()) if reads.read_word.size else 0
+        off = np.zeros(n + 1, np.uint32)
+        pos = np.zeros(max(cap, 1), np.int32)
+        nuc = np.zeros(max(cap, 1), np.uint8)
+        bj = np.ascontiguousarray(best_bfs_j, dtype=np.uint32)
+        rw = reads.read_word if reads.read_word.size else np.zeros(1, np.uint32)
+        check(lib.wepp_imputed_mutations(self._h, _ptr(reads.read_off), _ptr(rw), n, _ptr(bj), _ptr(off), _ptr(pos),
+                                         _ptr(nuc), cap))
+        return [list(zip(pos[off[r]:off[r + 1]].tolist(), nuc[off[r]:off[r + 1]].tolist())) for r in range(n)]
+
     def place_batch_device(self, d_read_off, d_read_word, n_reads, n_read_words, d_best, d_score, d_num_best,
                            d_flags, stream=0):
         """Device pointers (ints) in/out: wepp_place_batch_device; not synchronised."""

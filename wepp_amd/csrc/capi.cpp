@@ -132,6 +132,12 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
 #define UP(dst, vec) if ((rc = upload(h, vec, &dst)) != WEPP_OK) { release(h); return rc; }
     UP(d.node_woff, f.node_woff) UP(d.words, f.words) UP(d.nstat, f.nstat) UP(d.rank2dfs, f.rank2dfs)
     UP(d.dfs2bfs, f.dfs2bfs)
+    {
+        std::vector<uint32_t> bfs2dfs(f.N);
+        for (uint32_t k = 0; k < f.N; k++) bfs2dfs[f.dfs2bfs[k]] = k;
+        UP(d.bfs2dfs, bfs2dfs)
+    }
+    UP(d.parent_dfs, f.parent_dfs)
     for (size_t i = 0; i < f.streams.size(); i++) {
         const Stream& st = f.streams[i];
         DevStream ds{};
@@ -409,5 +415,51 @@ done:
     if (d_word) (void)hipFree(d_word);
     if (d_out) (void)hipFree(d_out);
     if (d_pns) (void)hipFree(d_pns);
+    return rc;
+}
+
+extern "C" int wepp_imputed_mutations(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word,
+                                      uint32_t n_reads, const uint32_t* best_bfs_j, uint32_t* imp_off,
+                                      int32_t* imp_pos, uint8_t* imp_nuc, uint64_t capacity) {
+    if (!mat || !read_off || !best_bfs_j || !imp_off) return set_error(WEPP_EINVAL, "null argument");
+    std::vector<uint32_t> pairs;
+    imp_off[0] = 0;
+    for (uint32_t r = 0; r < n_reads; r++) {
+        if (best_bfs_j[r] >= mat->dev.N) return set_error(WEPP_EINVAL, "best_bfs_j out of range");
+        for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++) {
+            const uint32_t w = read_word[k], a = (w >> 24) & 15u;
+            if (!((w >> 28) & 1u) && (a & (a - 1))) { pairs.push_back(r); pairs.push_back(k); }
+        }
+        imp_off[r + 1] = (uint32_t)(pairs.size() / 2);
+    }
+    const uint32_t np = (uint32_t)(pairs.size() / 2);
+    if (np > capacity) return set_error(WEPP_ELIMIT, "imputed-mutation buffers too small: need " + std::to_string(np));
+    if (np == 0) return WEPP_OK;
+    if (!imp_pos || !imp_nuc || !read_word) return set_error(WEPP_EINVAL, "null argument");
+    for (uint32_t i = 0; i < np; i++) imp_pos[i] = (int32_t)(read_word[pairs[2 * i + 1]] & 0xFFFFFu);
+    HIP_TRY(hipSetDevice(mat->device));
+    const uint64_t nw = read_off[n_reads];
+    uint32_t *d_off = nullptr, *d_word = nullptr, *d_best = nullptr, *d_pairs = nullptr;
+    uint8_t* d_nuc = nullptr;
+    int rc = WEPP_OK;
+    hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_best, (size_t)n_reads * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pairs, (size_t)np * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_nuc, np);
+    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
+    e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_best, best_bfs_j, (size_t)n_reads * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_pairs, pairs.data(), (size_t)np * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_imputed(mat->dev, d_off, d_word, d_best, d_pairs, np, d_nuc, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(imp_nuc, d_nuc, np, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hip_fail(e, "imputed-mutation kernel");
+done:
+    if (d_off) (void)hipFree(d_off);
+    if (d_word) (void)hipFree(d_word);
+    if (d_best) (void)hipFree(d_best);
+    if (d_pairs) (void)hipFree(d_pairs);
+    if (d_nuc) (void)hipFree(d_nuc);
     return rc;
 }

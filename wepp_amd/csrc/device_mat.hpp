@@ -41,6 +41,8 @@ struct DevMAT {
     const uint32_t* nstat;
     const uint32_t* rank2dfs;
     const uint32_t* dfs2bfs;
+    const uint32_t* bfs2dfs;      // inverse of dfs2bfs
+    const uint32_t* parent_dfs;   // DFS index of the parent (root: 0)
 };
 
 constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (grid-stride over the reads)
@@ -72,6 +74,10 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
 hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t* d_read_off,
                          const uint32_t* d_read_word, uint32_t n_reads, int32_t* d_out, hipStream_t stream);
+// one thread per (read, ambiguous entry) pair listed in `pairs` (read index, word index)
+hipError_t launch_imputed(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                          const uint32_t* d_best_bfs_j, const uint32_t* d_pairs, uint32_t n_pairs,
+                          uint8_t* d_nuc, hipStream_t stream);
 hipError_t sweep_set_max_lds(uint32_t bytes);
 
 // layout of tier_info (uint32): [0..8) counts, [8..16) max entries of one read, [16..25) offsets into the list

@@ -690,6 +690,53 @@ __global__ __launch_bounds__(64) void k_scores(DevStream m, const uint32_t* __re
 }
 
 // -----------------------------------------------------------------------------
+// k_imputed: allele imputed for an ambiguous read entry at the chosen node
+// (usher_mapper.cpp:293-378 with compute_vecs).  The node's genotype as the
+// scorer sees it: its own mutation at the position if it is "common" with the
+// read (:205-236; none of its mutations when the node is masked, :198-201; all
+// of them for the root, :266-271), else the most recent mutation on the path
+// above it (:276-287).  One thread per (read, entry) pair.
+// -----------------------------------------------------------------------------
+__global__ void k_imputed(DevMAT m, const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                          const uint32_t* __restrict__ best_bfs_j, const uint32_t* __restrict__ pairs,
+                          uint32_t n_pairs, uint8_t* __restrict__ nuc_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const uint32_t r = pairs[2 * i], wi = pairs[2 * i + 1];
+    const uint32_t s = read_word[wi];
+    const uint32_t pos = w_pos(s), a = rw_mut(s), sref = rw_ref(s);
+    uint32_t d = m.bfs2dfs[best_bfs_j[r]];
+    uint32_t anc = 0;          // allele of the genotype at pos, 0 = no mutation found
+    bool first = true;
+    for (;;) {
+        const uint32_t st = m.nstat[d];
+        const bool root = st & NS_ROOT_DEV;
+        const bool own_ok = !first || root || !(st & NS_MASKED_DEV);
+        if (own_ok) {
+            for (uint32_t w = m.node_woff[d]; w < m.node_woff[d + 1]; w++) {
+                const uint32_t tw = m.words[w];
+                if (w_pos(tw) != pos) continue;
+                // the placement node itself contributes only a mutation shared with the read
+                if (first && !root && (a & tw_mut(tw)) == 0) break;
+                anc = tw_mut(tw);
+                break;
+            }
+        }
+        if (anc || root) break;
+        d = m.parent_dfs[d];
+        first = false;
+    }
+    const bool found_pos = anc != 0;
+    const bool found = found_pos && (a & anc) != 0;
+    const bool has_ref = (a & sref) != 0;
+    uint32_t out;
+    if (found) out = anc;                               // :323-335
+    else if (!found_pos && has_ref) out = sref;         // :342-351
+    else out = has_ref ? sref : (a & (0u - a));         // :357-377 (lowest set bit)
+    nuc_out[i] = (uint8_t)out;
+}
+
+// -----------------------------------------------------------------------------
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
@@ -746,6 +793,15 @@ hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t*
     nchunks = (full.NB + bpc - 1) / bpc;
     hipLaunchKernelGGL(k_scores, dim3(n_reads * nchunks), dim3(64), 0, stream, full, m.dfs2bfs, d_read_off,
                        d_read_word, n_reads, bpc, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_imputed(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                          const uint32_t* d_best_bfs_j, const uint32_t* d_pairs, uint32_t n_pairs,
+                          uint8_t* d_nuc, hipStream_t stream) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_imputed, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, m, d_read_off, d_read_word,
+                       d_best_bfs_j, d_pairs, n_pairs, d_nuc);
     return hipGetLastError();
 }
 

@@ -76,6 +76,22 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
         wepp_mat_destroy(mat);
         return 1;
     }
+    // imputed mutations of the chosen node (column 4 of placement_stats.tsv, :764-781)
+    std::vector<uint32_t> imp_off(R + 1, 0);
+    std::vector<int32_t> imp_pos;
+    std::vector<uint8_t> imp_nuc;
+    if (!print_parsimony_scores) {
+        size_t amb = 0;
+        for (uint32_t w : read_word) amb += (!((w >> 28) & 1u) && (((w >> 24) & 15u) & (((w >> 24) & 15u) - 1))) ? 1 : 0;
+        imp_pos.resize(amb + 1);
+        imp_nuc.resize(amb + 1);
+        if (wepp_imputed_mutations(mat, read_off.data(), read_word.data(), R, best_j.data(), imp_off.data(),
+                                   imp_pos.data(), imp_nuc.data(), amb) != WEPP_OK) {
+            fprintf(stderr, "ERROR: %s\n", wepp_last_error());
+            wepp_mat_destroy(mat);
+            return 1;
+        }
+    }
     wepp_mat_destroy(mat);
 
     FileCloser stats, scores;
@@ -112,6 +128,17 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
             }
             if (best_set_difference > (int)max_parsimony)                                      // :464-466
                 fprintf(stderr, "WARNING: Parsimony score of the most parsimonious placement exceeds the maximum allowed value (%u). Ignoring sample %s.\n", max_parsimony, sample.c_str());
+            // :580 the placement branch (where the imputed mutations are printed) is only
+            // entered within the thresholds
+            if (nb <= max_uncertainty && best_set_difference <= (int)max_parsimony && imp_off[q + 1] > imp_off[q]) {
+                fprintf(stderr, "Imputed mutations:\t");                                      // :764-781
+                for (uint32_t i = imp_off[q]; i < imp_off[q + 1]; i++) {
+                    const char* sep = (i + 1 < imp_off[q + 1]) ? ";" : "";
+                    fprintf(stderr, "%i:%c%s", imp_pos[i], MAT::get_nuc((int8_t)imp_nuc[i]), sep);
+                    if (stats.f) fprintf(stats.f, "%i:%c%s", imp_pos[i], MAT::get_nuc((int8_t)imp_nuc[i]), sep);
+                }
+                fprintf(stderr, "\n");
+            }
         } else {
             fprintf(stderr, "Missing sample: %s\t Best parsimony score: %d\tNumber of parsimony-optimal placements: %zu\n",
                     sample.c_str(), best_set_difference, nb);                                  // :468-469
@@ -127,7 +154,7 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
                 }
             }
         }
-        if (stats.f) fputc('\n', stats.f);   // column 4 (imputed mutations) needs the pass-2 vectors; :785
+        if (stats.f) fputc('\n', stats.f);   // :785
         if (results)
             results->push_back({best_set_difference, nb, (size_t)best_j[q], bfs[best_j[q]],
                                 (flags[q] & WEPP_FLAG_HAS_UNIQUE) != 0});
