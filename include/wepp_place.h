@@ -217,7 +217,7 @@ int wepp_gen_reads_destroy(wepp_gen_reads_t *r);
  * Lets the CPU test-suite check the flattener (orders, parent alleles, per-node
  * constants, event stream) against the oracle.  `name` is one of: node_woff,
  * words, nkey, nstat, rank2dfs, dfs2bfs, bfs2id, dfs2id, parent_dfs, dfs_end,
- * num_leaves, blk_node0, blk_eoff, blk_sum, ev_word, ev_meta, cp_off, cp_word.
+ * num_leaves, blk_node0, blk_eoff, blk_sum, ev_word, ev_meta, ev_lb, cp_off, cp_word.
  * Stream fields (nkey, nstat, blk_*, ev_*, cp_*) take an optional "<i>:" prefix
  * selecting sweep stream i (default: the whole-tree stream).
  * The returned pointer is borrowed from the handle; *elem_bytes is the element

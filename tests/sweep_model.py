@@ -51,7 +51,8 @@ class FlatModel:
         for name in ("node_woff", "words", "rank2dfs", "dfs2bfs", "dfs2id", "bfs2id"):
             setattr(self, name, flat.get(name))
         self.gnstat = flat.get("nstat")            # whole-tree stream == global DFS order
-        for name in ("nkey", "nstat", "blk_node0", "blk_eoff", "blk_sum", "ev_word", "ev_meta", "cp_off", "cp_word"):
+        for name in ("nkey", "nstat", "blk_node0", "blk_eoff", "blk_sum", "ev_word", "ev_meta", "ev_lb", "cp_off",
+                     "cp_word"):
             setattr(self, name, flat.get(name, self.stream))
         self.NB = len(self.blk_node0) - 1
         self.N = len(self.nkey)
@@ -110,7 +111,11 @@ class FlatModel:
             touched = [False] * nn
             net = 0
             H = 0
+            lbmin = 0x3FFFFFFF
             for e in hits:
+                # crown streams: per-event bound; whole-tree stream: the block minimum
+                eager = self.stream != self.f.n_streams - 1
+                lbmin = min(lbmin, int(self.ev_lb[e]) if (eager and e < e0 + 128) else min(min_all, 0 if e >= e0 + 128 else min_all))
                 w = int(self.ev_word[e])
                 o = int(self.ev_meta[e]) & 63
                 s = Sd[w & 0xFFFFF]
@@ -132,7 +137,8 @@ class FlatModel:
                     a, dc = own_adjust(w, s)
                     adj[o] += a
                     dcom[o] += dc
-            pruned = bool(hits) and prune and node_scores is None and (min_all + c - H > bs)
+            pruned = (bool(hits) and prune and node_scores is None and (lbmin + c - H > bs)
+                      and (base == SCORE_INF or base + c > bs))
             self.n_heavy += 0 if (pruned or not hits) else 1
             self.n_light += 1 if pruned else 0
             if pruned and not self.verify_prune:

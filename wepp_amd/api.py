@@ -174,7 +174,7 @@ class GenTree:
 class FlatView:
     """Host-only view of the flattened MAT (wepp_flat_*), for the CPU tests."""
 
-    _DT = {"nkey": np.int64, "ev_meta": np.uint8}
+    _DT = {"nkey": np.int64, "ev_meta": np.uint8, "ev_lb": np.uint8}
 
     def __init__(self, tree):
         self._tree = tree

@@ -27,6 +27,7 @@ struct DevStream {
     const BlkSum* blk_sum;
     const uint32_t* ev_word;
     const uint8_t* ev_meta;
+    const uint8_t* ev_lb;
     const uint32_t* cp_off;
     const uint32_t* cp_word;
 };

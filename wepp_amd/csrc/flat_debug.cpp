@@ -51,7 +51,7 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
     }
     const wepp::Stream& st = f.streams[si];
     FIELD(st, nkey) FIELD(st, nstat) FIELD(st, blk_node0) FIELD(st, blk_eoff) FIELD(st, blk_sum) FIELD(st, ev_word)
-    FIELD(st, ev_meta) FIELD(st, cp_off) FIELD(st, cp_word)
+    FIELD(st, ev_meta) FIELD(st, ev_lb) FIELD(st, cp_off) FIELD(st, cp_word)
 #undef FIELD
     return wepp::set_error(WEPP_EINVAL, std::string("unknown flat field: ") + name);
 }

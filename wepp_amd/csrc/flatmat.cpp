@@ -92,6 +92,19 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
     {
         st.ev_word.assign(st.E, W_PAD);
         st.ev_meta.assign(st.E, 0);
+        st.ev_lb.assign(st.E, 255);
+        // min static score over the (selected) subtree of every node, and over the rest of its block
+        std::vector<int32_t> submin(n), sufmin(n);
+        for (uint32_t i = 0; i < n; i++) submin[i] = (int32_t)(st.nkey[i] >> 32);
+        for (uint32_t i = n; i-- > 1;) submin[lpar[i]] = std::min(submin[lpar[i]], submin[i]);
+        for (uint32_t b = 0; b < st.NB; b++) {
+            int32_t run = SCORE_INF;
+            for (uint32_t d = st.blk_node0[b + 1]; d-- > st.blk_node0[b];) {
+                run = std::min(run, (int32_t)(st.nkey[d] >> 32));
+                sufmin[d] = run;
+            }
+        }
+        auto clamp8 = [](int32_t v) { return (uint8_t)std::max(0, std::min(255, v)); };
         std::vector<uint32_t> blk_of(n), fill(n, 0);
         {
             uint32_t b = 0, cur = 0;
@@ -111,6 +124,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
                     const uint32_t e = fill[x]++;
                     st.ev_word[e] = f.words[w] | W_EXIT;
                     st.ev_meta[e] = (uint8_t)xoff;
+                    st.ev_lb[e] = clamp8(sufmin[x]);
                 }
             }
         }
@@ -122,6 +136,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
                 const uint32_t e = fill[i]++;
                 st.ev_word[e] = f.words[w] | (leaf ? W_LEAF : 0);
                 st.ev_meta[e] = (uint8_t)off;
+                st.ev_lb[e] = clamp8(submin[i]);
             }
         }
     }

@@ -71,6 +71,9 @@ struct Stream {
     std::vector<BlkSum> blk_sum;       // [NB]
     std::vector<uint32_t> ev_word;     // [E]
     std::vector<uint8_t> ev_meta;      // [E]
+    std::vector<uint8_t> ev_lb;        // [E] lower bound (clamped to 255) of the static score of every node the
+                                       //     event can affect inside its block: enter -> min over the subtree of
+                                       //     its node, exit -> min over the rest of the block
     // checkpoints: enter words of every node still open when a sequential sweep
     // reaches block i*cp_stride (node blk_node0[..]-1 unless it closes there, and its ancestors)
     std::vector<uint32_t> cp_off;      // [ncp+1]

@@ -386,21 +386,32 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
     // ---- one block: lane = read ----------------------------------------------------
     // w0/w1 = this lane's two words of the block's first 128 events (W_PAD beyond e1)
     auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, const BlkSum sum) {
-        int net = 0, H = 0;
+        int net = 0, H = 0, lbmin = 0x3FFFFFFF;
         bool touched = false;
-        // for a hit event, every read looks the position up in its own entries
-        auto light_hit = [&](uint32_t wl) {
+        // for a hit event, every read looks the position up in its own entries; lbl = lower
+        // bound of the static score of the nodes this event can affect in the block
+        auto light_hit = [&](uint32_t wl, int lbl) {
             const uint32_t s = have ? find_entry(S, my_off, my_k, w_pos(wl)) : NONE;
             if (s != NONE) {
                 const int d = enter_delta(wl, s);
                 const int ad = d < 0 ? -d : d;
                 touched = true;
+                lbmin = min(lbmin, lbl);
                 if (wl & W_EXIT_DEV) { net -= d; H += ad; }
                 else if (wl & W_LEAF_DEV) { H += 1; }
                 else { net += d; H += ad + 1; }
             }
         };
         const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
+        // per-event bounds of this lane's two events.  Crown streams interleave low- and
+        // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
+        // on the whole-tree stream the block minimum already prunes ~95 % and costs no load.
+        uint32_t lb0 = (uint32_t)max(sum.min_all, 0), lb1 = lb0;
+        if (m.eager && (hm0 | hm1) && e0 + 2 * lane < e1) {
+            const uint32_t ll = *reinterpret_cast<const uint16_t*>(m.ev_lb + e0 + 2 * lane);
+            lb0 = ll & 0xFFu;
+            lb1 = ll >> 8;
+        }
         // a block with a hit may need the node-by-node evaluation: fetch what it reads
         // now, so that the loads overlap the lookups below
         uint32_t m0 = 0, m1 = 0, st = 0;
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             // many hit events (long reads): lane = event.  Every lane looks its event up in
             // the tile-sorted key array and adds its contribution to the owning read's
             // accumulators in LDS; all events of the block are resolved together.
-            auto dense_half = [&](uint32_t w, bool act) {
+            auto dense_half = [&](uint32_t w, uint32_t lb, bool act) {
                 const uint32_t p = w_pos(w);
                 const uint32_t want = p << 12;
                 uint32_t lo = 0;
@@ -444,16 +455,18 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
                         const uint32_t o = owner[idx];
                         if (dn) atomicAdd(&acc[o], dn);
                         if (dh) atomicAdd(&acc[64 + o], dh);
-                        atomicAdd(&acc[128 + o], 1);
+                        // touched marker + running min of the events' bounds (max of 2^30 - lb)
+                        atomicMax(&acc[128 + o], 0x40000000 - (int)lb);
                     }
                     i++;
                 }
             };
-            dense_half(w0, (hm0 >> lane) & 1ull);
-            dense_half(w1, (hm1 >> lane) & 1ull);
+            dense_half(w0, lb0, (hm0 >> lane) & 1ull);
+            dense_half(w1, lb1, (hm1 >> lane) & 1ull);
             __syncthreads();
             if (acc[128 + lane]) {
                 touched = true;
+                lbmin = 0x40000000 - acc[128 + lane];
                 net = acc[lane];
                 H = acc[64 + lane];
                 acc[lane] = 0;
@@ -466,13 +479,13 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             while (hm) {
                 const int l = __builtin_ctzll(hm);
                 hm &= hm - 1;
-                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l));
+                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l), __builtin_amdgcn_readlane((int)lb0, l));
             }
             hm = hm1;
             while (hm) {
                 const int l = __builtin_ctzll(hm);
                 hm &= hm - 1;
-                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l));
+                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l), __builtin_amdgcn_readlane((int)lb1, l));
             }
         }
         for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             while (hm) {
                 const int l = __builtin_ctzll(hm);
                 hm &= hm - 1;
-                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w, l));
+                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w, l), min(sum.min_all, 0));   // overflow events: block bound
             }
         }
         // reads without an event in this block: one summary update
@@ -490,10 +503,12 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
             else if (s == bs) { cnt += sum.cnt; br = min(br, sum.rank); }
         }
-        // reads with events: no node of the block can reach the current best unless
-        // min_all + c - H does (|delta| per event bounds c, -1 per enter bounds the
-        // node's own adjustment); otherwise evaluate node by node
-        const bool heavy = touched && (sum.min_all + c - H <= bs);
+        // reads with events: a node changed by the events scores at least
+        // (min of the events' bounds) + c - H (|delta| per event bounds c, -1 per enter bounds
+        // the node's own adjustment), a node they leave alone at least base + c.  Unless one
+        // of the two can reach the current best, only c moves on; otherwise evaluate the
+        // block node by node
+        const bool heavy = touched && ((lbmin + c - H <= bs) || (sum.base != SCORE_INF_DEV && sum.base + c <= bs));
         unsigned long long hv = __ballot(heavy);
         while (hv) {
             const int r = __builtin_ctzll(hv);
