@@ -213,6 +213,23 @@ int wepp_gen_reads_get(const wepp_gen_reads_t *r, uint32_t *n_reads, const uint3
                        const uint32_t **read_word);
 int wepp_gen_reads_destroy(wepp_gen_reads_t *r);
 
+/* ---- per-site Fitch-Sankoff: building a MAT from a tree and a VCF ---------- *
+ * Replaces mapper_body::operator() (src/usher_mapper.cpp:7-162), which read_vcf
+ * runs once per VCF row when create_new_mat is set
+ * (src/mutation_annotated_tree.cpp:1907-2031).  Row s has reference base
+ * site_ref[s] (one-hot mask) and names the tree samples
+ * var_node[var_off[s] .. var_off[s+1]) (caller node ids) whose allele masks
+ * var_nuc[..] differ from the reference or are ambiguous; every other leaf
+ * carries the reference base.  The mutation lists of `tree` are ignored.
+ * Output: the mutations mapper_body would add (:145-156), as (row, node id,
+ * par_nuc mask, mut_nuc mask), rows in order and BFS order inside a row.
+ * *n_out receives their number; WEPP_ELIMIT (with *n_out set) when capacity is
+ * too small.  Limits: tree depth <= 140, < 2^28 nodes. */
+int wepp_fitch_sites(const wepp_tree_desc *tree, int device, uint32_t n_sites, const uint8_t *site_ref,
+                     const uint32_t *var_off, const uint32_t *var_node, const uint8_t *var_nuc,
+                     uint64_t capacity, uint64_t *n_out, uint32_t *out_site, uint32_t *out_node,
+                     uint8_t *out_par, uint8_t *out_mut);
+
 /* ---- host-side introspection of the flattened MAT (no GPU needed) -------- *
  * Lets the CPU test-suite check the flattener (orders, parent alleles, per-node
  * constants, event stream) against the oracle.  `name` is one of: node_woff,

@@ -751,3 +751,72 @@ int oracle_imputed_at_node(const otree *T, int nS, const int32_t *s_pos, const u
     free(scratch.v); free(scratch.pos); free(imp); free(nhu); free(st.best_j_vec.v); free(S);
     return n_imp;
 }
+
+/* ======================================================================== *
+ * mapper_body: per-site Fitch-Sankoff used when a MAT is built from a tree   *
+ * and a VCF (usher_mapper.cpp:7-162, called from read_vcf with              *
+ * create_new_mat, mutation_annotated_tree.cpp:1964).  One call = one VCF row.*
+ * Restated for the tree samples only (variants of samples that are not in   *
+ * the tree are appended to Missing_Sample lists at :64-83, which is not a   *
+ * computation).                                                            *
+ *   var_node[i]  caller id of a tree node named in the row                  *
+ *   var_nuc[i]   its allele mask (:50, one bit per possible base)           *
+ * Output: one (node id, par_nuc mask, mut_nuc mask) per mutation the site    *
+ * adds (:145-156), in BFS order of the nodes.  Returns their number.         *
+ * ======================================================================== */
+int oracle_mapper_body(const otree *T, uint8_t ref_nuc, int n_var, const int32_t *var_node,
+                       const uint8_t *var_nuc, int32_t *out_node, uint8_t *out_par, uint8_t *out_mut) {
+    const int num_nodes = T->n;
+    int *scores = (int *)calloc((size_t)num_nodes * 4, sizeof(int));        /* :22-32 */
+    int8_t *states = (int8_t *)calloc((size_t)num_nodes, 1);
+    int *bfs_idx = (int *)malloc(sizeof(int) * (size_t)num_nodes);          /* bfs_idx[caller id] */
+    for (int i = 0; i < num_nodes; i++) bfs_idx[T->bfs[i]->id] = i;
+    int ref_nuc_id = -1;                                                    /* MAT::get_nt, mat.cpp:142-162 */
+    for (int j = 0; j < 4; j++) if (ref_nuc == (1 << j)) ref_nuc_id = j;
+    if (ref_nuc_id < 0) { free(scores); free(states); free(bfs_idx); return -1; }
+    for (int i = 0; i < num_nodes; i++) {                                   /* :36-45 leaves */
+        if (!n_is_leaf(T->bfs[i])) continue;
+        for (int j = 0; j < 4; j++) if (j != ref_nuc_id) scores[i * 4 + j] = num_nodes;
+    }
+    for (int v = 0; v < n_var; v++) {                                       /* :48-63 */
+        int idx = bfs_idx[var_node[v]];
+        for (int j = 0; j < 4; j++) {
+            scores[idx * 4 + j] = num_nodes;
+            if (((1 << j) & var_nuc[v]) != 0) scores[idx * 4 + j] = 0;
+        }
+    }
+    for (int i = num_nodes - 1; i >= 0; i--) {                              /* :87-112 forward pass */
+        onode *node = T->bfs[i];
+        if (n_is_leaf(node)) continue;
+        for (int c = 0; c < node->nchildren; c++) {
+            int c_idx = bfs_idx[node->children[c]->id];
+            for (int j = 0; j < 4; j++) {
+                int min_s = num_nodes + 1;
+                for (int k = 0; k < 4; k++) {
+                    int c_s = (k == j) ? scores[c_idx * 4 + k] : scores[c_idx * 4 + k] + 1;
+                    if (c_s < min_s) min_s = c_s;
+                }
+                scores[i * 4 + j] += min_s;
+            }
+        }
+    }
+    int n_out = 0;
+    for (int i = 0; i < num_nodes; i++) {                                   /* :115-157 backward pass */
+        onode *node = T->bfs[i];
+        int8_t par_state = node->parent ? states[bfs_idx[node->parent->id]] : (int8_t)ref_nuc_id;
+        int8_t state = par_state;
+        int min_s = scores[i * 4 + par_state];
+        for (int j = 0; j < 4; j++)
+            if (scores[i * 4 + j] < min_s) { min_s = scores[i * 4 + j]; state = (int8_t)j; }
+        if (state != par_state && scores[i * 4 + par_state] == min_s) state = par_state;
+        states[i] = state;
+        if (state != par_state) {
+            out_node[n_out] = node->id;
+            out_par[n_out] = (uint8_t)(1 << par_state);
+            out_mut[n_out] = (uint8_t)(1 << state);
+            n_out++;
+        }
+    }
+    free(scores); free(states); free(bfs_idx);
+    return n_out;
+}

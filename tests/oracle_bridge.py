@@ -46,6 +46,7 @@ def lib():
         L.oracle_place_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         L.oracle_imputed_at_node.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_mapper_body.argtypes = [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_int] + [ctypes.c_void_p] * 5
         L.oracle_place_batch_nodepar.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         for f in ("oracle_tree_bfs_ids", "oracle_tree_dfs_ids", "oracle_tree_num_leaves"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -123,6 +124,17 @@ class OracleTree:
         c = lib().oracle_imputed_at_node(self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8),
                                          _p(missing if n else z8), int(bfs_j), _p(op), _p(on))
         return list(zip(op[:c].tolist(), on[:c].tolist()))
+
+    def mapper_body(self, ref_nuc, var_node, var_nuc):
+        """One VCF row through the Fitch-Sankoff mapper_body: list of (node id, par_nuc, mut_nuc)."""
+        vn = np.ascontiguousarray(var_node, np.int32)
+        vc = np.ascontiguousarray(var_nuc, np.uint8)
+        on = np.zeros(self.n, np.int32); op = np.zeros(self.n, np.uint8); om = np.zeros(self.n, np.uint8)
+        z32 = np.zeros(1, np.int32); z8 = np.zeros(1, np.uint8)
+        c = lib().oracle_mapper_body(self._h, int(ref_nuc), len(vn), _p(vn if len(vn) else z32),
+                                     _p(vc if len(vc) else z8), _p(on), _p(op), _p(om))
+        assert c >= 0
+        return list(zip(on[:c].tolist(), op[:c].tolist(), om[:c].tolist()))
 
     def place_batch(self, reads, nthreads=1, node_parallel=False):
         """reads: wepp_amd.Reads.  Returns a structured array.  node_parallel=True

@@ -1,0 +1,123 @@
+"""Per-site Fitch-Sankoff (mapper_body, usher_mapper.cpp:7-162): oracle sanity on
+the CPU, GPU kernels vs oracle through the C-ABI."""
+import numpy as np
+import pytest
+
+import fuzz_trees as ft
+import wepp_amd as w
+from wepp_amd import A, C, G, T, Tree
+
+
+def _random_rows(rng, tree, n_rows, p_var=0.15, p_internal=0.02, p_amb=0.1):
+    n = tree.n_nodes
+    has_child = np.zeros(n, bool)
+    for p in tree.parent:
+        if p >= 0:
+            has_child[p] = True
+    site_ref, var_off, var_node, var_nuc = [], [0], [], []
+    for _ in range(n_rows):
+        ref = 1 << int(rng.integers(0, 4))
+        site_ref.append(ref)
+        for i in range(n):
+            pr = p_internal if has_child[i] else p_var
+            if rng.random() < pr:
+                nuc = 1 << int(rng.integers(0, 4))
+                if rng.random() < p_amb:
+                    nuc |= 1 << int(rng.integers(0, 4))
+                var_node.append(i)
+                var_nuc.append(nuc)
+        var_off.append(len(var_node))
+    return (np.array(site_ref, np.uint8), np.array(var_off, np.uint32), np.array(var_node, np.uint32),
+            np.array(var_nuc, np.uint8))
+
+
+def test_oracle_mapper_body_hand_cases(oracle):
+    # ((A,B),(C,D)); site with ref A
+    t = Tree.from_lists([-1, 0, 0, 1, 1, 2, 2], [[] for _ in range(7)])
+    ot = oracle.OracleTree(t)
+    assert ot.mapper_body(A, [], []) == []                                  # nobody differs: no mutation
+    assert ot.mapper_body(A, [3], [G]) == [(3, A, G)]                       # one leaf: mutation on the leaf
+    assert ot.mapper_body(A, [3, 4], [G, G]) == [(1, A, G)]                 # both leaves of a cherry: on their parent
+    # three of four leaves G: G wins at the root, D (=6) mutates back to the reference base
+    assert ot.mapper_body(A, [3, 4, 5], [G, G, G]) == [(0, A, G), (6, G, A)]
+    # an ambiguous leaf (A or G) next to a G leaf resolves to G on the parent
+    assert ot.mapper_body(A, [3, 4], [G, A | G]) == [(1, A, G)]
+
+
+@pytest.mark.gpu
+def test_fitch_kernels_vs_oracle(oracle):
+    rng = np.random.default_rng(2024)
+    total = 0
+    for it in range(30):
+        tree, _ = ft.random_tree(rng, n_nodes=int(rng.integers(1, 300)), max_muts=0, root_muts=False, p_masked=0.0,
+                                 p_root_masked=0.0)
+        n_rows = int(rng.integers(1, 200))
+        site_ref, var_off, var_node, var_nuc = _random_rows(rng, tree, n_rows)
+        s, nd, par, mut = w.fitch_sites(tree, site_ref, var_off, var_node, var_nuc)
+        ot = oracle.OracleTree(tree)
+        k = 0
+        for r in range(n_rows):
+            a, b = int(var_off[r]), int(var_off[r + 1])
+            want = ot.mapper_body(int(site_ref[r]), var_node[a:b].astype(np.int32), var_nuc[a:b])
+            got = [(int(nd[i]), int(par[i]), int(mut[i])) for i in range(k, k + len(want))]
+            assert (s[k:k + len(want)] == r).all() and got == want, (it, r)
+            k += len(want)
+        assert k == len(s)
+        total += k
+    assert total > 1000
+
+
+@pytest.mark.gpu
+def test_fitch_rebuilds_the_mutations_of_a_generated_tree(oracle):
+    """Round trip: take a generated MAT, turn every leaf genotype into VCF rows, run
+    Fitch-Sankoff on the bare topology -- the result must equal the oracle's on every row."""
+    g = w.generate_tree(71, 4000, genome_len=400)
+    tree = g.tree
+    n = tree.n_nodes
+    has_child = np.zeros(n, bool)
+    has_child[tree.parent[tree.parent >= 0]] = True
+    # genotype of every leaf: walk up to the root
+    geno = {}
+    for leaf in np.flatnonzero(~has_child):
+        gt = {}
+        i = int(leaf)
+        while i >= 0:
+            for k in range(int(tree.mut_off[i]), int(tree.mut_off[i + 1])):
+                gt.setdefault(int(tree.mut_pos[k]), (int(tree.mut_ref[k]), int(tree.mut_mut[k])))
+            i = int(tree.parent[i])
+        geno[int(leaf)] = gt
+    sites = sorted({p for gt in geno.values() for p in gt})
+    ref_of = {}
+    for gt in geno.values():
+        for p, (r, m) in gt.items():
+            ref_of[p] = r
+    site_ref, var_off, var_node, var_nuc = [], [0], [], []
+    for p in sites:
+        site_ref.append(ref_of[p])
+        for leaf, gt in geno.items():
+            if p in gt and gt[p][1] != ref_of[p]:
+                var_node.append(leaf)
+                var_nuc.append(gt[p][1])
+        var_off.append(len(var_node))
+    bare = Tree(tree.parent, np.zeros(n + 1, np.uint32), [], [], [])
+    s, nd, par, mut = w.fitch_sites(bare, np.array(site_ref, np.uint8), np.array(var_off, np.uint32),
+                                    np.array(var_node, np.uint32), np.array(var_nuc, np.uint8))
+    ot = oracle.OracleTree(bare)
+    k = 0
+    for r in range(len(sites)):
+        a, b = var_off[r], var_off[r + 1]
+        want = ot.mapper_body(site_ref[r], np.array(var_node[a:b], np.int32), np.array(var_nuc[a:b], np.uint8))
+        got = [(int(nd[i]), int(par[i]), int(mut[i])) for i in range(k, k + len(want))]
+        assert got == want and (s[k:k + len(want)] == r).all(), r
+        k += len(want)
+    assert k == len(s) > 0
+
+
+@pytest.mark.gpu
+def test_fitch_argument_errors():
+    t = Tree.from_lists([-1, 0, 0], [[], [], []])
+    with pytest.raises(w.WeppError) as ei:
+        w.fitch_sites(t, [A | C], [0, 0], [], [])
+    assert ei.value.code == 1
+    with pytest.raises(w.WeppError):
+        w.fitch_sites(t, [A], [0, 1], [7], [G])

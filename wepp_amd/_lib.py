@@ -114,6 +114,8 @@ _SIGS = {
         [_V, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64),
          ctypes.POINTER(ctypes.c_uint64)],
     ),
+    "wepp_fitch_sites": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.c_int, ctypes.c_uint32, _V, _V, _V, _V,
+                                        ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), _V, _V, _V, _V]),
     "wepp_last_error": (ctypes.c_char_p, []),
     "wepp_gen_tree_create": (ctypes.c_int, [ctypes.POINTER(GenTreeParams), ctypes.POINTER(_V)]),
     "wepp_gen_tree_desc": (ctypes.c_int, [_V, ctypes.POINTER(TreeDescC)]),

@@ -221,6 +221,35 @@ class FlatView:
             pass
 
 
+def fitch_sites(tree, site_ref, var_off, var_node, var_nuc, device=0, capacity=None):
+    """Per-site Fitch-Sankoff (wepp_fitch_sites): returns arrays (site, node id, par_nuc, mut_nuc)
+    of the mutations mapper_body would add, rows in order, BFS order inside a row."""
+    site_ref = np.ascontiguousarray(site_ref, np.uint8)
+    var_off = np.ascontiguousarray(var_off, np.uint32)
+    var_node = np.ascontiguousarray(var_node, np.uint32)
+    var_nuc = np.ascontiguousarray(var_nuc, np.uint8)
+    n_sites = int(site_ref.shape[0])
+    cap = int(capacity if capacity is not None else max(1024, 4 * int(var_off[-1]) + n_sites))
+    d = tree.desc()
+    while True:
+        o_site = np.zeros(cap, np.uint32)
+        o_node = np.zeros(cap, np.uint32)
+        o_par = np.zeros(cap, np.uint8)
+        o_mut = np.zeros(cap, np.uint8)
+        n_out = ctypes.c_uint64()
+        vn = var_node if var_node.size else np.zeros(1, np.uint32)
+        vc = var_nuc if var_nuc.size else np.zeros(1, np.uint8)
+        rc = lib.wepp_fitch_sites(ctypes.byref(d), int(device), n_sites, _ptr(site_ref), _ptr(var_off), _ptr(vn),
+                                  _ptr(vc), cap, ctypes.byref(n_out), _ptr(o_site), _ptr(o_node), _ptr(o_par),
+                                  _ptr(o_mut))
+        if rc == 4 and n_out.value > cap and capacity is None:
+            cap = int(n_out.value)
+            continue
+        check(rc)
+        n = int(n_out.value)
+        return o_site[:n], o_node[:n], o_par[:n], o_mut[:n]
+
+
 class PlacementResult:
     def __init__(self, best_bfs_j, score, num_best, flags):
         self.best_bfs_j = best_bfs_j

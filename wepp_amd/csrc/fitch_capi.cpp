@@ -1,0 +1,157 @@
+// fitch_capi.cpp -- C-ABI of the per-site Fitch-Sankoff pass (mapper_body,
+// src/usher_mapper.cpp:7-162, driven by read_vcf(create_new_mat = true),
+// src/mutation_annotated_tree.cpp:1907-2031).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/wepp_place.h"
+#include "errors.hpp"
+#include "fitch.hpp"
+#include "flatmat.hpp"
+
+using namespace wepp;
+
+namespace {
+int hipf(hipError_t e, const char* what) {
+    return set_error(WEPP_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 16)); }
+    template <typename T> T* as() { return (T*)p; }
+};
+}  // namespace
+
+extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t n_sites, const uint8_t* site_ref,
+                                const uint32_t* var_off, const uint32_t* var_node, const uint8_t* var_nuc,
+                                uint64_t capacity, uint64_t* n_out, uint32_t* out_site, uint32_t* out_node,
+                                uint8_t* out_par, uint8_t* out_mut) {
+    if (!tree || !n_out || !var_off || (n_sites && !site_ref)) return set_error(WEPP_EINVAL, "null argument");
+    *n_out = 0;
+    if (n_sites == 0) return WEPP_OK;
+    // topology only: the mutation lists of `tree` are ignored (a new MAT is being built)
+    std::vector<uint32_t> zero_off((size_t)tree->n_nodes + 1, 0);
+    wepp_tree_desc topo = *tree;
+    topo.mut_off = zero_off.data();
+    topo.mut_pos = nullptr; topo.mut_ref = nullptr; topo.mut_par = nullptr; topo.mut_mut = nullptr;
+    FlatMAT f;
+    std::string err;
+    try {
+        int rc = flatten_tree(topo, f, err);
+        if (rc != WEPP_OK) return set_error(rc, err);
+    } catch (const std::bad_alloc&) {
+        return set_error(WEPP_ENOMEM, "out of host memory while flattening the tree");
+    }
+    const uint32_t N = f.N;
+    if (N >= (1u << 28)) return set_error(WEPP_ELIMIT, "more than 2^28 nodes");
+    if (f.max_depth > FITCH_MAX_DEPTH)
+        return set_error(WEPP_ELIMIT, "tree depth " + std::to_string(f.max_depth) + " exceeds the LDS stack (" +
+                                          std::to_string(FITCH_MAX_DEPTH) + ")");
+    std::vector<uint32_t> meta(N), id2dfs(N);
+    {
+        std::vector<uint32_t> depth(N, 0);
+        for (uint32_t d = 0; d < N; d++) {
+            if (d) depth[d] = depth[f.parent_dfs[d]] + 1;
+            meta[d] = depth[d] | ((f.nstat[d] & NS_LEAF) ? 0x80000000u : 0u);
+            id2dfs[f.dfs2id[d]] = d;
+        }
+    }
+    // rows: reference base index, tree samples sorted by DFS index
+    const uint64_t nv = var_off[n_sites];
+    if (nv && (!var_node || !var_nuc)) return set_error(WEPP_EINVAL, "null variant arrays");
+    std::vector<uint8_t> ref_idx(n_sites), vnuc(nv);
+    std::vector<uint32_t> vdfs(nv);
+    std::vector<std::pair<uint32_t, uint8_t>> row;
+    for (uint32_t s = 0; s < n_sites; s++) {
+        const uint8_t r = site_ref[s] & 15;
+        if (r == 0 || (r & (r - 1)))
+            return set_error(WEPP_EINVAL, "site_ref must be a single nucleotide (row " + std::to_string(s) + ")");
+        ref_idx[s] = (uint8_t)__builtin_ctz(r);
+        if (var_off[s + 1] < var_off[s]) return set_error(WEPP_EINVAL, "var_off not monotone");
+        row.clear();
+        for (uint32_t k = var_off[s]; k < var_off[s + 1]; k++) {
+            if (var_node[k] >= N) return set_error(WEPP_EINVAL, "var_node out of range");
+            row.emplace_back(id2dfs[var_node[k]], var_nuc[k]);
+        }
+        // a node named twice in a row: the later entry wins, as the later assignment does at usher_mapper.cpp:57-62
+        std::stable_sort(row.begin(), row.end(), [](const std::pair<uint32_t, uint8_t>& a,
+                                                    const std::pair<uint32_t, uint8_t>& b) { return a.first < b.first; });
+        uint32_t w = var_off[s];
+        for (size_t i = 0; i < row.size(); i++) {
+            if (i + 1 < row.size() && row[i + 1].first == row[i].first) continue;
+            vdfs[w] = row[i].first;
+            vnuc[w] = row[i].second;
+            w++;
+        }
+        for (; w < var_off[s + 1]; w++) { vdfs[w] = 0xFFFFFFFFu; vnuc[w] = 0; }   // dropped duplicates
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return set_error(WEPP_EDEVICE, "no HIP device available (the Fitch-Sankoff pass has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(WEPP_EINVAL, "device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hipf(e, "hipSetDevice");
+
+    DevBuf d_meta, d_ref, d_voff, d_vdfs, d_vnuc, d_tables, d_count, d_out;
+    const uint32_t nbatches = (n_sites + 63) / 64;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const size_t per_batch = (size_t)N * 64;
+    const size_t budget = free_b / 2;
+    const uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nbatches, budget / std::max<size_t>(per_batch, 1)));
+    if ((e = d_meta.alloc((size_t)N * 4)) != hipSuccess || (e = d_ref.alloc(n_sites)) != hipSuccess ||
+        (e = d_voff.alloc((size_t)(n_sites + 1) * 4)) != hipSuccess || (e = d_vdfs.alloc(nv * 4)) != hipSuccess ||
+        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_tables.alloc(per_batch * group)) != hipSuccess ||
+        (e = d_count.alloc(8)) != hipSuccess || (e = d_out.alloc(std::max<uint64_t>(capacity, 1) * 8)) != hipSuccess)
+        return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemcpy(d_meta.p, meta.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_ref.p, ref_idx.data(), n_sites, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_voff.p, var_off, (size_t)(n_sites + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nv) e = hipMemcpy(d_vdfs.p, vdfs.data(), nv * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nv) e = hipMemcpy(d_vnuc.p, vnuc.data(), nv, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_count.p, 0, 8);
+    if (e != hipSuccess) return hipf(e, "upload");
+    FitchTree ft{N, f.max_depth, d_meta.as<uint32_t>()};
+    FitchSites fs{n_sites, d_ref.as<uint8_t>(), d_voff.as<uint32_t>(), d_vdfs.as<uint32_t>(), d_vnuc.as<uint8_t>()};
+    for (uint32_t b0 = 0; b0 < nbatches; b0 += group) {
+        const uint32_t nb = std::min(group, nbatches - b0);
+        e = launch_fitch_forward(ft, fs, b0, nb, d_tables.as<uint8_t>(), nullptr);
+        if (e == hipSuccess)
+            e = launch_fitch_backward(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_count.as<unsigned long long>(), capacity,
+                                      d_out.as<uint2>(), nullptr);
+        if (e != hipSuccess) return hipf(e, "Fitch-Sankoff kernels");
+    }
+    unsigned long long cnt = 0;
+    e = hipMemcpy(&cnt, d_count.p, 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hipf(e, "Fitch-Sankoff kernels");
+    *n_out = cnt;
+    if (cnt > capacity) return set_error(WEPP_ELIMIT, "output buffers too small: " + std::to_string(cnt) + " mutations");
+    if (cnt == 0) return WEPP_OK;
+    if (!out_site || !out_node || !out_par || !out_mut) return set_error(WEPP_EINVAL, "null output buffer");
+    std::vector<uint2> raw(cnt);
+    e = hipMemcpy(raw.data(), d_out.p, cnt * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hipf(e, "D2H copy of the mutations");
+    // rows in order; inside a row, nodes in BFS order (the order mapper_body visits them, :115)
+    std::vector<uint64_t> order(cnt);
+    std::iota(order.begin(), order.end(), 0ull);
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+        if (raw[a].x != raw[b].x) return raw[a].x < raw[b].x;
+        return f.dfs2bfs[raw[a].y & 0x0FFFFFFFu] < f.dfs2bfs[raw[b].y & 0x0FFFFFFFu];
+    });
+    for (uint64_t i = 0; i < cnt; i++) {
+        const uint2 r = raw[order[i]];
+        out_site[i] = r.x;
+        out_node[i] = f.dfs2id[r.y & 0x0FFFFFFFu];
+        out_par[i] = (uint8_t)(1u << ((r.y >> 28) & 3u));
+        out_mut[i] = (uint8_t)(1u << ((r.y >> 30) & 3u));
+    }
+    return WEPP_OK;
+}
