@@ -249,7 +249,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t* info = mat->h_info;
 
     // ---- plan the launches ---------------------------------------------------------
-    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; };
+    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; };
     Plan plans[MAX_STREAMS];
     uint32_t np = 0;
     size_t part_total = 0;
@@ -271,21 +271,24 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         p.ntiles = (count + Tp - 1) / Tp;
         // a read longer than MAX_TILE_ENTRIES words is swept alone with its words left in global memory
         p.s_in_lds = maxk <= MAX_TILE_ENTRIES;
-        p.dense = p.s_in_lds && maxk >= DENSE_MIN_READ_WORDS;
+        p.dense = p.s_in_lds && maxk >= DENSE_MIN_READ_WORDS && mat->dev.max_pos <= DENSE_MAX_POS;
         const uint64_t need = std::min<uint64_t>((uint64_t)std::min(Tp, count) * maxk, MAX_TILE_ENTRIES);
-        uint32_t cap = 64;
-        if (p.dense) while (cap < need) cap <<= 1;          // the bitonic network wants a power of two
-        else cap = (uint32_t)((need + 63) & ~63ull);
+        const uint32_t cap = (uint32_t)((need + 63) & ~63ull);
+        uint32_t kcap = 64;
+        while (kcap < need) kcap <<= 1;                        // the bitonic network wants a power of two
         p.ent_cap = p.s_in_lds ? cap : 0;
-        p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, p.dense) : bm_bytes;
+        p.key_cap = p.dense ? kcap : 0;
+        p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, kcap, p.dense) : bm_bytes;
         // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
         const DevStream& st = mat->streams[t];
         const uint32_t target_waves = 8192;
         uint32_t nchunks = std::max<uint32_t>(1, (target_waves + p.ntiles - 1) / p.ntiles);
+        if (p.dense) nchunks = std::max<uint32_t>(nchunks, DENSE_WAVES_PER_WG);   // one chunk per wave of the workgroup
         nchunks = std::min(nchunks, st.ncp);
         const uint32_t cps_per_chunk = (st.ncp + nchunks - 1) / nchunks;
         p.bpc = cps_per_chunk * st.cp_stride;
         p.nchunks = (st.NB + p.bpc - 1) / p.bpc;
+        if (p.dense) p.nchunks = (p.nchunks + DENSE_WAVES_PER_WG - 1) / DENSE_WAVES_PER_WG * DENSE_WAVES_PER_WG;
         p.part_off = part_total;
         part_total += (size_t)p.nchunks * count * 12;
     }
@@ -318,7 +321,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
         uint32_t* pc = pr + (size_t)p.nchunks * p.count;
         HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, p.T, p.ntiles,
-                             p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.lds_bytes, ps, pr, pc, q));
+                             p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
         passes += p.ntiles;                                   // every tile sweeps its stream once
         bytes += (uint64_t)p.ntiles * mat->stream_bytes[p.t];
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,

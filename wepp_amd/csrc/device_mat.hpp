@@ -59,15 +59,17 @@ hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
                         const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
-                        uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank,
-                        uint32_t* part_cnt, hipStream_t stream);
+                        uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
+                        uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream);
+constexpr uint32_t DENSE_WAVES_PER_WG = 8;     // waves sharing one tile's LDS index in the dense variant
 // LDS bytes of a k_sweep workgroup: bitmap + read words (+ dense: sorted keys + owners + accumulators)
-inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, bool dense) {
-    return bm_words * 4 + ent_cap * (dense ? 9 : 4) + (dense ? 3 * 64 * 4 : 0);
+inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense) {
+    return bm_words * 4 + ent_cap * (dense ? 5 : 4) + (dense ? key_cap * 4 + DENSE_WAVES_PER_WG * 3 * 64 * 4 : 0);
 }
-// read words per tile (<= 4096: 12-bit entry index in the sorted keys).  Measured on 1.2 kb reads
-// (58 words each) at 16 M nodes: 2048 -> 41.9 K reads/s, 4096 -> 35.5 K (LDS-limited occupancy)
-constexpr uint32_t MAX_TILE_ENTRIES = 2048;
+// read words per tile: the plain variant is bounded by its LDS request, the dense variant by
+// the 13-bit entry index of its sorted keys (pos:19 | idx:13, hence also max_pos < 2^19)
+constexpr uint32_t MAX_TILE_ENTRIES = 8192;
+constexpr uint32_t DENSE_MAX_POS = (1u << 19) - 1;
 constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep the sorted position index
 hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,

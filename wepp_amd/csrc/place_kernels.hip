@@ -39,6 +39,7 @@ namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int DENSE_MIN_HITS = 3;   // hit events per block from which the lane = event lookup pays
+constexpr uint32_t DENSE_WAVES = wepp::DENSE_WAVES_PER_WG;
 
 // ---- word field helpers ------------------------------------------------------
 // tree / event word: pos:20 | ref idx:2 | par:4 | mut:4 | exit | leaf (flatmat.hpp)
@@ -195,26 +196,29 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
 // longer than MAX_TILE_ENTRIES words).  DENSE: additionally keep a tile-sorted position
 // index in LDS and resolve blocks with many hit events with lane = event (long reads).
 template <bool S_IN_LDS, bool DENSE>
-__global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
-                                              const uint32_t* __restrict__ read_off,
-                                              const uint32_t* __restrict__ read_word,
-                                              const uint32_t* __restrict__ list, uint32_t n_list,
-                                              uint32_t T, uint32_t ntiles, uint32_t blocks_per_chunk,
-                                              int32_t* __restrict__ part_score,
-                                              uint32_t* __restrict__ part_rank,
-                                              uint32_t* __restrict__ part_cnt) {
-    // LDS: [bm_words] bitmap | [ent_cap] read words (tile order) | DENSE only: [ent_cap, pow2]
-    // tile-sorted keys pos:20|idx:12 | [ent_cap] owner lane of each entry (bytes) | [3*64] accumulators
+__global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
+    DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
+    const uint32_t* __restrict__ read_off,
+    const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
+    uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
+    uint32_t* __restrict__ part_cnt) {
+    // A workgroup = one tile of reads.  Plain variant: one wave, one chunk of the stream.
+    // DENSE variant: DENSE_WAVES waves share the tile's LDS structures (so that the larger
+    // footprint does not cost occupancy) and each sweeps its own chunk.
+    // LDS: [bm_words] bitmap | [ent_cap] read words (tile order) | DENSE only: [key_cap, pow2]
+    // tile-sorted keys pos:19|idx:13 | [ent_cap] owner lane of each entry (bytes) | per wave [3*64] accumulators
+    constexpr uint32_t NW = DENSE ? DENSE_WAVES : 1;
     extern __shared__ uint32_t lds[];
     uint32_t* bitmap = lds;
     uint32_t* S_lds = lds + bm_words;
     uint32_t* skey = S_lds + ent_cap;
-    uint8_t* owner = reinterpret_cast<uint8_t*>(skey + ent_cap);
-    int* acc = reinterpret_cast<int*>(owner + ent_cap);        // net[64], H[64], cnt[64]
+    uint8_t* owner = reinterpret_cast<uint8_t*>(skey + key_cap);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    int* acc = reinterpret_cast<int*>(owner + ent_cap) + wv * 192;   // net[64], H[64], bound[64] of this wave
 
-    const uint32_t lane = threadIdx.x;
     const uint32_t tile = blockIdx.x % ntiles;
-    const uint32_t chunk = blockIdx.x / ntiles;
+    const uint32_t chunk = (blockIdx.x / ntiles) * NW + wv;
     const uint32_t r0 = tile * T;                   // first list slot of the tile
     const uint32_t nr = min(T, n_list - r0);
     const bool have = lane < nr;
@@ -231,8 +235,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
     }
     const uint32_t lds_off = incl - my_k;
 
-    for (uint32_t i = lane; i < bm_words; i += 64) bitmap[i] = 0;
-    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bm_words; i += 64 * NW) bitmap[i] = 0;
     // bm_words is a power of two >= (max_pos >> 5) + 1: positions beyond the tree's
     // last mutated site (and the padding word) alias into the map; a false positive
     // only costs a failed lookup in the reads.
@@ -241,26 +244,28 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
     uint32_t n2 = 1;                                   // bitonic network size (power of two >= n_ent)
     while (n2 < n_ent) n2 <<= 1;
     if (DENSE) {
-        for (uint32_t i = lane; i < n2; i += 64) skey[i] = 0xFFFFFFFFu;
-        for (uint32_t i = lane; i < 3 * 64; i += 64) acc[i] = 0;
-        __syncthreads();
-    }
-    for (uint32_t j = 0; j < my_k; j++) {
-        const uint32_t w = read_word[so + j];
-        const uint32_t p = w_pos(w);
-        if (S_IN_LDS) S_lds[lds_off + j] = w;
-        if (DENSE) {
-            skey[lds_off + j] = (p << 12) | (lds_off + j);
-            owner[lds_off + j] = (uint8_t)lane;
-        }
-        if (p <= max_pos) atomicOr(&bitmap[(p >> 5) & bm_mask], 1u << (p & 31));
+        for (uint32_t i = threadIdx.x; i < n2; i += 64 * NW) skey[i] = 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < 192; i += 64) acc[i] = 0;
     }
     __syncthreads();
-    // tile-wide position index: bitonic sort of the keys (once per tile sweep)
+    if (wv == 0) {
+        for (uint32_t j = 0; j < my_k; j++) {
+            const uint32_t w = read_word[so + j];
+            const uint32_t p = w_pos(w);
+            if (S_IN_LDS) S_lds[lds_off + j] = w;
+            if (DENSE) {
+                skey[lds_off + j] = (p << 13) | (lds_off + j);
+                owner[lds_off + j] = (uint8_t)lane;
+            }
+            if (p <= max_pos) atomicOr(&bitmap[(p >> 5) & bm_mask], 1u << (p & 31));
+        }
+    }
+    __syncthreads();
+    // tile-wide position index: bitonic sort of the keys (once per tile, by the whole workgroup)
     if (DENSE) {
         for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
             for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                for (uint32_t i = lane; i < n2; i += 64) {
+                for (uint32_t i = threadIdx.x; i < n2; i += 64 * NW) {
                     const uint32_t x = i ^ j2;
                     if (x > i) {
                         const uint32_t a = skey[i], b = skey[x];
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             }
         }
     }
+    // from here on the waves of a workgroup never synchronise with each other again
 
     // Slice of this lane's read inside S (LDS copy or the global array).
     const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : read_word;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
     const uint32_t b1 = min(m.NB, b0 + blocks_per_chunk);
 
     // ---- state at the chunk start: enter words of every node still open there -
-    {
+    if (b0 < m.NB) {
         const uint32_t cpi = b0 / m.cp_stride;
         const uint32_t e0 = m.cp_off[cpi], e1 = m.cp_off[cpi + 1];
         for (uint32_t e = e0; e < e1; e += 64) {
@@ -437,15 +443,15 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             // accumulators in LDS; all events of the block are resolved together.
             auto dense_half = [&](uint32_t w, uint32_t lb, bool act) {
                 const uint32_t p = w_pos(w);
-                const uint32_t want = p << 12;
+                const uint32_t want = p << 13;
                 uint32_t lo = 0;
                 for (uint32_t step = n2 >> 1; step > 0; step >>= 1)      // lower_bound, n2 is a power of two
                     if (skey[lo + step - 1] < want) lo += step;
                 uint32_t i = lo;
-                while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 12) == p)) {
+                while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 13) == p)) {
                     const uint32_t kv = skey[min(i, n2 - 1)];
-                    if (act && i < n2 && (kv >> 12) == p) {
-                        const uint32_t idx = kv & 4095u;
+                    if (act && i < n2 && (kv >> 13) == p) {
+                        const uint32_t idx = kv & 8191u;
                         const int d = enter_delta(w, S_lds[idx]);
                         const int ad = d < 0 ? -d : d;
                         int dn, dh;
@@ -463,7 +469,10 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
             };
             dense_half(w0, lb0, (hm0 >> lane) & 1ull);
             dense_half(w1, lb1, (hm1 >> lane) & 1ull);
-            __syncthreads();
+            // the accumulators belong to this wave alone; its LDS operations complete in
+            // program order, the barriers only stop the compiler from reordering them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (acc[128 + lane]) {
                 touched = true;
                 lbmin = 0x40000000 - acc[128 + lane];
@@ -473,7 +482,8 @@ __global__ __launch_bounds__(64) void k_sweep(DevStream m, uint32_t bm_words, ui
                 acc[64 + lane] = 0;
                 acc[128 + lane] = 0;
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         } else {
             hm = hm0;
             while (hm) {
@@ -772,15 +782,18 @@ hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
                         const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
-                        uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank,
-                        uint32_t* part_cnt, hipStream_t stream) {
-    const dim3 grid(ntiles * nchunks), block(64);
-#define WEPP_SWEEP(A, B, CAP)                                                                                         \
-    hipLaunchKernelGGL((k_sweep<A, B>), grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, CAP, d_read_off,    \
-                       d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt)
-    if (s_in_lds && dense) WEPP_SWEEP(true, true, ent_cap);
-    else if (s_in_lds) WEPP_SWEEP(true, false, ent_cap);
-    else WEPP_SWEEP(false, false, 0u);
+                        uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
+                        uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream) {
+    // nchunks is a multiple of DENSE_WAVES_PER_WG for the dense variant (capi.cpp)
+    const dim3 grid(dense ? ntiles * (nchunks / DENSE_WAVES_PER_WG) : ntiles * nchunks);
+    const dim3 block(dense ? 64 * DENSE_WAVES_PER_WG : 64);
+#define WEPP_SWEEP(A, B, CAP, KCAP)                                                                                   \
+    hipLaunchKernelGGL((k_sweep<A, B>), grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, CAP, KCAP,          \
+                       d_read_off, d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank,      \
+                       part_cnt)
+    if (s_in_lds && dense) WEPP_SWEEP(true, true, ent_cap, key_cap);
+    else if (s_in_lds) WEPP_SWEEP(true, false, ent_cap, 0u);
+    else WEPP_SWEEP(false, false, 0u, 0u);
 #undef WEPP_SWEEP
     return hipGetLastError();
 }
