@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwepp_place.so")
+# WEPP_PLACE_LIB lets an experiment load another build of the same library
+LIB_PATH = os.environ.get("WEPP_PLACE_LIB") or os.path.join(_HERE, "libwepp_place.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -61,7 +61,10 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
                         uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
                         uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream);
-constexpr uint32_t DENSE_WAVES_PER_WG = 8;     // waves sharing one tile's LDS index in the dense variant
+#ifndef WEPP_DENSE_WAVES
+#define WEPP_DENSE_WAVES 8
+#endif
+constexpr uint32_t DENSE_WAVES_PER_WG = WEPP_DENSE_WAVES;     // waves sharing one tile's LDS index in the dense variant
 // LDS bytes of a k_sweep workgroup: bitmap + read words (+ dense: sorted keys + owners + accumulators)
 inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense) {
     return bm_words * 4 + ent_cap * (dense ? 5 : 4) + (dense ? key_cap * 4 + DENSE_WAVES_PER_WG * 3 * 64 * 4 : 0);

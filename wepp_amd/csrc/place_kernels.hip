@@ -38,7 +38,10 @@ namespace wepp {
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int DENSE_MIN_HITS = 3;   // hit events per block from which the lane = event lookup pays
+#ifndef WEPP_DENSE_MIN_HITS
+#define WEPP_DENSE_MIN_HITS 3
+#endif
+constexpr int DENSE_MIN_HITS = WEPP_DENSE_MIN_HITS;   // hit events per block from which the lane = event lookup pays
 constexpr uint32_t DENSE_WAVES = wepp::DENSE_WAVES_PER_WG;
 
 // ---- word field helpers ------------------------------------------------------
@@ -441,13 +444,17 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
             // many hit events (long reads): lane = event.  Every lane looks its event up in
             // the tile-sorted key array and adds its contribution to the owning read's
             // accumulators in LDS; all events of the block are resolved together.
-            auto dense_half = [&](uint32_t w, uint32_t lb, bool act) {
-                const uint32_t p = w_pos(w);
-                const uint32_t want = p << 13;
-                uint32_t lo = 0;
-                for (uint32_t step = n2 >> 1; step > 0; step >>= 1)      // lower_bound, n2 is a power of two
-                    if (skey[lo + step - 1] < want) lo += step;
-                uint32_t i = lo;
+            // both events of the lane are searched in one loop: two independent chains of
+            // dependent LDS reads in flight instead of one
+            const uint32_t p0 = w_pos(w0), p1 = w_pos(w1);
+            const uint32_t want0 = p0 << 13, want1 = p1 << 13;
+            uint32_t lo0 = 0, lo1 = 0;
+            for (uint32_t step = n2 >> 1; step > 0; step >>= 1) {          // lower_bound, n2 is a power of two
+                const uint32_t k0 = skey[lo0 + step - 1], k1 = skey[lo1 + step - 1];
+                if (k0 < want0) lo0 += step;
+                if (k1 < want1) lo1 += step;
+            }
+            auto dense_apply = [&](uint32_t w, uint32_t p, uint32_t lb, uint32_t i, bool act) {
                 while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 13) == p)) {
                     const uint32_t kv = skey[min(i, n2 - 1)];
                     if (act && i < n2 && (kv >> 13) == p) {
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
                     i++;
                 }
             };
-            dense_half(w0, lb0, (hm0 >> lane) & 1ull);
-            dense_half(w1, lb1, (hm1 >> lane) & 1ull);
+            dense_apply(w0, p0, lb0, lo0, (hm0 >> lane) & 1ull);
+            dense_apply(w1, p1, lb1, lo1, (hm1 >> lane) & 1ull);
             // the accumulators belong to this wave alone; its LDS operations complete in
             // program order, the barriers only stop the compiler from reordering them
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
