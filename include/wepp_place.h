@@ -94,9 +94,9 @@ typedef struct {
     /* sweep streams: crowns {static score <= tau} closed under ancestors, in
      * increasing tau; the last one is the whole tree (tau = INT32_MAX) */
     uint32_t n_streams;
-    int32_t  stream_tau[8];
-    uint64_t stream_nodes[8];
-    uint64_t stream_bytes_of[8];
+    int32_t  stream_tau[16];
+    uint64_t stream_nodes[16];
+    uint64_t stream_bytes_of[16];
 } wepp_mat_stats;
 
 /* Per-read result flags (out parameter `flags`). */

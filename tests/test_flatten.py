@@ -167,7 +167,7 @@ def test_crown_streams_give_the_same_answer_as_the_whole_tree(oracle):
     """Work skipping: a read routed to a crown stream (k_route's theta bound)
     must be placed exactly as on the whole-tree stream and as by the oracle."""
     rng = np.random.default_rng(4)
-    routed = np.zeros(8, int)
+    routed = np.zeros(16, int)
     for _ in range(120):
         tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(1, 400)), genome=int(rng.choice([60, 200, 1000])),
                                    max_muts=int(rng.choice([2, 4])))

@@ -60,9 +60,9 @@ class MatStats(ctypes.Structure):
         ("stream_bytes", ctypes.c_uint64),
         ("device_bytes", ctypes.c_uint64),
         ("n_streams", ctypes.c_uint32),
-        ("stream_tau", ctypes.c_int32 * 8),
-        ("stream_nodes", ctypes.c_uint64 * 8),
-        ("stream_bytes_of", ctypes.c_uint64 * 8),
+        ("stream_tau", ctypes.c_int32 * 16),
+        ("stream_nodes", ctypes.c_uint64 * 16),
+        ("stream_bytes_of", ctypes.c_uint64 * 16),
     ]
 
 

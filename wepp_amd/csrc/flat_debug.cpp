@@ -1,4 +1,5 @@
 // flat_debug.cpp -- host-only view of the flattened MAT for the CPU tests.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,9 +42,9 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
         return WEPP_OK;                                                 \
     }
     size_t si = f.streams.size() - 1;
-    if (name[0] >= '0' && name[0] <= '9' && name[1] == ':') {
-        si = (size_t)(name[0] - '0');
-        name += 2;
+    if (name[0] >= '0' && name[0] <= '9' && std::strchr(name, ':')) {
+        si = (size_t)std::strtoul(name, nullptr, 10);
+        name = std::strchr(name, ':') + 1;
         if (si >= f.streams.size()) return wepp::set_error(WEPP_EINVAL, "stream index out of range");
     } else {
         FIELD(f, node_woff) FIELD(f, words) FIELD(f, rank2dfs) FIELD(f, dfs2bfs) FIELD(f, bfs2id) FIELD(f, dfs2id)

@@ -395,7 +395,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
     // base(n) > theta(read), so a read only needs the
     // crown {base <= theta} closed under ancestors.
     {
-        static const int32_t taus[] = {2, 4, 6, 9, 13, 19, 27};
+        static const int32_t taus[] = {2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 19, 23, 27};
         std::vector<uint8_t> keep(N);
         std::vector<uint32_t> sel;
         size_t prev = 0;
@@ -409,7 +409,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
             for (uint32_t d = 0; d < N; d++)
                 if (keep[d]) sel.push_back(d);
             if (sel.size() * 2 > N) break;                       // not worth a separate stream
-            if (prev && sel.size() < prev + prev / 2) continue;  // too close to the previous crown
+            if (prev && sel.size() < prev + prev / 4) continue;  // too close to the previous crown
             f.streams.emplace_back();
             f.streams.back().tau = tau;
             int rc = build_stream(f, sel, f.streams.back(), err);

@@ -103,7 +103,7 @@ struct FlatMAT {
     const Stream& full() const { return streams.back(); }
 };
 
-constexpr uint32_t MAX_STREAMS = 8;
+constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of wepp_mat_stats
 
 // Returns WEPP_OK or an error code; `err` receives the message.
 int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err);
