@@ -307,29 +307,68 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     }
     char* part_base = (char*)mat->ws + tier_bytes + list_bytes;
 
-    // ---- sweeps (timed as a group) + finalizes; the streams' launches are independent
-    // and run concurrently on side streams forked from / joined into `stream` ------
+    // ---- sweeps (timed as a group) + finalizes ------------------------------------------
+    // The plain (short-read) plans are fused into ONE launch, longest chunks first; dense
+    // and out-of-LDS plans get their own launch on a side stream forked from / joined into
+    // `stream`.  Every plan's finalize follows its sweep.
     const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
     HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
-    HIP_TRY(hipEventRecord(mat->fork_ev, stream));
     uint64_t passes = 0, bytes = 0;
+    auto parts = [&](const Plan& p, int32_t*& ps, uint32_t*& pr, uint32_t*& pc) {
+        ps = (int32_t*)(part_base + p.part_off);
+        pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
+        pc = pr + (size_t)p.nchunks * p.count;
+    };
+    uint32_t order[MAX_STREAMS], n_plain = 0, n_other = 0, others[MAX_STREAMS];
     for (uint32_t i = 0; i < np; i++) {
-        const Plan& p = plans[i];
-        hipStream_t q = (np > 1) ? mat->side[i] : stream;
-        if (np > 1) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
-        int32_t* ps = (int32_t*)(part_base + p.part_off);
-        uint32_t* pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
-        uint32_t* pc = pr + (size_t)p.nchunks * p.count;
+        if (plans[i].s_in_lds && !plans[i].dense) order[n_plain++] = i;
+        else others[n_other++] = i;
+        passes += plans[i].ntiles;                                   // every tile sweeps its stream once
+        bytes += (uint64_t)plans[i].ntiles * mat->stream_bytes[plans[i].t];
+    }
+    std::sort(order, order + n_plain, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
+    const bool fork = n_other > 0 && (n_plain > 0 || n_other > 1);
+    if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
+    for (uint32_t k = 0; k < n_other; k++) {
+        const Plan& p = plans[others[k]];
+        hipStream_t q = fork ? mat->side[k] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        int32_t* ps; uint32_t *pr, *pc;
+        parts(p, ps, pr, pc);
         HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, p.T, p.ntiles,
                              p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
-        passes += p.ntiles;                                   // every tile sweeps its stream once
-        bytes += (uint64_t)p.ntiles * mat->stream_bytes[p.t];
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
-        if (np > 1) {
-            HIP_TRY(hipEventRecord(mat->join_ev[i], q));
-            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[i], 0));
+        if (fork) {
+            HIP_TRY(hipEventRecord(mat->join_ev[k], q));
+            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[k], 0));
         }
+    }
+    if (n_plain) {
+        SweepPlans pl{};
+        uint32_t wg = 0, fin = 0, lds_max = 0;
+        for (uint32_t k = 0; k < n_plain; k++) {
+            const Plan& p = plans[order[k]];
+            SweepPlanDev& d = pl.p[k];
+            d.st = mat->streams[p.t];
+            d.list = list + p.off;
+            d.n_list = p.count;
+            d.T = p.T;
+            d.ntiles = p.ntiles;
+            d.bpc = p.bpc;
+            d.ent_cap = p.ent_cap;
+            d.nchunks = p.nchunks;
+            parts(p, d.part_score, d.part_rank, d.part_cnt);
+            wg += p.ntiles * p.nchunks;
+            d.wg_end = wg;
+            fin += (p.nchunks > 8) ? (p.count + 3) / 4 : (p.count + 255) / 256;   // wave / thread per read
+            d.fin_end = fin;
+            lds_max = std::max(lds_max, p.lds_bytes);
+        }
+        pl.n = n_plain;
+        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, lds_max, stream));
+        HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
+                                      stream));
     }
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
     mat->n_timed++;

@@ -46,6 +46,21 @@ struct DevMAT {
     const uint32_t* parent_dfs;   // DFS index of the parent (root: 0)
 };
 
+// the plain plans of one call, fused into one launch (k_sweep_multi)
+struct SweepPlanDev {
+    DevStream st;
+    const uint32_t* list;
+    uint32_t n_list, T, ntiles, bpc, ent_cap, nchunks;
+    uint32_t wg_end, fin_end;   // first sweep workgroup / finalize block after this plan
+    int32_t* part_score;
+    uint32_t* part_rank;
+    uint32_t* part_cnt;
+};
+struct SweepPlans {
+    uint32_t n;
+    SweepPlanDev p[MAX_STREAMS];
+};
+
 constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (grid-stride over the reads)
 constexpr uint32_t ROUTE_THREADS = 256;
 
@@ -74,6 +89,11 @@ inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t ke
 constexpr uint32_t MAX_TILE_ENTRIES = 8192;
 constexpr uint32_t DENSE_MAX_POS = (1u << 19) - 1;
 constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep the sorted position index
+hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
+                              const uint32_t* d_read_word, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_finalize_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
+                                 const uint32_t* d_read_word, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
+                                 uint32_t* flags, hipStream_t stream);
 hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,

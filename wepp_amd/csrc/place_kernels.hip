@@ -199,8 +199,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
 // longer than MAX_TILE_ENTRIES words).  DENSE: additionally keep a tile-sorted position
 // index in LDS and resolve blocks with many hit events with lane = event (long reads).
 template <bool S_IN_LDS, bool DENSE>
-__global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
-    DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
+__device__ __forceinline__ void sweep_tile(
+    const DevStream& m, uint32_t wg, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
     const uint32_t* __restrict__ read_off,
     const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
     const uint32_t wv = threadIdx.x >> 6;
     int* acc = reinterpret_cast<int*>(owner + ent_cap) + wv * 192;   // net[64], H[64], bound[64] of this wave
 
-    const uint32_t tile = blockIdx.x % ntiles;
-    const uint32_t chunk = (blockIdx.x / ntiles) * NW + wv;
+    const uint32_t tile = wg % ntiles;
+    const uint32_t chunk = (wg / ntiles) * NW + wv;
     const uint32_t r0 = tile * T;                   // first list slot of the tile
     const uint32_t nr = min(T, n_list - r0);
     const bool have = lane < nr;
@@ -568,13 +568,37 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
     }
 }
 
+// one stream per launch (dense variant, reads too long for LDS)
+template <bool S_IN_LDS, bool DENSE>
+__global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
+    DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
+    const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+    const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T, uint32_t ntiles, uint32_t blocks_per_chunk,
+    int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank, uint32_t* __restrict__ part_cnt) {
+    sweep_tile<S_IN_LDS, DENSE>(m, blockIdx.x, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, list, n_list, T,
+                                ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+}
+
+// all the plain (short-read) plans of one placement call in ONE launch: the workgroups of
+// the different streams run side by side instead of queueing behind the hardware queues
+__global__ __launch_bounds__(64) void k_sweep_multi(SweepPlans pl, uint32_t bm_words, uint32_t max_pos,
+                                                    const uint32_t* __restrict__ read_off,
+                                                    const uint32_t* __restrict__ read_word) {
+    uint32_t p = 0;
+    while (p + 1 < pl.n && blockIdx.x >= pl.p[p].wg_end) p++;
+    const SweepPlanDev& q = pl.p[p];
+    const uint32_t wg0 = p ? pl.p[p - 1].wg_end : 0;
+    sweep_tile<true, false>(q.st, blockIdx.x - wg0, bm_words, max_pos, q.ent_cap, 0u, read_off, read_word, q.list,
+                            q.n_list, q.T, q.ntiles, q.bpc, q.part_score, q.part_rank, q.part_cnt);
+}
+
 // -----------------------------------------------------------------------------
 // finalize: combine the chunks of a read, map the winner back to the
 // reference's BFS index and recompute its has_unique flag
 // (usher_mapper.cpp:184,199,262,472,492).
 // -----------------------------------------------------------------------------
 template <bool WAVE_PER_READ>
-__global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
+__device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, const uint32_t* __restrict__ read_off,
                            const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
                            uint32_t n_list, uint32_t nchunks, const int32_t* __restrict__ part_score,
                            const uint32_t* __restrict__ part_rank, const uint32_t* __restrict__ part_cnt,
@@ -583,7 +607,7 @@ __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
     // few chunks: one thread per list entry; many chunks (small batches): one wave
     // per entry, lanes stride over the chunks, then a wave reduction
     const uint32_t lane = WAVE_PER_READ ? (threadIdx.x & 63) : 0;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blk * blockDim.x + threadIdx.x;
     const uint32_t i = WAVE_PER_READ ? (gid >> 6) : gid;
     if (i >= n_list) return;
     const uint32_t r = list[i];
@@ -627,6 +651,34 @@ __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
     if (score) score[r] = bs;
     if (num_best) num_best[r] = cnt;
     if (flags) flags[r] = hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+}
+
+template <bool WAVE_PER_READ>
+__global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
+                           const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
+                           uint32_t n_list, uint32_t nchunks, const int32_t* __restrict__ part_score,
+                           const uint32_t* __restrict__ part_rank, const uint32_t* __restrict__ part_cnt,
+                           uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
+                           uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
+    finalize_reads<WAVE_PER_READ>(m, blockIdx.x, read_off, read_word, list, n_list, nchunks, part_score, part_rank,
+                                  part_cnt, best_bfs_j, score, num_best, flags);
+}
+
+// the finalizes of all fused plans in one launch (fin_end = first block after a plan)
+__global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __restrict__ read_off,
+                                 const uint32_t* __restrict__ read_word, uint32_t* __restrict__ best_bfs_j,
+                                 int32_t* __restrict__ score, uint32_t* __restrict__ num_best,
+                                 uint32_t* __restrict__ flags) {
+    uint32_t p = 0;
+    while (p + 1 < pl.n && blockIdx.x >= pl.p[p].fin_end) p++;
+    const SweepPlanDev& q = pl.p[p];
+    const uint32_t blk = blockIdx.x - (p ? pl.p[p - 1].fin_end : 0);
+    if (q.nchunks > 8)
+        finalize_reads<true>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank,
+                             q.part_cnt, best_bfs_j, score, num_best, flags);
+    else
+        finalize_reads<false>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank,
+                              q.part_cnt, best_bfs_j, score, num_best, flags);
 }
 
 // -----------------------------------------------------------------------------
@@ -805,6 +857,23 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
     return hipGetLastError();
 }
 
+hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
+                              const uint32_t* d_read_word, uint32_t lds_bytes, hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sweep_multi, dim3(pl.p[pl.n - 1].wg_end), dim3(64), lds_bytes, stream, pl, m.bm_words,
+                       m.max_pos, d_read_off, d_read_word);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
+                                 const uint32_t* d_read_word, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
+                                 uint32_t* flags, hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_multi, dim3(pl.p[pl.n - 1].fin_end), dim3(256), 0, stream, m, pl, d_read_off,
+                       d_read_word, best_bfs_j, score, num_best, flags);
+    return hipGetLastError();
+}
+
 hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
@@ -844,6 +913,8 @@ hipError_t sweep_set_max_lds(uint32_t bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)k_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_sweep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_sweep_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_sweep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
