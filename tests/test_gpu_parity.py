@@ -190,6 +190,33 @@ def test_big_tile_falls_back_to_global_read_words(oracle):
     mat.close()
 
 
+def test_mixed_batch_short_long_and_huge_reads(oracle):
+    """One batch that exercises every sweep variant at once: short reads (fused plain
+    plans on several crown streams), long reads (dense 8-wave variant) and a few reads too
+    long for LDS (words left in global memory)."""
+    g = w.generate_tree(81, 60000, genome_len=20000, p_ambiguous=0.003, root_mutations=1)
+    short = g.reads(82, 700, p_iupac=0.05)
+    long_ = g.reads(83, 150, read_len=1200, amplicon_len=1200, amplicon_step=1000, p_substitution=0.03, p_n=0.02)
+    huge = g.reads(84, 3, read_len=20000, amplicon_len=20000, amplicon_step=20000, p_substitution=0.5, p_n=0.3)
+    assert np.diff(huge.read_off).max() > 8192
+    lists = []
+    rng = np.random.default_rng(1)
+    for src in (short, long_, huge):
+        for q in range(src.n_reads):
+            p, rf, a, ms = src.entries(q)
+            lists.append([(int(p[i]), int(rf[i]), int(a[i]), int(ms[i])) for i in range(len(p))])
+    order = rng.permutation(len(lists))
+    reads = Reads.from_lists([lists[i] for i in order])
+    mat = w.Mat(g.tree)
+    res = mat.place_batch(reads)
+    assert_same(res, oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count()), "mixed")
+    mat.set_use_crowns(False)
+    off = mat.place_batch(reads)
+    assert (off.score == res.score).all() and (off.best_bfs_j == res.best_bfs_j).all()
+    assert (off.num_best == res.num_best).all() and (off.flags == res.flags).all()
+    mat.close()
+
+
 def test_rejects_unsorted_or_duplicate_read_positions():
     g = w.generate_tree(47, 1000)
     mat = w.Mat(g.tree)
