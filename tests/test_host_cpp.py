@@ -154,6 +154,14 @@ def test_wepp_usher_end_to_end(tmp_path, oracle):
         assert (rows[q][3] if len(rows[q]) > 3 else "") == want4, (q, rows[q], want4)
         assert f"Sample name: {snames[q]}\tParsimony score: {o['score']}\tNumber of parsimony-optimal placements: {o['num_best']}" in r.stderr
     assert n_imputed > 5
+    # -s: rows ordered by (score, number of optimal placements), stable (usher_common.cpp:276-283)
+    out3 = tmp_path / "o3"
+    out3.mkdir()
+    r3 = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-s", "-d", str(out3)], capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stderr
+    rows3 = [l.split("\t") for l in open(out3 / "placement_stats.tsv").read().splitlines()]
+    want3 = sorted(rows, key=lambda x: (int(x[1]), int(x[2])))
+    assert [x[:3] for x in rows3] == [x[:3] for x in want3]
     r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-p", "-d", str(out2)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     lines = open(out2 / "parsimony-scores.tsv").read().splitlines()

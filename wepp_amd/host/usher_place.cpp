@@ -17,10 +17,15 @@ struct FileCloser {
 int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t max_parsimony,
                         bool print_parsimony_scores, std::vector<Missing_Sample>& missing_samples,
                         std::vector<std::string>& low_confidence_samples, MAT::Tree* T,
-                        std::vector<usher_place_result>* results, int device) {
+                        std::vector<usher_place_result>* results, int device, bool sort_before_placement_1,
+                        bool sort_before_placement_2, bool sort_before_placement_3, bool reverse_sort) {
     if (!T || !T->root) {
         fprintf(stderr, "ERROR: empty tree!\n");
         return 1;
+    }
+    if (sort_before_placement_3) {                                   // usher_common.cpp:140-155
+        std::stable_sort(missing_samples.begin(), missing_samples.end());
+        if (reverse_sort) std::reverse(missing_samples.begin(), missing_samples.end());
     }
     // BFS order once (the reference re-expands per sample, :339); node id = BFS
     // index, so ascending id under a parent is the stored child order.
@@ -103,9 +108,24 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
         }
     }
     if (results) results->clear();
-    for (uint32_t q = 0; q < R; q++) {
+    // order in which the rows are written (usher_common.cpp:164-169, :276-295)
+    std::vector<uint32_t> indexes(R);
+    for (uint32_t q = 0; q < R; q++) indexes[q] = q;
+    if ((sort_before_placement_1 || sort_before_placement_2) && missing_samples.size() > 1) {
+        if (sort_before_placement_1)
+            std::stable_sort(indexes.begin(), indexes.end(), [&](uint32_t a, uint32_t b) {
+                return best_sd[a] < best_sd[b] || (best_sd[a] == best_sd[b] && num_best[a] < num_best[b]);
+            });
+        else
+            std::stable_sort(indexes.begin(), indexes.end(), [&](uint32_t a, uint32_t b) {
+                return num_best[a] < num_best[b] || (num_best[a] == num_best[b] && best_sd[a] < best_sd[b]);
+            });
+        if (reverse_sort) std::reverse(indexes.begin(), indexes.end());
+    }
+    for (uint32_t qi = 0; qi < R; qi++) {
+        const uint32_t q = indexes[qi];
         const std::string& sample = missing_samples[todo[q]].name;
-        if (print_parsimony_scores && !outdir.empty() && q == 0) {
+        if (print_parsimony_scores && !outdir.empty() && qi == 0) {
             std::string fn = outdir + "/parsimony-scores.tsv";                                 // :329-336
             fprintf(stderr, "\nNow computing branch parsimony scores for adding the missing samples at each of the %zu nodes in the existing tree without modifying the tree.\n", total_nodes);
             fprintf(stderr, "The branch parsimony scores will be written to file %s\n\n", fn.c_str());

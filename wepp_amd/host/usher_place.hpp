@@ -26,9 +26,15 @@ struct usher_place_result {       // what the reference keeps in locals per samp
 //   max_uncertainty / max_parsimony   thresholds of the warnings at :453-466
 //   print_parsimony_scores   the -p mode (:328-336, :403-409, :555-574)
 //   low_confidence_samples   receives the samples with >1 optimal placement (:453-456)
-//   results                  optional, one entry per sample
+//   results                  optional, one entry per placed sample, in output order
 //   device                   HIP device index
+//   sort_before_placement_1/2/3, reverse_sort   the sample orderings of usher_common.cpp:140-155
+//                            (3: by number of ambiguous bases, reorders missing_samples) and
+//                            :184-298 (1: by score then number of optimal placements, 2: the
+//                            other way round); with --no-add they only change the row order
 int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t max_parsimony,
                         bool print_parsimony_scores, std::vector<Missing_Sample>& missing_samples,
                         std::vector<std::string>& low_confidence_samples, MAT::Tree* T,
-                        std::vector<usher_place_result>* results = nullptr, int device = 0);
+                        std::vector<usher_place_result>* results = nullptr, int device = 0,
+                        bool sort_before_placement_1 = false, bool sort_before_placement_2 = false,
+                        bool sort_before_placement_3 = false, bool reverse_sort = false);

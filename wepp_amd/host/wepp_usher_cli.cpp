@@ -12,12 +12,12 @@
 
 static void usage() {
     fprintf(stderr, "usage: wepp-usher -i <mat.pb[.gz]> -v <samples.vcf[.gz]> [-d <outdir>] [-p] [-e max_uncertainty] "
-                    "[-E max_parsimony] [--device N] [--dump]\n");
+                    "[-E max_parsimony] [-s|-S|-A] [-r] [--device N] [--dump]\n");
 }
 
 int main(int argc, char** argv) {
     std::string pb, vcf, outdir = ".";
-    bool print_scores = false, dump = false;
+    bool print_scores = false, dump = false, sort1 = false, sort2 = false, sort3 = false, reverse_sort = false;
     uint32_t max_uncertainty = 1000000, max_parsimony = 1000000;   // usher.cpp:77-80 defaults
     int device = 0;
     for (int i = 1; i < argc; i++) {
@@ -30,6 +30,10 @@ int main(int argc, char** argv) {
         else if (a == "-e" || a == "--max-uncertainty-per-sample") max_uncertainty = (uint32_t)atoi(next());
         else if (a == "-E" || a == "--max-parsimony-per-sample") max_parsimony = (uint32_t)atoi(next());
         else if (a == "-n" || a == "--no-add") {}
+        else if (a == "-s" || a == "--sort-before-placement-1") sort1 = true;
+        else if (a == "-S" || a == "--sort-before-placement-2") sort2 = true;
+        else if (a == "-A" || a == "--sort-before-placement-3") sort3 = true;
+        else if (a == "-r" || a == "--reverse-sort") reverse_sort = true;
         else if (a == "--device") device = atoi(next());
         else if (a == "--dump") dump = true;
         else { usage(); return 1; }
@@ -55,8 +59,12 @@ int main(int argc, char** argv) {
             return 0;
         }
         std::vector<std::string> low_conf;
+        if (sort1 && sort2) {
+            fprintf(stderr, "ERROR: Can't use sort-before-placement-1 and sort-before-placement-2 simultaneously. Please specify only one.\n");
+            return 1;                                               // usher_common.cpp:14-71 style validation
+        }
         return usher_place_samples(outdir, max_uncertainty, max_parsimony, print_scores, missing_samples, low_conf, &T,
-                                   nullptr, device);
+                                   nullptr, device, sort1, sort2, sort3, reverse_sort);
     } catch (const std::exception& e) {
         fprintf(stderr, "%s\n", e.what());
         return 1;
