@@ -216,7 +216,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t T = mat->tile_reads;
     const uint32_t ns = mat->dev.n_streams;
 
-    // ---- workspace: [tier_of R bytes][list R][partials: sum over tiers of nchunks*count*12] ----
+    // ---- workspace: [tier_of R bytes][list R][root_score R][partials: sum over tiers of nchunks*count*12] ----
     // The partials are sized for the worst case once the per-tier counts are known.
     auto grow = [&](size_t need) -> int {
         if (need <= mat->ws_bytes) return WEPP_OK;
@@ -231,18 +231,19 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const size_t list_bytes = (((size_t)n_reads * 4) + 255) & ~(size_t)255;
     {
         // before routing only the first two regions are needed; reserve a typical partial size too
-        int rc = grow(tier_bytes + list_bytes + (size_t)n_reads * 12 * 2);
+        int rc = grow(tier_bytes + 2 * list_bytes + (size_t)n_reads * 12 * 2);
         if (rc != WEPP_OK) return rc;
     }
     uint8_t* tier_of = (uint8_t*)mat->ws;
     uint32_t* list = (uint32_t*)((char*)mat->ws + tier_bytes);
+    int32_t* root_score = (int32_t*)((char*)mat->ws + tier_bytes + list_bytes);
     uint32_t* tier_info = mat->d_info;
     uint32_t* blk_counts = mat->d_info + TI_WORDS;
 
     // ---- route the reads to streams ------------------------------------------------
     HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
-    HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, blk_counts, tier_info,
-                         stream));
+    HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score, blk_counts,
+                         tier_info, stream));
     HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
     HIP_TRY(hipMemcpyAsync(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -293,19 +294,20 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         part_total += (size_t)p.nchunks * count * 12;
     }
     {
-        int rc = grow(tier_bytes + list_bytes + part_total);
+        int rc = grow(tier_bytes + 2 * list_bytes + part_total);
         if (rc != WEPP_OK) return rc;
         tier_of = (uint8_t*)mat->ws;
         if ((uint32_t*)((char*)mat->ws + tier_bytes) != list) {
             // the workspace moved: redo the (cheap) routing into the new buffer
             list = (uint32_t*)((char*)mat->ws + tier_bytes);
+            root_score = (int32_t*)((char*)mat->ws + tier_bytes + list_bytes);
             HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
-            HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, blk_counts,
-                                 tier_info, stream));
+            HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score,
+                                 blk_counts, tier_info, stream));
             HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
         }
     }
-    char* part_base = (char*)mat->ws + tier_bytes + list_bytes;
+    char* part_base = (char*)mat->ws + tier_bytes + 2 * list_bytes;
 
     // ---- sweeps (timed as a group) + finalizes ------------------------------------------
     // The plain (short-read) plans are fused into ONE launch, longest chunks first; dense
@@ -335,7 +337,8 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
-        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, list + p.off, p.count, p.T, p.ntiles,
+        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, root_score, list + p.off, p.count, p.T,
+                             p.ntiles,
                              p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
@@ -366,7 +369,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             lds_max = std::max(lds_max, p.lds_bytes);
         }
         pl.n = n_plain;
-        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, lds_max, stream));
+        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, stream));
         HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
                                       stream));
     }

@@ -66,13 +66,14 @@ constexpr uint32_t ROUTE_THREADS = 256;
 
 // route: tier of every read + per-(block, tier) counts and per-tier max entries
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint8_t* tier_of, uint32_t* blk_counts, uint32_t* tier_info,
-                        hipStream_t stream);
+                        int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
+                        uint32_t* tier_info, hipStream_t stream);
 // scatter: read indices grouped by tier into `list` (tier t occupies [tier_off[t], tier_off[t+1]))
 hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32_t* blk_counts, uint32_t* tier_info,
                           uint32_t* list, hipStream_t stream);
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
-                        const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
+                        const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list,
+                        uint32_t n_list, uint32_t T,
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
                         uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
                         uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream);
@@ -90,7 +91,8 @@ constexpr uint32_t MAX_TILE_ENTRIES = 8192;
 constexpr uint32_t DENSE_MAX_POS = (1u << 19) - 1;
 constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep the sorted position index
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
-                              const uint32_t* d_read_word, uint32_t lds_bytes, hipStream_t stream);
+                              const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
+                              hipStream_t stream);
 hipError_t launch_finalize_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                                  const uint32_t* d_read_word, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
                                  uint32_t* flags, hipStream_t stream);

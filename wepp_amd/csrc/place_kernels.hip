@@ -121,6 +121,7 @@ __device__ __forceinline__ uint32_t find_entry(SPtr S, uint32_t off, uint32_t k,
 __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_t* __restrict__ read_off,
                                                           const uint32_t* __restrict__ read_word, uint32_t n_reads,
                                                           int use_crowns, uint8_t* __restrict__ tier_of,
+                                                          int32_t* __restrict__ root_score,
                                                           uint32_t* __restrict__ blk_counts,
                                                           uint32_t* __restrict__ tier_info) {
     __shared__ uint32_t cnt[MAX_STREAMS], mx[MAX_STREAMS];
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             const uint32_t sw = find_entry(read_word, so, k, w_pos(tw));
             if (sw != NONE) c += enter_delta(tw, sw);
         }
+        root_score[r] = m.root_base + c;       // the root always competes: an upper bound of the best score
         const int theta = m.root_base + c + (int)k;
         uint32_t t = m.n_streams - 1;
         if (use_crowns)
@@ -202,7 +204,8 @@ template <bool S_IN_LDS, bool DENSE>
 __device__ __forceinline__ void sweep_tile(
     const DevStream& m, uint32_t wg, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
     const uint32_t* __restrict__ read_off,
-    const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
+    const uint32_t* __restrict__ read_word, const int32_t* __restrict__ root_score,
+    const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
     // A workgroup = one tile of reads.  Plain variant: one wave, one chunk of the stream.
@@ -315,7 +318,10 @@ __device__ __forceinline__ void sweep_tile(
         }
     }
 
-    int bs = 0x7FFFFFFF;        // best score of this lane's read
+    // best score of this lane's read.  It starts one above the root's score: the root always
+    // competes, so nothing worse can win or tie -- every chunk prunes against that bound from
+    // its first block on (a chunk that finds nothing reports count 0 and loses in k_finalize)
+    int bs = have ? root_score[rd] + 1 : 0x7FFFFFFF;
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
 
@@ -573,22 +579,25 @@ template <bool S_IN_LDS, bool DENSE>
 __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
     DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
     const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
-    const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T, uint32_t ntiles, uint32_t blocks_per_chunk,
-    int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank, uint32_t* __restrict__ part_cnt) {
-    sweep_tile<S_IN_LDS, DENSE>(m, blockIdx.x, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, list, n_list, T,
-                                ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+    const int32_t* __restrict__ root_score, const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
+    uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
+    uint32_t* __restrict__ part_cnt) {
+    sweep_tile<S_IN_LDS, DENSE>(m, blockIdx.x, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, root_score,
+                                list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
 }
 
 // all the plain (short-read) plans of one placement call in ONE launch: the workgroups of
 // the different streams run side by side instead of queueing behind the hardware queues
 __global__ __launch_bounds__(64) void k_sweep_multi(SweepPlans pl, uint32_t bm_words, uint32_t max_pos,
                                                     const uint32_t* __restrict__ read_off,
-                                                    const uint32_t* __restrict__ read_word) {
+                                                    const uint32_t* __restrict__ read_word,
+                                                    const int32_t* __restrict__ root_score) {
     uint32_t p = 0;
     while (p + 1 < pl.n && blockIdx.x >= pl.p[p].wg_end) p++;
     const SweepPlanDev& q = pl.p[p];
     const uint32_t wg0 = p ? pl.p[p - 1].wg_end : 0;
-    sweep_tile<true, false>(q.st, blockIdx.x - wg0, bm_words, max_pos, q.ent_cap, 0u, read_off, read_word, q.list,
+    sweep_tile<true, false>(q.st, blockIdx.x - wg0, bm_words, max_pos, q.ent_cap, 0u, read_off, read_word, root_score,
+                            q.list,
                             q.n_list, q.T, q.ntiles, q.bpc, q.part_score, q.part_rank, q.part_cnt);
 }
 
@@ -616,6 +625,7 @@ __device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, co
     for (uint32_t ch = lane; ch < nchunks; ch += (WAVE_PER_READ ? 64 : 1)) {
         const size_t o = (size_t)ch * n_list + i;
         const int s = part_score[o];
+        if (part_cnt[o] == 0) continue;                      // this chunk found nothing within the bound
         if (s < bs) { bs = s; br = part_rank[o]; cnt = part_cnt[o]; }
         else if (s == bs) { cnt += part_cnt[o]; br = min(br, part_rank[o]); }
     }
@@ -824,10 +834,10 @@ __global__ void k_imputed(DevMAT m, const uint32_t* __restrict__ read_off, const
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint8_t* tier_of, uint32_t* blk_counts, uint32_t* tier_info,
-                        hipStream_t stream) {
+                        int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
+                        uint32_t* tier_info, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
-                       n_reads, use_crowns, tier_of, blk_counts, tier_info);
+                       n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info);
     return hipGetLastError();
 }
 
@@ -839,7 +849,8 @@ hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32
 }
 
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
-                        const uint32_t* d_read_word, const uint32_t* list, uint32_t n_list, uint32_t T,
+                        const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list,
+                        uint32_t n_list, uint32_t T,
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
                         uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
                         uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream) {
@@ -848,8 +859,8 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
     const dim3 block(dense ? 64 * DENSE_WAVES_PER_WG : 64);
 #define WEPP_SWEEP(A, B, CAP, KCAP)                                                                                   \
     hipLaunchKernelGGL((k_sweep<A, B>), grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, CAP, KCAP,          \
-                       d_read_off, d_read_word, list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank,      \
-                       part_cnt)
+                       d_read_off, d_read_word, root_score, list, n_list, T, ntiles, blocks_per_chunk, part_score,    \
+                       part_rank, part_cnt)
     if (s_in_lds && dense) WEPP_SWEEP(true, true, ent_cap, key_cap);
     else if (s_in_lds) WEPP_SWEEP(true, false, ent_cap, 0u);
     else WEPP_SWEEP(false, false, 0u, 0u);
@@ -858,10 +869,11 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
 }
 
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
-                              const uint32_t* d_read_word, uint32_t lds_bytes, hipStream_t stream) {
+                              const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
+                              hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_sweep_multi, dim3(pl.p[pl.n - 1].wg_end), dim3(64), lds_bytes, stream, pl, m.bm_words,
-                       m.max_pos, d_read_off, d_read_word);
+                       m.max_pos, d_read_off, d_read_word, root_score);
     return hipGetLastError();
 }
 
