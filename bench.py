@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     # workload knobs (defaults = BASELINE.json configs[2], the config the metric is quoted on)
     ap.add_argument("--nodes", type=int, default=16_000_000)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")

@@ -40,7 +40,7 @@ def main(src, name, mode):
         agg = collections.defaultdict(float)
         n = collections.defaultdict(int)
         for row in csv.DictReader(open(fs[0])):
-            if "k_sweep" in row["Kernel_Name"]:
+            if "k_sweep" in row["Kernel_Name"]:  # k_sweep, k_sweep_multi
                 agg[row["Counter_Name"]] += float(row["Counter_Value"])
                 n[row["Counter_Name"]] += 1
         for k in agg:
