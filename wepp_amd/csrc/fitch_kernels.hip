@@ -84,17 +84,28 @@ __global__ __launch_bounds__(64) void k_fitch_forward(FitchTree t, FitchSites s,
             const bool leaf = mt >> 31;
             const uint32_t d = d0 + i;
             while (sp > dep) close_top();
-            if (sp > 0) stack[(size_t)(sp - 1) * 64 + lane] = cur;      // park the parent
-            // open node d (:26-63)
+            // scores of node d before its children (:26-63)
+            I4 nd;
 #pragma unroll
-            for (int j = 0; j < 4; j++) cur.a[j] = (leaf && (uint32_t)j != ref) ? big : 0;
+            for (int j = 0; j < 4; j++) nd.a[j] = (leaf && (uint32_t)j != ref) ? big : 0;
             if (vnext == d) {
                 const uint32_t nuc = s.var_nuc[vp];
 #pragma unroll
-                for (int j = 0; j < 4; j++) cur.a[j] = ((nuc >> j) & 1u) ? 0 : big;
+                for (int j = 0; j < 4; j++) nd.a[j] = ((nuc >> j) & 1u) ? 0 : big;
                 vp++;
                 vnext = vp < vend ? s.var_dfs[vp] : 0xFFFFFFFFu;
             }
+            if (leaf && dep > 0) {
+                // a leaf is final at once: table out, contribution straight into the parent's
+                // accumulator, which stays in registers (no stack traffic for ~half of the nodes)
+                tbl[(size_t)d * 64 + lane] = (uint8_t)decision_table(nd);
+                const int mn = min(min(nd.a[0], nd.a[1]), min(nd.a[2], nd.a[3]));
+#pragma unroll
+                for (int j = 0; j < 4; j++) cur.a[j] += min(min(nd.a[j], mn + 1), big + 1);
+                continue;
+            }
+            if (sp > 0) stack[(size_t)(sp - 1) * 64 + lane] = cur;      // park the parent
+            cur = nd;
             if (lane == 0) open_ids[sp] = d;
             open_node = d;
             sp = dep + 1;
