@@ -45,7 +45,12 @@ def test_oracle_mapper_body_hand_cases(oracle):
 
 
 @pytest.mark.gpu
-def test_fitch_kernels_vs_oracle(oracle):
+@pytest.mark.parametrize("chunks", [None, 2, 5, 17])
+def test_fitch_kernels_vs_oracle(oracle, chunks, monkeypatch):
+    """chunks: how many waves share one walk of the tree (None = the library's choice, 1 for
+    trees this small); nodes spanning chunk boundaries go through the stitch kernel."""
+    if chunks:
+        monkeypatch.setenv("WEPP_FITCH_CHUNKS", str(chunks))
     rng = np.random.default_rng(2024)
     total = 0
     for it in range(30):

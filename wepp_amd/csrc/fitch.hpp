@@ -7,7 +7,12 @@ namespace wepp {
 
 struct FitchTree {
     uint32_t N, max_depth;
-    const uint32_t* meta;       // [N] DFS pre-order: depth | leaf << 31
+    uint32_t C;                     // chunks of consecutive DFS nodes, one wave each
+    const uint32_t* meta;           // [N] DFS pre-order: depth | leaf << 31
+    const uint32_t* chunk_start;    // [C + 1]
+    const uint32_t* chunk_depth;    // [C + 1] nodes open when chunk c starts (c = C: after the last node)
+    const uint32_t* chunk_min;      // [C] smallest depth of a node of the chunk
+    const uint32_t* chunk_open;     // [(C + 1) * (max_depth + 1)] the open node of every level at a chunk start
 };
 
 struct FitchSites {
@@ -20,8 +25,10 @@ struct FitchSites {
 
 constexpr uint32_t FITCH_MAX_DEPTH = 140;   // (depth + 1) KiB of LDS per wave
 
+// forward = chunk-parallel pass + stitch of the nodes that span chunk boundaries;
+// inh_part / out_part: [nbatches][C][max_depth + 1][64] int4 scratch each
 hipError_t launch_fitch_forward(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
-                                uint8_t* tables, hipStream_t stream);
+                                uint8_t* tables, int4* inh_part, int4* out_part, hipStream_t stream);
 hipError_t launch_fitch_backward(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
                                  const uint8_t* tables, unsigned long long* out_count, uint64_t capacity, uint2* out,
                                  hipStream_t stream);

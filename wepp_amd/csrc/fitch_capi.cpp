@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -54,14 +55,36 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (f.max_depth > FITCH_MAX_DEPTH)
         return set_error(WEPP_ELIMIT, "tree depth " + std::to_string(f.max_depth) + " exceeds the LDS stack (" +
                                           std::to_string(FITCH_MAX_DEPTH) + ")");
-    std::vector<uint32_t> meta(N), id2dfs(N);
-    {
-        std::vector<uint32_t> depth(N, 0);
-        for (uint32_t d = 0; d < N; d++) {
-            if (d) depth[d] = depth[f.parent_dfs[d]] + 1;
-            meta[d] = depth[d] | ((f.nstat[d] & NS_LEAF) ? 0x80000000u : 0u);
-            id2dfs[f.dfs2id[d]] = d;
+    std::vector<uint32_t> meta(N), id2dfs(N), depth(N, 0);
+    for (uint32_t d = 0; d < N; d++) {
+        if (d) depth[d] = depth[f.parent_dfs[d]] + 1;
+        meta[d] = depth[d] | ((f.nstat[d] & NS_LEAF) ? 0x80000000u : 0u);
+        id2dfs[f.dfs2id[d]] = d;
+    }
+    // chunks of consecutive DFS nodes (one wave each) and what is open at their boundaries
+    const uint32_t D = f.max_depth + 1;
+    uint32_t C = std::max<uint32_t>(1, std::min<uint32_t>(256, N / 2048));
+    if (const char* env = std::getenv("WEPP_FITCH_CHUNKS"))      // test hook: force the number of chunks
+        C = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::atoi(env), N));
+    std::vector<uint32_t> chunk_start(C + 1), chunk_depth(C + 1), chunk_min(C), chunk_open((size_t)(C + 1) * D, 0);
+    for (uint32_t c = 0; c <= C; c++) chunk_start[c] = (uint32_t)((uint64_t)N * c / C);
+    for (uint32_t c = 0; c <= C; c++) {
+        // nodes open before node a (c < C): its strict ancestors; after the last node: the
+        // strict ancestors of that leaf (the single node itself when the tree is one node)
+        uint32_t x;
+        if (c < C) { x = chunk_start[c]; chunk_depth[c] = depth[x]; }
+        else if (N == 1) { chunk_depth[c] = 1; chunk_open[(size_t)c * D] = 0; continue; }
+        else { x = N - 1; chunk_depth[c] = depth[x]; }
+        uint32_t anc = x;
+        for (uint32_t k = chunk_depth[c]; k-- > 0;) {
+            anc = f.parent_dfs[anc];
+            chunk_open[(size_t)c * D + k] = anc;
         }
+    }
+    for (uint32_t c = 0; c < C; c++) {
+        uint32_t mn = 0xFFFFFFFFu;
+        for (uint32_t d = chunk_start[c]; d < chunk_start[c + 1]; d++) mn = std::min(mn, depth[d]);
+        chunk_min[c] = mn;
     }
     // rows: reference base index, tree samples sorted by DFS index
     const uint64_t nv = var_off[n_sites];
@@ -100,16 +123,21 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hipf(e, "hipSetDevice");
 
-    DevBuf d_meta, d_ref, d_voff, d_vdfs, d_vnuc, d_tables, d_count, d_out;
+    DevBuf d_meta, d_ref, d_voff, d_vdfs, d_vnuc, d_tables, d_count, d_out, d_cs, d_cd, d_cm, d_co, d_inh, d_outp;
     const uint32_t nbatches = (n_sites + 63) / 64;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const size_t per_batch = (size_t)N * 64;
+    // per batch of 64 rows: the decision tables and the two partial-sum scratch arrays
+    const size_t part_bytes = (size_t)C * D * 64 * 16;
+    const size_t per_batch = (size_t)N * 64 + 2 * part_bytes;
     const size_t budget = free_b / 2;
     const uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nbatches, budget / std::max<size_t>(per_batch, 1)));
     if ((e = d_meta.alloc((size_t)N * 4)) != hipSuccess || (e = d_ref.alloc(n_sites)) != hipSuccess ||
         (e = d_voff.alloc((size_t)(n_sites + 1) * 4)) != hipSuccess || (e = d_vdfs.alloc(nv * 4)) != hipSuccess ||
-        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_tables.alloc(per_batch * group)) != hipSuccess ||
+        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_tables.alloc((size_t)N * 64 * group)) != hipSuccess ||
+        (e = d_inh.alloc(part_bytes * group)) != hipSuccess || (e = d_outp.alloc(part_bytes * group)) != hipSuccess ||
+        (e = d_cs.alloc((C + 1) * 4)) != hipSuccess || (e = d_cd.alloc((C + 1) * 4)) != hipSuccess ||
+        (e = d_cm.alloc(C * 4)) != hipSuccess || (e = d_co.alloc(chunk_open.size() * 4)) != hipSuccess ||
         (e = d_count.alloc(8)) != hipSuccess || (e = d_out.alloc(std::max<uint64_t>(capacity, 1) * 8)) != hipSuccess)
         return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     e = hipMemcpy(d_meta.p, meta.data(), (size_t)N * 4, hipMemcpyHostToDevice);
@@ -117,13 +145,18 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (e == hipSuccess) e = hipMemcpy(d_voff.p, var_off, (size_t)(n_sites + 1) * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && nv) e = hipMemcpy(d_vdfs.p, vdfs.data(), nv * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && nv) e = hipMemcpy(d_vnuc.p, vnuc.data(), nv, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cs.p, chunk_start.data(), (C + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cd.p, chunk_depth.data(), (C + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cm.p, chunk_min.data(), C * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_co.p, chunk_open.data(), chunk_open.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_count.p, 0, 8);
     if (e != hipSuccess) return hipf(e, "upload");
-    FitchTree ft{N, f.max_depth, d_meta.as<uint32_t>()};
+    FitchTree ft{N, f.max_depth, C, d_meta.as<uint32_t>(), d_cs.as<uint32_t>(), d_cd.as<uint32_t>(),
+                 d_cm.as<uint32_t>(), d_co.as<uint32_t>()};
     FitchSites fs{n_sites, d_ref.as<uint8_t>(), d_voff.as<uint32_t>(), d_vdfs.as<uint32_t>(), d_vnuc.as<uint8_t>()};
     for (uint32_t b0 = 0; b0 < nbatches; b0 += group) {
         const uint32_t nb = std::min(group, nbatches - b0);
-        e = launch_fitch_forward(ft, fs, b0, nb, d_tables.as<uint8_t>(), nullptr);
+        e = launch_fitch_forward(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_inh.as<int4>(), d_outp.as<int4>(), nullptr);
         if (e == hipSuccess)
             e = launch_fitch_backward(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_count.as<unsigned long long>(), capacity,
                                       d_out.as<uint2>(), nullptr);
