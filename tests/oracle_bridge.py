@@ -9,15 +9,16 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "oracle", "mapper2_oracle.c")
+SRCS = [os.path.join(ROOT, "oracle", f) for f in ("mapper2_oracle.c", "epp_oracle.c")]
+DEPS = SRCS + [os.path.join(ROOT, "oracle", "oracle_tree.h")]
 OUT_DIR = os.path.join(ROOT, "oracle", "_build")
 OUT = os.path.join(OUT_DIR, "liboracle.so")
 
 
 def build(force=False):
-    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < os.path.getmtime(SRC):
+    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(f) for f in DEPS):
         os.makedirs(OUT_DIR, exist_ok=True)
-        subprocess.check_call(["gcc", "-O3", "-DNDEBUG", "-shared", "-fPIC", "-o", OUT, SRC, "-lpthread"])
+        subprocess.check_call(["gcc", "-O3", "-DNDEBUG", "-shared", "-fPIC", "-o", OUT] + SRCS + ["-lpthread"])
     return OUT
 
 
@@ -48,6 +49,10 @@ def lib():
             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_mapper_body.argtypes = [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_int] + [ctypes.c_void_p] * 5
         L.oracle_place_batch_nodepar.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
+        L.oracle_epp_map.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32] + [ctypes.c_void_p] * 12 + [
+            ctypes.c_uint64] + [ctypes.c_void_p] * 3
+        L.oracle_epp_distance.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [
+            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         for f in ("oracle_tree_bfs_ids", "oracle_tree_dfs_ids", "oracle_tree_num_leaves"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
@@ -153,6 +158,41 @@ class OracleTree:
         arr = np.frombuffer(res, dtype=np.dtype([("score", "<i4"), ("num_best", "<u4"), ("best_j", "<u4"),
                                                  ("best_node_id", "<i4"), ("has_unique", "<u4")]), count=R).copy()
         return arr
+
+    def epp_map(self, reads, genome_size, node_mapped=None):
+        """wepp_filter::cartesian_map (src/WEPP/initial_filter.cpp:140-239) for a wepp_amd.EppReads
+        batch.  Haplotype indices are pre-order (arena) indices."""
+        from wepp_amd import unpack_read_word
+        R = reads.n_reads
+        pos, ref, mut, _ = unpack_read_word(reads.read_word)
+        if pos.size == 0:
+            pos = np.zeros(1, np.int32); ref = np.zeros(1, np.uint8); mut = np.zeros(1, np.uint8)
+        pos = np.ascontiguousarray(pos); ref = np.ascontiguousarray(ref); mut = np.ascontiguousarray(mut)
+        mp = np.zeros(max(R, 1), np.int32); mult = np.zeros(max(R, 1), np.uint32)
+        eoff = np.zeros(R + 1, np.uint64)
+        cap = 2048 * max(R, 1)
+        enodes = np.zeros(cap, np.uint32)
+        score = np.zeros(self.n, np.float64); counts = np.zeros((self.n, 50), np.int32)
+        div = np.zeros(self.n, np.float64)
+        nm = None if node_mapped is None else np.ascontiguousarray(node_mapped, np.uint8)
+        rc = lib().oracle_epp_map(self._h, int(genome_size), R, _p(reads.read_off), _p(pos), _p(ref), _p(mut),
+                                  _p(reads.start), _p(reads.end), _p(reads.degree), _p(nm) if nm is not None else None,
+                                  _p(mp), _p(mult), _p(eoff), _p(enodes), cap, _p(score), _p(counts), _p(div))
+        if rc != 0:
+            raise ValueError("oracle_epp_map failed: %d" % rc)
+        return dict(max_parsimony=mp[:R], multiplicity=mult[:R], epp_off=eoff, epp_nodes=enodes[: int(eoff[R])],
+                    score=score, counts=counts, divergence=div)
+
+    def epp_distance(self, pos, ref, mut, start, end):
+        """haplotype::mutation_distance(read) (src/WEPP/haplotype.hpp:123-173) for every haplotype."""
+        pos = np.ascontiguousarray(pos, np.int32); ref = np.ascontiguousarray(ref, np.uint8)
+        mut = np.ascontiguousarray(mut, np.uint8)
+        n = len(pos)
+        z32 = np.zeros(1, np.int32); z8 = np.zeros(1, np.uint8)
+        out = np.zeros(self.n, np.int32)
+        lib().oracle_epp_distance(self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8),
+                                  int(start), int(end), _p(out))
+        return out
 
     def close(self):
         if self._h:

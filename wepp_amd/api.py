@@ -118,6 +118,24 @@ class Reads:
         return unpack_read_word(self.read_word[a:b])
 
 
+class EppReads(Reads):
+    """WEPP's raw_read batch (src/WEPP/read.hpp:8-14): the CSR of mutations plus, per read,
+    the 1-based inclusive genome window [start, end] and the multiplicity `degree`."""
+
+    def __init__(self, read_off, read_word, start, end, degree):
+        super().__init__(read_off, read_word)
+        self.start = np.ascontiguousarray(start, dtype=np.int32)
+        self.end = np.ascontiguousarray(end, dtype=np.int32)
+        self.degree = np.ascontiguousarray(degree, dtype=np.int32)
+        if not (self.start.shape[0] == self.end.shape[0] == self.degree.shape[0] == self.n_reads):
+            raise ValueError("start / end / degree must have one entry per read")
+
+    @classmethod
+    def from_lists(cls, reads, start, end, degree=None):
+        base = Reads.from_lists(reads)
+        return cls(base.read_off, base.read_word, start, end, np.ones(len(reads), np.int32) if degree is None else degree)
+
+
 def generate_tree(seed, n_nodes, genome_len=29903, p_recent_parent=0.25, zipf_s=0.6, p_back_mutation=0.02,
                   p_ambiguous=0.0, p_masked_node=0.0, root_mutations=0):
     """Deterministic synthetic MAT (wepp_gen_tree_create); returns (Tree, handle)."""
