@@ -211,6 +211,9 @@ int wepp_gen_reads_create(const wepp_gen_tree_t *t, const wepp_gen_reads_params 
 /* borrowed pointers: read_off[n_reads+1], read_word[read_off[n_reads]] */
 int wepp_gen_reads_get(const wepp_gen_reads_t *r, uint32_t *n_reads, const uint32_t **read_off,
                        const uint32_t **read_word);
+/* borrowed pointers: the 1-based inclusive genome window [start, end] every read covers
+ * (raw_read::start / end for wepp_epp_map) */
+int wepp_gen_reads_windows(const wepp_gen_reads_t *r, const int32_t **start, const int32_t **end);
 int wepp_gen_reads_destroy(wepp_gen_reads_t *r);
 
 /* ---- per-site Fitch-Sankoff: building a MAT from a tree and a VCF ---------- *
@@ -229,6 +232,63 @@ int wepp_fitch_sites(const wepp_tree_desc *tree, int device, uint32_t n_sites, c
                      const uint32_t *var_off, const uint32_t *var_node, const uint8_t *var_nuc,
                      uint64_t capacity, uint64_t *n_out, uint32_t *out_site, uint32_t *out_node,
                      uint8_t *out_par, uint8_t *out_mut);
+
+/* ---- WEPP's own read placement: EPP sets and haplotype scores -------------- *
+ * Replaces wepp_filter::cartesian_map (src/WEPP/initial_filter.cpp:140-239) with
+ * single_read_tree (:41-136), the range trees it walks (src/WEPP/arena.cpp:68-169)
+ * and the per-read distance haplotype::mutation_distance (src/WEPP/haplotype.hpp:
+ * 123-173).  `mat` is created from the CONDENSED tree (create_condensed_tree,
+ * src/WEPP/util.cpp:79-133): one node per haplotype; haplotypes are addressed by
+ * their arena index = pre-order index (arena::from_mat, arena.cpp:3-55), which
+ * wepp_mat_dfs_order maps to caller node ids.
+ * A read is a raw_read (src/WEPP/read.hpp:8-14): genome window [start, end]
+ * (1-based, inclusive), multiplicity `degree`, and one packed word
+ * (wepp_pack_read_word, mut_nuc 15 = N) per position where it differs from the
+ * reference, sorted by position.
+ * Outputs (all host buffers):
+ *   max_parsimony[R]   wepp_filter::max_parismony: smallest windowed distance (:203)
+ *   multiplicity[R]    parsimony_multiplicity: number of haplotypes attaining it (:204)
+ *   epp_off/epp_nodes  epp_positions_cache: ascending arena indices of those
+ *                      haplotypes for every read with multiplicity <= max_cached_epp
+ *                      (MAX_CACHED_EPP_SIZE = 2048, config.hpp:9), CSR over the reads;
+ *                      both may be NULL
+ *   hap_score[N]       haplotype::score = sum over reads of
+ *                      degree / ((1 + parsimony) * multiplicity) (initial_filter.hpp:54-57);
+ *                      accumulated in 64-bit fixed point: run-to-run identical, exact zeros,
+ *                      absolute error <= (reads mapped to the haplotype) * 2^-(42 - log2(sum of degrees))
+ *   hap_read_counts[N*50]  haplotype::mapped_read_counts (bin = min(start / (genome_size / 50), 49)); may be NULL
+ *   hap_divergence[N]  haplotype::dist_divergence (:224-233); may be NULL
+ * The final sort of the haplotypes by score (:236) is left to the caller.
+ * Preconditions (WEPP_EINVAL otherwise): listed alleles differ from the reference base,
+ * positions sorted and unique, 1 <= start <= end, genome_size >= 50. */
+#define WEPP_NUM_RANGE_BINS 50
+#define WEPP_MAX_CACHED_EPP_SIZE 2048
+typedef struct {
+    uint32_t n_reads;
+    const uint32_t *read_off;   /* [n_reads + 1] */
+    const uint32_t *read_word;  /* [read_off[n_reads]] */
+    const int32_t *start;       /* [n_reads] raw_read::start */
+    const int32_t *end;         /* [n_reads] raw_read::end   */
+    const int32_t *degree;      /* [n_reads] raw_read::degree */
+} wepp_epp_reads;
+typedef struct {
+    int32_t *max_parsimony;
+    uint32_t *multiplicity;
+    uint64_t *epp_off;          /* [n_reads + 1] or NULL */
+    uint32_t *epp_nodes;        /* [epp_capacity] or NULL */
+    uint64_t epp_capacity;
+    double *hap_score;
+    int32_t *hap_read_counts;   /* node-major [N][50] or NULL */
+    double *hap_divergence;     /* or NULL */
+} wepp_epp_out;
+int wepp_epp_map(wepp_mat_t *mat, const wepp_epp_reads *reads, uint32_t genome_size, uint32_t max_cached_epp,
+                 wepp_epp_out *out);
+/* caller node id of the haplotype with arena (pre-order) index k, for k = 0 .. n_nodes-1 */
+int wepp_mat_dfs_order(const wepp_mat_t *mat, uint32_t *ids);
+/* device time of the calling thread's last wepp_epp_map, by phase (HIP events), and its work:
+ * events_swept = sum over tiles of the window-stream events one tile walks per pass */
+int wepp_epp_last_timing(double *select_ms, double *sweep1_ms, double *sweep2_ms, double *finish_ms,
+                         uint64_t *events_swept, uint64_t *stream_events, uint32_t *groups, uint32_t *jobs);
 
 /* ---- host-side introspection of the flattened MAT (no GPU needed) -------- *
  * Lets the CPU test-suite check the flattener (orders, parent alleles, per-node

@@ -65,3 +65,28 @@ def test_single_read_tree_equals_mutation_distance(oracle):
             assert got.tolist() == epp.tolist(), (it, r)
             checked += 1
     assert checked > 500
+
+
+def test_flat_event_stream_model_equals_oracle(oracle):
+    """The flattener's EPP event stream + the closed form the kernels use, run as a Python model,
+    reproduce the oracle on random trees (back-mutations, ambiguous alleles, masked mutations)."""
+    import epp_model
+    import wepp_amd as w
+    rng = np.random.default_rng(4242)
+    for it in range(40):
+        genome = 60
+        tree, ref = ft.random_tree(rng, genome=genome)
+        reads = epp_fuzz.random_epp_reads(rng, tree, ref, genome, n_reads=int(rng.integers(1, 25)))
+        fv = w.FlatView(tree)
+        ew, en = fv.get("epp_word"), fv.get("epp_node")
+        assert len(ew) == len(en) and (np.diff(en.astype(np.int64)) >= 0).all()
+        got = epp_model.epp_map(ew, en, tree.n_nodes, reads, genome)
+        want = oracle.OracleTree(tree).epp_map(reads, genome_size=genome)
+        assert (got["max_parsimony"] == want["max_parsimony"]).all(), it
+        assert (got["multiplicity"] == want["multiplicity"]).all(), it
+        for r in range(reads.n_reads):
+            wl = want["epp_nodes"][int(want["epp_off"][r]):int(want["epp_off"][r + 1])]
+            assert got["lists"][r].tolist() == wl.tolist(), (it, r)
+        assert np.allclose(got["score"], want["score"], rtol=1e-12, atol=1e-15)
+        assert (got["counts"] == want["counts"]).all()
+        fv.close()

@@ -93,6 +93,17 @@ class GenReadsParams(ctypes.Structure):
     ]
 
 
+class EppReadsC(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint32), ("read_off", ctypes.c_void_p), ("read_word", ctypes.c_void_p),
+                ("start", ctypes.c_void_p), ("end", ctypes.c_void_p), ("degree", ctypes.c_void_p)]
+
+
+class EppOutC(ctypes.Structure):
+    _fields_ = [("max_parsimony", ctypes.c_void_p), ("multiplicity", ctypes.c_void_p), ("epp_off", ctypes.c_void_p),
+                ("epp_nodes", ctypes.c_void_p), ("epp_capacity", ctypes.c_uint64), ("hap_score", ctypes.c_void_p),
+                ("hap_read_counts", ctypes.c_void_p), ("hap_divergence", ctypes.c_void_p)]
+
+
 # every symbol include/wepp_place.h declares (tests/test_abi.py checks the list
 # against the header)
 _V = ctypes.c_void_p
@@ -117,6 +128,12 @@ _SIGS = {
     ),
     "wepp_fitch_sites": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.c_int, ctypes.c_uint32, _V, _V, _V, _V,
                                         ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), _V, _V, _V, _V]),
+    "wepp_epp_map": (ctypes.c_int, [_V, ctypes.POINTER(EppReadsC), ctypes.c_uint32, ctypes.c_uint32,
+                                    ctypes.POINTER(EppOutC)]),
+    "wepp_mat_dfs_order": (ctypes.c_int, [_V, _V]),
+    "wepp_epp_last_timing": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)] * 4 + [
+        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
+        ctypes.POINTER(ctypes.c_uint32)]),
     "wepp_last_error": (ctypes.c_char_p, []),
     "wepp_gen_tree_create": (ctypes.c_int, [ctypes.POINTER(GenTreeParams), ctypes.POINTER(_V)]),
     "wepp_gen_tree_desc": (ctypes.c_int, [_V, ctypes.POINTER(TreeDescC)]),
@@ -126,6 +143,7 @@ _SIGS = {
         ctypes.c_int,
         [_V, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(c_u32p), ctypes.POINTER(c_u32p)],
     ),
+    "wepp_gen_reads_windows": (ctypes.c_int, [_V, ctypes.POINTER(c_i32p), ctypes.POINTER(c_i32p)]),
     "wepp_gen_reads_destroy": (ctypes.c_int, [_V]),
     "wepp_flat_create": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.POINTER(_V)]),
     "wepp_flat_get": (

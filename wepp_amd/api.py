@@ -161,7 +161,9 @@ class GenTree:
         )
 
     def reads(self, seed, n_reads, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.001,
-              p_n=0.005, p_iupac=0.0):
+              p_n=0.005, p_iupac=0.0, windows=False, max_degree=1):
+        """Synthetic reads; windows=True returns EppReads (with the genome window of every read and a
+        multiplicity drawn from 1..max_degree) for Mat.epp_map."""
         p = _lib.GenReadsParams(seed, n_reads, read_len, amplicon_len, amplicon_step, p_substitution, p_n, p_iupac)
         h = ctypes.c_void_p()
         check(lib.wepp_gen_reads_create(self._h, ctypes.byref(p), ctypes.byref(h)))
@@ -173,8 +175,17 @@ class GenTree:
             off = np.ctypeslib.as_array(po, shape=(n.value + 1,)).copy()
             nw = int(off[-1])
             words = np.ctypeslib.as_array(pw, shape=(nw,)).copy() if nw else np.zeros(0, np.uint32)
+            if windows:
+                ps, pe = _lib.c_i32p(), _lib.c_i32p()
+                check(lib.wepp_gen_reads_windows(h, ctypes.byref(ps), ctypes.byref(pe)))
+                st = np.ctypeslib.as_array(ps, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+                en = np.ctypeslib.as_array(pe, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
         finally:
             lib.wepp_gen_reads_destroy(h)
+        if windows:
+            deg = (np.random.default_rng(seed).integers(1, max_degree + 1, n.value).astype(np.int32)
+                   if max_degree > 1 else np.ones(n.value, np.int32))
+            return EppReads(off, words, st, en, deg)
         return Reads(off, words)
 
     def close(self):
@@ -322,6 +333,36 @@ class Mat:
             res.per_node_scores = pns
         return res
 
+    def dfs_order(self):
+        """Caller node id of the haplotype with arena (pre-order) index k."""
+        out = np.zeros(self.n_nodes, np.uint32)
+        check(lib.wepp_mat_dfs_order(self._h, _ptr(out)))
+        return out
+
+    def epp_map(self, reads, genome_size, max_cached_epp=2048, want_counts=True, want_divergence=True,
+                want_lists=True, epp_capacity=None):
+        """wepp_epp_map: WEPP's cartesian_map for an EppReads batch; haplotypes by arena index."""
+        R, n = reads.n_reads, self.n_nodes
+        mp = np.zeros(max(R, 1), np.int32); mult = np.zeros(max(R, 1), np.uint32)
+        score = np.zeros(n, np.float64)
+        counts = np.zeros((n, 50), np.int32) if want_counts else None
+        div = np.zeros(n, np.float64) if want_divergence else None
+        cap = int(epp_capacity if epp_capacity is not None else max_cached_epp * max(R, 1))
+        eoff = np.zeros(R + 1, np.uint64) if want_lists else None
+        enodes = np.zeros(max(cap, 1), np.uint32) if want_lists else None
+        rw = reads.read_word if reads.read_word.size else np.zeros(1, np.uint32)
+        rd = _lib.EppReadsC(R, _ptr(reads.read_off).value, _ptr(rw).value, _ptr(reads.start).value,
+                            _ptr(reads.end).value, _ptr(reads.degree).value)
+        o = _lib.EppOutC(_ptr(mp).value, _ptr(mult).value, _ptr(eoff).value if want_lists else None,
+                         _ptr(enodes).value if want_lists else None, cap, _ptr(score).value,
+                         _ptr(counts).value if want_counts else None, _ptr(div).value if want_divergence else None)
+        check(lib.wepp_epp_map(self._h, ctypes.byref(rd), int(genome_size), int(max_cached_epp), ctypes.byref(o)))
+        out = dict(max_parsimony=mp[:R], multiplicity=mult[:R], score=score, counts=counts, divergence=div)
+        if want_lists:
+            out["epp_off"] = eoff
+            out["epp_nodes"] = enodes[: int(eoff[R])]
+        return out
+
     def imputed_mutations(self, reads, best_bfs_j):
         """Per read: list of (position, nucleotide mask) imputed for its ambiguous entries at
         the chosen node (column 4 of placement_stats.tsv): wepp_imputed_mutations."""
@@ -367,3 +408,14 @@ class Mat:
             self.close()
         except Exception:
             pass
+
+
+def epp_last_timing():
+    """Device time by phase (ms) and work counters of this thread's last Mat.epp_map call."""
+    d = [ctypes.c_double() for _ in range(4)]
+    ev, se = ctypes.c_uint64(), ctypes.c_uint64()
+    g, j = ctypes.c_uint32(), ctypes.c_uint32()
+    check(lib.wepp_epp_last_timing(*[ctypes.byref(x) for x in d], ctypes.byref(ev), ctypes.byref(se), ctypes.byref(g),
+                                   ctypes.byref(j)))
+    return dict(select_ms=d[0].value, sweep1_ms=d[1].value, sweep2_ms=d[2].value, finish_ms=d[3].value,
+                events_swept=ev.value, stream_events=se.value, groups=g.value, jobs=j.value)

@@ -11,67 +11,16 @@
 #include <string>
 #include <vector>
 
-#include "../../include/wepp_place.h"
-#include "device_mat.hpp"
-#include "errors.hpp"
-#include "flatmat.hpp"
-
-using namespace wepp;
-
-struct wepp_mat {
-    int device = 0;
-    DevMAT dev{};
-    std::vector<DevStream> streams;
-    std::vector<uint64_t> stream_bytes;
-    wepp_mat_stats stats{};
-    std::vector<uint32_t> bfs2id;
-    std::vector<void*> allocs;
-    uint32_t tile_reads = 64;
-    int use_crowns = 1;
-    // grow-only workspace: tier of each read, read list, routing counters, partial results
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
-    uint32_t* d_info = nullptr;       // tier_info (TI_WORDS) followed by blk_counts
-    uint32_t* h_info = nullptr;       // pinned copy of tier_info
-    // the sweeps of different streams are independent: they run concurrently on side streams
-    hipStream_t side[MAX_STREAMS] = {};
-    hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
-    static constexpr uint32_t kRing = 64;
-    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
-    uint64_t n_timed = 0;             // placement calls since the last timing reset
-    uint64_t last_passes = 0, last_bytes = 0;
-};
+#include "handle.hpp"
 
 namespace {
-
-int hip_fail(hipError_t e, const char* what) {
-    return set_error(WEPP_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define HIP_TRY(expr)                                      \
-    do {                                                   \
-        hipError_t _e = (expr);                            \
-        if (_e != hipSuccess) return hip_fail(_e, #expr);  \
-    } while (0)
-
-template <typename T>
-int upload(wepp_mat* h, const std::vector<T>& v, const T** out) {
-    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    h->allocs.push_back(p);
-    h->stats.device_bytes += bytes;
-    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    *out = (const T*)p;
-    return WEPP_OK;
-}
 
 void release(wepp_mat* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->epp_ws) (void)hipFree(h->epp_ws);
     if (h->d_info) (void)hipFree(h->d_info);
     if (h->h_info) (void)hipHostFree(h->h_info);
     for (uint32_t i = 0; i < wepp_mat::kRing; i++) {
@@ -110,6 +59,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     if (!h) return set_error(WEPP_ENOMEM, "out of host memory");
     h->device = device;
     h->bfs2id = f.bfs2id;
+    h->dfs2id = f.dfs2id;
     h->stats.n_nodes = f.N;
     h->stats.n_mutations = f.M;
     h->stats.n_masked = f.n_masked;
@@ -138,6 +88,8 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         UP(d.bfs2dfs, bfs2dfs)
     }
     UP(d.parent_dfs, f.parent_dfs)
+    UP(h->epp_word, f.epp_word) UP(h->epp_node, f.epp_node)
+    h->epp_events = f.epp_word.size();
     for (size_t i = 0; i < f.streams.size(); i++) {
         const Stream& st = f.streams[i];
         DevStream ds{};

@@ -48,7 +48,7 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
         if (si >= f.streams.size()) return wepp::set_error(WEPP_EINVAL, "stream index out of range");
     } else {
         FIELD(f, node_woff) FIELD(f, words) FIELD(f, rank2dfs) FIELD(f, dfs2bfs) FIELD(f, bfs2id) FIELD(f, dfs2id)
-        FIELD(f, parent_dfs) FIELD(f, dfs_end) FIELD(f, num_leaves)
+        FIELD(f, parent_dfs) FIELD(f, dfs_end) FIELD(f, num_leaves) FIELD(f, epp_word) FIELD(f, epp_node)
     }
     const wepp::Stream& st = f.streams[si];
     FIELD(st, nkey) FIELD(st, nstat) FIELD(st, blk_node0) FIELD(st, blk_eoff) FIELD(st, blk_sum) FIELD(st, ev_word)

@@ -422,6 +422,29 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
         int rc = build_stream(f, sel, f.streams.back(), err);
         if (rc != WEPP_OK) return rc;
     }
+
+    // ---- EPP event stream (see flatmat.hpp) -----------------------------------------
+    {
+        f.epp_word.reserve(2 * f.M);
+        f.epp_node.reserve(2 * f.M);
+        std::vector<uint32_t> open;                          // nodes with mutations on the current path
+        auto close = [&](uint32_t a) {
+            for (uint32_t k = f.node_woff[a]; k < f.node_woff[a + 1]; k++) {
+                f.epp_word.push_back(f.words[k] | W_EXIT);
+                f.epp_node.push_back(f.dfs_end[a] + 1);
+            }
+        };
+        for (uint32_t d = 0; d < N; d++) {
+            while (!open.empty() && f.dfs_end[open.back()] < d) { close(open.back()); open.pop_back(); }
+            if (f.node_woff[d + 1] == f.node_woff[d]) continue;
+            for (uint32_t k = f.node_woff[d]; k < f.node_woff[d + 1]; k++) {
+                f.epp_word.push_back(f.words[k]);
+                f.epp_node.push_back(d);
+            }
+            open.push_back(d);
+        }
+        while (!open.empty()) { close(open.back()); open.pop_back(); }
+    }
     return WEPP_OK;
 }
 

@@ -100,6 +100,14 @@ struct FlatMAT {
     std::vector<uint32_t> num_leaves;  // [N]                                (host only)
     // streams[0 .. n-2] = crowns of increasing tau, streams.back() = whole tree
     std::vector<Stream> streams;
+    // EPP event stream (epp_kernels.hip): every non-masked mutation twice, in the order a
+    // pre-order walk applies and retracts it -- enter words when its node is entered, the same
+    // words with W_EXIT once the node's subtree is done.  epp_node[i] = number of nodes
+    // (pre-order indices) entered before event i takes effect: the node's own index for an
+    // enter, one past the subtree's last index for an exit.  The genotype between two
+    // consecutive events i, j is constant and belongs to the nodes [epp_node[i], epp_node[j]).
+    std::vector<uint32_t> epp_word;    // [2M]
+    std::vector<uint32_t> epp_node;    // [2M]
     const Stream& full() const { return streams.back(); }
 };
 

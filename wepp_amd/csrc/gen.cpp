@@ -69,6 +69,7 @@ struct wepp_gen_tree {
 
 struct wepp_gen_reads {
     std::vector<uint32_t> read_off, read_word;
+    std::vector<int32_t> win_start, win_end;   // genome window every read was drawn from
 };
 
 extern "C" int wepp_gen_tree_create(const wepp_gen_tree_params* pp, wepp_gen_tree_t** out) {
@@ -215,6 +216,8 @@ extern "C" int wepp_gen_reads_create(const wepp_gen_tree_t* t, const wepp_gen_re
                 ws = a0 + (uint32_t)rng.below(a1 - a0 + 2 - pp->read_len);
                 we = ws + pp->read_len - 1;
             }
+            r->win_start.push_back((int32_t)ws);
+            r->win_end.push_back((int32_t)we);
             // leaf genotype inside the window: most recent mutation per position
             ents.clear();
             seen.clear();
@@ -264,6 +267,13 @@ extern "C" int wepp_gen_reads_create(const wepp_gen_tree_t* t, const wepp_gen_re
         return wepp::set_error(WEPP_ENOMEM, "out of host memory");
     }
     *out = r;
+    return WEPP_OK;
+}
+
+extern "C" int wepp_gen_reads_windows(const wepp_gen_reads_t* r, const int32_t** start, const int32_t** end) {
+    if (!r) return wepp::set_error(WEPP_EINVAL, "null argument");
+    if (start) *start = r->win_start.data();
+    if (end) *end = r->win_end.data();
     return WEPP_OK;
 }
 

@@ -1,0 +1,73 @@
+// handle.hpp -- the object behind wepp_mat_t and the small helpers the C-ABI translation
+// units (capi.cpp, epp_capi.cpp) share.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/wepp_place.h"
+#include "device_mat.hpp"
+#include "errors.hpp"
+#include "flatmat.hpp"
+
+using namespace wepp;
+
+struct wepp_mat {
+    int device = 0;
+    DevMAT dev{};
+    std::vector<DevStream> streams;
+    std::vector<uint64_t> stream_bytes;
+    wepp_mat_stats stats{};
+    std::vector<uint32_t> bfs2id;
+    std::vector<uint32_t> dfs2id;     // caller id of the node with pre-order (arena) index k
+    // EPP event stream (flatmat.hpp), resident next to the sweep streams
+    const uint32_t* epp_word = nullptr;
+    const uint32_t* epp_node = nullptr;
+    uint64_t epp_events = 0;
+    void* epp_ws = nullptr;           // grow-only workspace of wepp_epp_map
+    size_t epp_ws_bytes = 0;
+    std::vector<void*> allocs;
+    uint32_t tile_reads = 64;
+    int use_crowns = 1;
+    // grow-only workspace: tier of each read, read list, routing counters, partial results
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint32_t* d_info = nullptr;       // tier_info (TI_WORDS) followed by blk_counts
+    uint32_t* h_info = nullptr;       // pinned copy of tier_info
+    // the sweeps of different streams are independent: they run concurrently on side streams
+    hipStream_t side[MAX_STREAMS] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
+    static constexpr uint32_t kRing = 64;
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    uint64_t n_timed = 0;             // placement calls since the last timing reset
+    uint64_t last_passes = 0, last_bytes = 0;
+};
+
+namespace wepp {
+
+inline int hip_fail(hipError_t e, const char* what) {
+    return set_error(WEPP_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+    } while (0)
+
+template <typename T>
+inline int upload(wepp_mat* h, const std::vector<T>& v, const T** out) {
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    h->allocs.push_back(p);
+    h->stats.device_bytes += bytes;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return WEPP_OK;
+}
+
+}  // namespace wepp
