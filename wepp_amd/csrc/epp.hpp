@@ -27,7 +27,7 @@ struct EppGroup {
 struct EppSweepArgs {
     const EppGroup* groups;
     uint32_t G, n_jobs, R, N;
-    uint32_t chunk_events, bm_words, ent_cap, bin_size;
+    uint32_t chunk_events, bm_words, tab_rows, bin_size;
     const uint32_t* st_word;
     const uint32_t* st_node;
     const uint32_t* read_off;

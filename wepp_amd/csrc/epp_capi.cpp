@@ -113,7 +113,7 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     const uint32_t G = (ntiles + tpg - 1) / tpg;
     std::vector<EppGroup> groups(G);
     std::vector<uint32_t> we_max(G);
-    uint32_t bm_words = 1, ent_cap = 1;
+    uint32_t bm_words = 1, max_span = 0;
     for (uint32_t g = 0; g < G; g++) {
         EppGroup& gr = groups[g];
         gr = EppGroup{};
@@ -122,23 +122,25 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
         gr.ws = 0xFFFFFFFFu;
         gr.we = 0;
         for (uint32_t t = gr.tile0; t < gr.tile0 + gr.ntiles; t++) {
-            uint32_t ts = 0xFFFFFFFFu, te = 0, ents = 0;
+            uint32_t ts = 0xFFFFFFFFu, te = 0;
             for (uint32_t s = t * 64; s < std::min(R, t * 64 + 64); s++) {
                 const uint32_t r = order[s];
                 ts = std::min(ts, (uint32_t)rd->start[r]);
                 te = std::max(te, (uint32_t)rd->end[r]);
-                ents += rd->read_off[r + 1] - rd->read_off[r];
+                max_span = std::max(max_span, (uint32_t)(rd->end[r] - rd->start[r]));
             }
             bm_words = std::max(bm_words, ((te - ts) >> 5) + 1);
-            ent_cap = std::max(ent_cap, ents);
             gr.ws = std::min(gr.ws, ts);
             gr.we = std::max(gr.we, te);
         }
         we_max[g] = g ? std::max(we_max[g - 1], gr.we) : gr.we;
     }
-    const uint32_t lds_bytes = (bm_words + ent_cap) * 4;
+    // per-read allele table: one nibble per window position, 8 positions per word, lane-interleaved
+    const uint32_t tab_rows = (max_span >> 3) + 1;
+    const uint32_t lds_bytes = (bm_words + tab_rows * 64) * 4;
     if (lds_bytes > 150 * 1024)
-        return set_error(WEPP_ELIMIT, "a tile of 64 reads needs " + std::to_string(lds_bytes) + " bytes of LDS (window bitmap + read words)");
+        return set_error(WEPP_ELIMIT, "a tile of 64 reads needs " + std::to_string(lds_bytes) +
+                                          " bytes of LDS (window bitmap + allele table): reads longer than ~4500 bases");
 
     // ---- device copies of the reads ------------------------------------------------------
     DevPool pool;
@@ -213,7 +215,7 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     fx_bits = std::min(fx_bits, 52);
     EppSweepArgs a{};
     a.groups = d_groups; a.G = G; a.n_jobs = n_jobs; a.R = R; a.N = N;
-    a.chunk_events = chunk_events; a.bm_words = bm_words; a.ent_cap = ent_cap;
+    a.chunk_events = chunk_events; a.bm_words = bm_words; a.tab_rows = tab_rows;
     a.bin_size = genome_size / EPP_BINS;
     a.st_word = d_stw; a.st_node = d_stn;
     a.read_off = d_off; a.read_word = d_word; a.start = d_start; a.end = d_end; a.degree = d_degree; a.order = d_order;

@@ -52,6 +52,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o > v ? o : v; }
     return v;
 }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int lo = __shfl_xor((int)(uint32_t)v, m, 64), hi = __shfl_xor((int)(v >> 32), m, 64);
+        v += (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+    }
+    return v;
+}
 // groups that may hold position p: ws ascending, we_max = running maximum of we
 __device__ __forceinline__ void candidate_groups(const uint32_t* ws, const uint32_t* wemax, uint32_t G, uint32_t p,
                                                  uint32_t& g_lo, uint32_t& g_hi_excl) {
@@ -179,8 +192,9 @@ __global__ __launch_bounds__(64) void k_epp_select_scatter(const uint32_t* __res
 template <int PASS>
 __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
     extern __shared__ uint32_t lds[];
-    uint32_t* bm = lds;                       // [bm_words] listed positions of the tile, relative to its window
-    uint32_t* S = lds + a.bm_words;           // [ent_cap]  read words of the tile
+    uint32_t* bm = lds;                       // [bm_words] positions listed by some read of the tile, relative to its window
+    uint32_t* tab = lds + a.bm_words;         // [tab_rows][64] allele of read `lane` at window offset o: nibble o & 7 of
+                                              //                tab[(o >> 3) * 64 + lane], 0 = not listed
     const uint32_t lane = threadIdx.x;
     const uint32_t job = blockIdx.x;
     // group of the job
@@ -201,24 +215,21 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
     const uint32_t rs = have ? (uint32_t)a.start[r] : 0xFFFFFFFFu;
     const uint32_t re = have ? (uint32_t)a.end[r] : 0;
     const uint32_t span_r = have ? re - rs : 0;
-    // tile window and LDS copy of the tile's reads
+    // tile window, tile bitmap and the per-read allele table
     const uint32_t tws = wave_min_u32(rs);
     const uint32_t twe = wave_max_u32(re);
     const uint32_t tspan = twe - tws;
-    uint32_t loff;                             // offset of this lane's words in S (exclusive prefix of k)
-    {
-        uint32_t incl = k;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
-        loff = incl - k;
-    }
     for (uint32_t i = lane; i < a.bm_words; i += 64) bm[i] = 0;
+    for (uint32_t i = 0; i < a.tab_rows; i++) tab[i * 64 + lane] = 0;
     __syncthreads();
     for (uint32_t j = 0; j < k; j++) {
         const uint32_t w = a.read_word[off + j];
-        S[loff + j] = w;
-        const uint32_t rel = (w & W_POS) - tws;
-        if (rel <= tspan) atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+        const uint32_t o = (w & W_POS) - rs;
+        if (o <= span_r) {                     // a position outside the read's window never changes its distance
+            tab[(o >> 3) * 64 + lane] |= ((w >> 24) & 15u) << ((o & 7) * 4);
+            const uint32_t rel = (w & W_POS) - tws;
+            atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+        }
     }
     __syncthreads();
 
@@ -234,85 +245,151 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
 
     int D = 0, mn = INT_INF;
     uint32_t cnt = 0;
-    // pass 2 state
-    int best = 0;
+    // pass 2 state: per lane the read's minimum, score delta, degree, bin and EPP-list cursor;
+    // wave-uniform the lanes whose range is open and the sums of the last flip
+    int best = INT_INF;                        // lanes without a read never match
     long long dfx = 0;
     int deg = 0;
     uint32_t bucket = 0;
-    unsigned long long list_at = ~0ull;
-    bool open = false;
+    unsigned long long list_at = 0;
+    unsigned long long open_mask = 0, list_mask = 0;
+    unsigned long long c_t = 0, c_on = 0;
+    long long c_vs = 0;
+    int c_nb = 0, c_cs[2] = {0, 0};
+    uint32_t c_b[2] = {0, 0};
     if (PASS == 2) {
         D = a.part_net[row];                   // distance at the chunk's start
+        bool keep = false;
         if (have) {
             best = a.best[sidx];
             dfx = a.delta_fx[sidx];
             deg = a.degree[r];
             bucket = min((uint32_t)a.start[r] / a.bin_size, EPP_BINS - 1);
             const uint64_t eb = a.epp_base[r];
-            if (eb != ~0ull) list_at = eb + a.part_cnt[row];
-        } else {
-            best = INT_INF;                    // never matches
+            keep = eb != ~0ull;
+            list_at = eb + a.part_cnt[row];
         }
+        list_mask = __ballot(keep);
     }
+
+    // flips of pass 2: the lanes in `tmask` start (those also in `onmask`) or stop matching at node p
+    auto flip = [&](unsigned long long tmask, unsigned long long onmask, uint32_t p) {
+        // A mutation's enter and exit events usually flip the same lanes in opposite directions
+        // (always when its node is a leaf): the sums of the previous flip are reused.
+        const bool same_dir = tmask == c_t && onmask == c_on;
+        const bool opp_dir = tmask == c_t && onmask == (c_t & ~c_on);
+        if (!(same_dir || opp_dir) || c_nb > 2) {
+            const bool t_l = (tmask >> lane) & 1ull, on_l = (onmask >> lane) & 1ull;
+            const long long vs = wave_sum_i64(t_l ? (on_l ? dfx : -dfx) : 0);
+            c_vs = ((long long)__builtin_amdgcn_readfirstlane((int)(vs >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vs);
+            c_nb = 0;
+            if (a.diff_cnt) {
+                const int cv = t_l ? (on_l ? deg : -deg) : 0;
+                unsigned long long pending = tmask;
+                while (pending) {
+                    const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bucket, __builtin_ctzll(pending));
+                    const bool same = t_l && bucket == bb;
+                    const int cs = __builtin_amdgcn_readfirstlane(wave_sum_i32(same ? cv : 0));
+                    if (c_nb < 2) { c_b[c_nb] = bb; c_cs[c_nb] = cs; }
+                    else if (lane == 0) atomicAdd(&a.diff_cnt[(size_t)p * EPP_BINS + bb], cs);
+                    c_nb++;
+                    pending &= ~__ballot(same);
+                }
+            }
+            c_t = tmask;
+            c_on = onmask;
+        } else if (opp_dir) {
+            c_vs = -c_vs;
+            c_cs[0] = -c_cs[0];
+            c_cs[1] = -c_cs[1];
+            c_on = onmask;
+        }
+        if (lane == 0) {
+            atomicAdd(&a.diff_score[p], (unsigned long long)c_vs);
+            if (a.diff_cnt) {
+                if (c_nb > 0) atomicAdd(&a.diff_cnt[(size_t)p * EPP_BINS + c_b[0]], c_cs[0]);
+                if (c_nb > 1) atomicAdd(&a.diff_cnt[(size_t)p * EPP_BINS + c_b[1]], c_cs[1]);
+            }
+        }
+    };
 
     // the nodes [p_prev, p) carry the current distance
     auto credit = [&](uint32_t p) {
         const uint32_t gap = p - p_prev;
         if (gap == 0) return;
         if (PASS == 1) {
-            if (D < mn) { mn = D; cnt = gap; }
-            else if (D == mn) cnt += gap;
+            cnt = D < mn ? 0u : cnt;
+            mn = min(mn, D);
+            cnt += D == mn ? gap : 0u;
         } else {
-            const bool match = D == best;
-            if (match != open) {
-                const unsigned long long v = match ? (unsigned long long)dfx : (unsigned long long)(-dfx);
-                atomicAdd(&a.diff_score[p_prev], v);
-                if (a.diff_cnt) atomicAdd(&a.diff_cnt[(size_t)p_prev * EPP_BINS + bucket], match ? deg : -deg);
-                open = match;
+            const unsigned long long match_mask = __ballot(D == best);
+            const unsigned long long tmask = match_mask ^ open_mask;
+            if (tmask) {
+                flip(tmask, tmask & match_mask, p_prev);
+                open_mask = match_mask;
             }
-            if (match && list_at != ~0ull) {
-                for (uint32_t q = 0; q < gap; q++) a.epp_nodes[list_at + q] = p_prev + q;
-                list_at += gap;
+            if (match_mask & list_mask) {
+                if (((match_mask & list_mask) >> lane) & 1ull) {
+                    for (uint32_t q = 0; q < gap; q++) a.epp_nodes[list_at + q] = p_prev + q;
+                    list_at += gap;
+                }
             }
         }
         p_prev = p;
     };
 
+    // The walk is serial in the events but most of what an event needs does not depend on the
+    // read: it is computed lane = event for 64 events at a time, the events inside the tile's
+    // window are packed to the low lanes, and the serial loop only broadcasts three registers
+    // per event.
     for (uint32_t b0 = e0; b0 < e1; b0 += 64) {
         const uint32_t i = b0 + lane;
         const uint32_t w = i < e1 ? sw[i] : PAD_WORD;
         const uint32_t nd = i < e1 ? sn[i] : 0;
-        const uint32_t rel = (w & W_POS) - tws;
+        const uint32_t wpos = w & W_POS;
+        const uint32_t rel = wpos - tws;
         const bool in_tile = rel <= tspan;
         const bool listed = in_tile && ((bm[rel >> 5] >> (rel & 31)) & 1u);
-        unsigned long long m_in = __ballot(in_tile);
-        const unsigned long long m_hit = __ballot(listed);
-        while (m_in) {
-            const int j = __builtin_ctzll(m_in);
-            m_in &= m_in - 1;
-            const uint32_t ew = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
-            const uint32_t ep = (uint32_t)__builtin_amdgcn_readlane((int)nd, j);
-            credit(ep);
-            const uint32_t pos = ew & W_POS;
-            const uint32_t refm = 1u << ((ew >> 20) & 3u);
-            const uint32_t par = (ew >> 22) & 15u;
-            const uint32_t mut = (ew >> 26) & 15u;
+        // distance change for a read that does not list the position (it shows the reference base);
+        // bits 8.. keep what a read that lists it needs: mut, genotype above, exit flag
+        uint32_t info;
+        {
+            const uint32_t refm = 1u << ((w >> 20) & 3u);
+            const uint32_t par = (w >> 22) & 15u, mut = (w >> 26) & 15u;
             const uint32_t pare = par ? par : refm;            // genotype above the mutation
-            int d = (int)(mut != refm) - (int)(pare != refm);  // a read that does not list the position shows ref
+            int dref = (int)(mut != refm) - (int)(pare != refm);
+            if (w & W_EXIT_BIT) dref = -dref;
+            info = (uint32_t)(dref & 0xFF) | (mut << 8) | (pare << 12) | (((w >> 30) & 1u) << 16);
+        }
+        const unsigned long long m_in = __ballot(in_tile);
+        if (m_in == 0) continue;
+        const uint32_t n_in = (uint32_t)__popcll(m_in);
+        const int dst = (int)(in_tile ? (uint32_t)__popcll(m_in & ((1ull << lane) - 1ull)) : 63u) << 2;
+        const uint32_t c_pos = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)wpos);
+        const uint32_t c_info = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)info);
+        const uint32_t c_nd = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)nd);
+        const bool c_listed = __builtin_amdgcn_ds_permute(dst, (int)listed) != 0 && lane < n_in;
+        const unsigned long long m_hit = __ballot(c_listed);
+        for (uint32_t j = 0; j < n_in; j++) {
+            const uint32_t ep = (uint32_t)__builtin_amdgcn_readlane((int)c_nd, (int)j);
+            credit(ep);
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)c_pos, (int)j);
+            const uint32_t ei = (uint32_t)__builtin_amdgcn_readlane((int)c_info, (int)j);
+            const uint32_t o = pos - rs;
+            const bool in_win = o <= span_r;                   // only inside the read's own window (:56,60)
+            int d = (int)(int8_t)(ei & 0xFF);
             if ((m_hit >> j) & 1ull) {
-                // some read of the tile lists this position
-                uint32_t lo = 0, hi = k;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((S[loff + mid] & W_POS) < pos) lo = mid + 1; else hi = mid; }
-                if (lo < k) {
-                    const uint32_t s = S[loff + lo];
-                    if ((s & W_POS) == pos) {
-                        const uint32_t al = (s >> 24) & 15u;
-                        d = al == 15u ? 0 : (int)(mut != al) - (int)(pare != al);   // N matches anything (:68)
-                    }
-                }
+                // some read of the tile lists this position: each lane looks its own allele up
+                const uint32_t oo = in_win ? o : 0;
+                const uint32_t al = (tab[(oo >> 3) * 64 + lane] >> ((oo & 7) * 4)) & 15u;
+                const uint32_t mut = (ei >> 8) & 15u, pare = (ei >> 12) & 15u;
+                int dl = (int)(mut != al) - (int)(pare != al);
+                if ((ei >> 16) & 1u) dl = -dl;
+                dl = al == 15u ? 0 : dl;                       // N matches anything (:68)
+                d = al ? dl : d;
             }
-            if (ew & W_EXIT_BIT) d = -d;
-            if (pos - rs <= span_r) D += d;                    // only inside the read's own window (:56,60)
+            D += in_win ? d : 0;
         }
     }
     credit(p_end);
@@ -320,9 +397,8 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
         a.part_min[row] = mn;
         a.part_cnt[row] = cnt;
         a.part_net[row] = D;
-    } else if (open) {
-        atomicAdd(&a.diff_score[p_end], (unsigned long long)(-dfx));
-        if (a.diff_cnt) atomicAdd(&a.diff_cnt[(size_t)p_end * EPP_BINS + bucket], -deg);
+    } else if (open_mask) {
+        flip(open_mask, 0ull, p_end);          // ranges still open at the chunk's end stop at its last node
     }
 }
 
