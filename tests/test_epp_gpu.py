@@ -23,12 +23,15 @@ def _check(got, want, n_reads, tag):
     assert np.array_equal(got["divergence"], want["divergence"], equal_nan=True), tag
 
 
-def test_fuzz_small_trees(oracle):
+@pytest.mark.parametrize("rpl", [1, 4])
+def test_fuzz_small_trees(oracle, rpl, monkeypatch):
+    """rpl = reads per lane of the sweep (a tile is 64 * rpl reads); the library picks 4 for big batches."""
+    monkeypatch.setenv("WEPP_EPP_RPL", str(rpl))
     rng = np.random.default_rng(31337)
     for it in range(40):
         genome = 60
         tree, ref = ft.random_tree(rng, genome=genome)
-        reads = epp_fuzz.random_epp_reads(rng, tree, ref, genome, n_reads=int(rng.integers(1, 200)))
+        reads = epp_fuzz.random_epp_reads(rng, tree, ref, genome, n_reads=int(rng.integers(1, 600)))
         mat = w.Mat(tree)
         got = mat.epp_map(reads, genome)
         want = oracle.OracleTree(tree).epp_map(reads, genome_size=genome)
@@ -60,11 +63,13 @@ def test_edge_cases(oracle):
     mat.close()
 
 
+@pytest.mark.parametrize("rpl", [1, 4])
 @pytest.mark.parametrize("n_nodes,n_reads,read_len,cap", [(3000, 700, 150, 2048), (20000, 3000, 150, 64),
                                                           (8000, 300, 1200, 2048)])
-def test_generated_trees(oracle, n_nodes, n_reads, read_len, cap):
-    """SARS-CoV-2-sized genome, amplicon reads drawn from leaf genotypes (several windows, tiles,
-    chunks); EPP lists capped at `cap` placements."""
+def test_generated_trees(oracle, n_nodes, n_reads, read_len, cap, rpl, monkeypatch):
+    monkeypatch.setenv("WEPP_EPP_RPL", str(rpl))
+    # SARS-CoV-2-sized genome, amplicon reads drawn from leaf genotypes (several windows, tiles,
+    # chunks); EPP lists capped at `cap` placements
     g = w.generate_tree(5, n_nodes)
     reads = g.reads(6, n_reads, read_len=read_len, amplicon_len=max(400, read_len), amplicon_step=300 if read_len < 400 else 1000,
                     p_substitution=0.003, p_n=0.01, windows=True, max_degree=7)

@@ -16,7 +16,7 @@ constexpr uint32_t EPP_NO_LIST = 0xFFFFFFFFu;
 // the sub-sequence of the MAT's EPP event stream with positions inside [ws, we].
 struct EppGroup {
     uint32_t ws, we;          // genome window covered by the group's reads
-    uint32_t tile0, ntiles;   // tiles (64 consecutive sorted reads) of the group
+    uint32_t tile0, ntiles;   // tiles (64 * rpl consecutive sorted reads) of the group
     uint32_t n_events;        // length of the window's event stream
     uint32_t nchunks;         // the stream is swept in nchunks pieces of chunk_events
     uint32_t job0;            // first sweep job: job = job0 + chunk * ntiles + tile
@@ -61,8 +61,9 @@ hipError_t launch_epp_select_scan(uint32_t* cnt, uint32_t G, uint32_t nblk, uint
 hipError_t launch_epp_select_scatter(const uint32_t* ev_word, const uint32_t* ev_node, uint64_t n_events,
                                      const EppGroup* groups, const uint32_t* we_max, uint32_t G, uint32_t nblk,
                                      const uint32_t* cnt, uint32_t* st_word, uint32_t* st_node, hipStream_t stream);
-hipError_t launch_epp_sweep(const EppSweepArgs& a, int pass, uint32_t lds_bytes, hipStream_t stream);
-hipError_t launch_epp_combine(const EppSweepArgs& a, uint32_t tiles_per_group, hipStream_t stream);
+// rpl = reads per lane (1 or 4): a tile is 64 * rpl reads
+hipError_t launch_epp_sweep(const EppSweepArgs& a, int pass, uint32_t rpl, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_epp_combine(const EppSweepArgs& a, uint32_t tiles_per_group, uint32_t rpl, hipStream_t stream);
 // prefix sums of the difference arrays -> per-haplotype outputs (arena order)
 hipError_t launch_epp_finish(uint32_t N, const unsigned long long* diff_score, double inv_scale, double* score,
                              const int* diff_cnt, const int* true_counts, int* counts, double* divergence,

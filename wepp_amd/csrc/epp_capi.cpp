@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -108,7 +109,19 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
         if (rd->end[a] != rd->end[b]) return rd->end[a] < rd->end[b];
         return a < b;
     });
-    const uint32_t ntiles = (R + 63) / 64;
+    // reads per lane.  4 shares the serial per-event work (broadcasts, flips, atomics) among 256 reads
+    // per wave, but a tile that large lists almost every position of its window, so every event takes
+    // the allele-lookup path: measured 1.4x slower than 1 -- kept selectable for
+    // experiments, and only while its allele table leaves room for several waves per CU.
+    uint32_t rpl = 1;
+    if (const char* env = std::getenv("WEPP_EPP_RPL")) rpl = std::atoi(env) == 4 ? 4 : 1;
+    if (rpl == 4) {
+        int32_t longest = 0;
+        for (uint32_t r = 0; r < R; r++) longest = std::max(longest, rd->end[r] - rd->start[r]);
+        if ((((uint32_t)longest >> 3) + 1) * 64 * 4 * 4 > 48 * 1024) rpl = 1;
+    }
+    const uint32_t TS = 64 * rpl;
+    const uint32_t ntiles = (R + TS - 1) / TS;
     const uint32_t tpg = std::max<uint32_t>(1, (ntiles + EPP_MAX_GROUPS - 1) / EPP_MAX_GROUPS);
     const uint32_t G = (ntiles + tpg - 1) / tpg;
     std::vector<EppGroup> groups(G);
@@ -123,7 +136,7 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
         gr.we = 0;
         for (uint32_t t = gr.tile0; t < gr.tile0 + gr.ntiles; t++) {
             uint32_t ts = 0xFFFFFFFFu, te = 0;
-            for (uint32_t s = t * 64; s < std::min(R, t * 64 + 64); s++) {
+            for (uint32_t s = t * TS; s < std::min<uint64_t>(R, (uint64_t)t * TS + TS); s++) {
                 const uint32_t r = order[s];
                 ts = std::min(ts, (uint32_t)rd->start[r]);
                 te = std::max(te, (uint32_t)rd->end[r]);
@@ -137,10 +150,10 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     }
     // per-read allele table: one nibble per window position, 8 positions per word, lane-interleaved
     const uint32_t tab_rows = (max_span >> 3) + 1;
-    const uint32_t lds_bytes = (bm_words + tab_rows * 64) * 4;
+    const uint32_t lds_bytes = (bm_words + tab_rows * 64 * rpl) * 4;
     if (lds_bytes > 150 * 1024)
         return set_error(WEPP_ELIMIT, "a tile of 64 reads needs " + std::to_string(lds_bytes) +
-                                          " bytes of LDS (window bitmap + allele table): reads longer than ~4500 bases");
+                                          " bytes of LDS (window bitmap + allele table): reads too long");
 
     // ---- device copies of the reads ------------------------------------------------------
     DevPool pool;
@@ -205,7 +218,7 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     HIP_TRY(hipEventRecord(ev[1], stream));
 
     // ---- pass 1, combine -------------------------------------------------------------------
-    const size_t rows = (size_t)n_jobs * 64;
+    const size_t rows = (size_t)n_jobs * 64 * rpl;
     int32_t *d_pmin, *d_pnet, *d_best;
     uint32_t *d_pcnt, *d_mult;
     long long* d_fx;
@@ -222,8 +235,8 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     a.part_min = d_pmin; a.part_cnt = d_pcnt; a.part_net = d_pnet;
     a.best = d_best; a.mult = d_mult; a.delta_fx = d_fx;
     a.fx_scale = std::ldexp(1.0, fx_bits);
-    HIP_TRY(launch_epp_sweep(a, 1, lds_bytes, stream));
-    HIP_TRY(launch_epp_combine(a, tpg, stream));
+    HIP_TRY(launch_epp_sweep(a, 1, rpl, lds_bytes, stream));
+    HIP_TRY(launch_epp_combine(a, tpg, rpl, stream));
     std::vector<int32_t> best_s(R);
     std::vector<uint32_t> mult_s(R);
     HIP_TRY(hipMemcpyAsync(best_s.data(), d_best, (size_t)R * 4, hipMemcpyDeviceToHost, stream));
@@ -259,7 +272,7 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     HIP_TRY(hipMemsetAsync(d_dscore, 0, ((size_t)N + 1) * 8, stream));
     if (want_cnt) HIP_TRY(hipMemsetAsync(d_dcnt, 0, ((size_t)N + 1) * EPP_BINS * 4, stream));
     a.epp_base = d_ebase; a.epp_nodes = d_enodes; a.diff_score = d_dscore; a.diff_cnt = d_dcnt;
-    HIP_TRY(launch_epp_sweep(a, 2, lds_bytes, stream));
+    HIP_TRY(launch_epp_sweep(a, 2, rpl, lds_bytes, stream));
     HIP_TRY(hipEventRecord(ev[3], stream));
 
     // ---- prefix sums -> per-haplotype outputs ------------------------------------------------

@@ -189,12 +189,15 @@ __global__ __launch_bounds__(64) void k_epp_select_scatter(const uint32_t* __res
 // ---------------------------------------------------------------------------------------
 // sweep
 // ---------------------------------------------------------------------------------------
-template <int PASS>
+// RPL = reads per lane: a tile is 64 * RPL reads consecutive in window order (slot q of lane l is
+// read tile * 64 * RPL + q * 64 + l), so that the serial per-event work of the walk is shared by
+// 64 * RPL reads.
+template <int PASS, int RPL>
 __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
     extern __shared__ uint32_t lds[];
     uint32_t* bm = lds;                       // [bm_words] positions listed by some read of the tile, relative to its window
-    uint32_t* tab = lds + a.bm_words;         // [tab_rows][64] allele of read `lane` at window offset o: nibble o & 7 of
-                                              //                tab[(o >> 3) * 64 + lane], 0 = not listed
+    uint32_t* tab = lds + a.bm_words;         // [tab_rows][RPL][64] allele of read (q, lane) at window offset o: nibble o & 7
+                                              //                of tab[((o >> 3) * RPL + q) * 64 + lane], 0 = not listed
     const uint32_t lane = threadIdx.x;
     const uint32_t job = blockIdx.x;
     // group of the job
@@ -207,28 +210,39 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
     const EppGroup gr = a.groups[g];
     const uint32_t local = job - gr.job0;
     const uint32_t tl = local % gr.ntiles, c = local / gr.ntiles;
-    const uint32_t sidx = (gr.tile0 + tl) * 64 + lane;
-    const bool have = sidx < a.R;
-    const uint32_t r = have ? a.order[sidx] : 0;
-    const uint32_t off = have ? a.read_off[r] : 0;
-    const uint32_t k = have ? a.read_off[r + 1] - off : 0;
-    const uint32_t rs = have ? (uint32_t)a.start[r] : 0xFFFFFFFFu;
-    const uint32_t re = have ? (uint32_t)a.end[r] : 0;
-    const uint32_t span_r = have ? re - rs : 0;
+    uint32_t sidx[RPL], rd[RPL], rs[RPL], span_r[RPL];
+    bool have[RPL];
+    uint32_t tws = 0xFFFFFFFFu, twe = 0;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+        sidx[q] = ((gr.tile0 + tl) * RPL + q) * 64 + lane;
+        have[q] = sidx[q] < a.R;
+        rd[q] = have[q] ? a.order[sidx[q]] : 0;
+        rs[q] = have[q] ? (uint32_t)a.start[rd[q]] : 0xFFFFFFFFu;
+        const uint32_t re = have[q] ? (uint32_t)a.end[rd[q]] : 0;
+        span_r[q] = have[q] ? re - rs[q] : 0;
+        tws = min(tws, rs[q]);
+        twe = max(twe, re);
+    }
     // tile window, tile bitmap and the per-read allele table
-    const uint32_t tws = wave_min_u32(rs);
-    const uint32_t twe = wave_max_u32(re);
+    tws = wave_min_u32(tws);
+    twe = wave_max_u32(twe);
     const uint32_t tspan = twe - tws;
     for (uint32_t i = lane; i < a.bm_words; i += 64) bm[i] = 0;
-    for (uint32_t i = 0; i < a.tab_rows; i++) tab[i * 64 + lane] = 0;
+    for (uint32_t i = 0; i < a.tab_rows * RPL; i++) tab[i * 64 + lane] = 0;
     __syncthreads();
-    for (uint32_t j = 0; j < k; j++) {
-        const uint32_t w = a.read_word[off + j];
-        const uint32_t o = (w & W_POS) - rs;
-        if (o <= span_r) {                     // a position outside the read's window never changes its distance
-            tab[(o >> 3) * 64 + lane] |= ((w >> 24) & 15u) << ((o & 7) * 4);
-            const uint32_t rel = (w & W_POS) - tws;
-            atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+        if (!have[q]) continue;
+        const uint32_t off = a.read_off[rd[q]], k = a.read_off[rd[q] + 1] - off;
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t w = a.read_word[off + j];
+            const uint32_t o = (w & W_POS) - rs[q];
+            if (o <= span_r[q]) {              // a position outside the read's window never changes its distance
+                tab[((o >> 3) * RPL + q) * 64 + lane] |= ((w >> 24) & 15u) << ((o & 7) * 4);
+                const uint32_t rel = (w & W_POS) - tws;
+                atomicOr(&bm[rel >> 5], 1u << (rel & 31));
+            }
         }
     }
     __syncthreads();
@@ -241,69 +255,99 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
     const uint32_t p_end = e1 < gr.n_events ? sn[e1] : a.N;       // first node index that is not this chunk's
     uint32_t p_prev = (c == 0 || e0 >= gr.n_events) ? 0u : sn[e0];
     if (c > 0 && e0 >= gr.n_events) p_prev = a.N;                 // empty trailing chunk: no nodes
-    const size_t row = (size_t)job * 64 + lane;
+    const size_t row0 = (size_t)job * RPL * 64 + lane;            // + q * 64
 
-    int D = 0, mn = INT_INF;
-    uint32_t cnt = 0;
-    // pass 2 state: per lane the read's minimum, score delta, degree, bin and EPP-list cursor;
-    // wave-uniform the lanes whose range is open and the sums of the last flip
-    int best = INT_INF;                        // lanes without a read never match
-    long long dfx = 0;
-    int deg = 0;
-    uint32_t bucket = 0;
-    unsigned long long list_at = 0;
-    unsigned long long open_mask = 0, list_mask = 0;
-    unsigned long long c_t = 0, c_on = 0;
+    int D[RPL], mn[RPL];
+    uint32_t cnt[RPL];
+    // pass 2 state: per read its minimum, score delta, degree, bin and EPP-list cursor;
+    // wave-uniform the reads whose range is open and the sums of the last flip
+    int best[RPL];
+    long long dfx[RPL];
+    int deg[RPL];
+    uint32_t bucket[RPL];
+    unsigned long long list_at[RPL];
+    unsigned long long open_mask[RPL], list_mask[RPL], c_t[RPL], c_on[RPL];
     long long c_vs = 0;
     int c_nb = 0, c_cs[2] = {0, 0};
     uint32_t c_b[2] = {0, 0};
-    if (PASS == 2) {
-        D = a.part_net[row];                   // distance at the chunk's start
-        bool keep = false;
-        if (have) {
-            best = a.best[sidx];
-            dfx = a.delta_fx[sidx];
-            deg = a.degree[r];
-            bucket = min((uint32_t)a.start[r] / a.bin_size, EPP_BINS - 1);
-            const uint64_t eb = a.epp_base[r];
-            keep = eb != ~0ull;
-            list_at = eb + a.part_cnt[row];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+        D[q] = 0; mn[q] = INT_INF; cnt[q] = 0;
+        best[q] = INT_INF;                     // slots without a read never match
+        dfx[q] = 0; deg[q] = 0; bucket[q] = 0; list_at[q] = 0;
+        open_mask[q] = 0; list_mask[q] = 0; c_t[q] = 0; c_on[q] = 0;
+        if (PASS == 2) {
+            D[q] = a.part_net[row0 + q * 64];  // distance at the chunk's start
+            bool keep = false;
+            if (have[q]) {
+                best[q] = a.best[sidx[q]];
+                dfx[q] = a.delta_fx[sidx[q]];
+                deg[q] = a.degree[rd[q]];
+                bucket[q] = min((uint32_t)a.start[rd[q]] / a.bin_size, EPP_BINS - 1);
+                const uint64_t eb = a.epp_base[rd[q]];
+                keep = eb != ~0ull;
+                list_at[q] = eb + a.part_cnt[row0 + q * 64];
+            }
+            list_mask[q] = __ballot(keep);
         }
-        list_mask = __ballot(keep);
     }
 
-    // flips of pass 2: the lanes in `tmask` start (those also in `onmask`) or stop matching at node p
-    auto flip = [&](unsigned long long tmask, unsigned long long onmask, uint32_t p) {
-        // A mutation's enter and exit events usually flip the same lanes in opposite directions
+    // flips of pass 2: the reads in `tmask` start (those also in `onmask`) or stop matching at node p
+    auto flip = [&](const unsigned long long (&tmask)[RPL], const unsigned long long (&onmask)[RPL], uint32_t p) {
+        // A mutation's enter and exit events usually flip the same reads in opposite directions
         // (always when its node is a leaf): the sums of the previous flip are reused.
-        const bool same_dir = tmask == c_t && onmask == c_on;
-        const bool opp_dir = tmask == c_t && onmask == (c_t & ~c_on);
-        if (!(same_dir || opp_dir) || c_nb > 2) {
-            const bool t_l = (tmask >> lane) & 1ull, on_l = (onmask >> lane) & 1ull;
-            const long long vs = wave_sum_i64(t_l ? (on_l ? dfx : -dfx) : 0);
+        bool same_t = true, same_dir = true, opp_dir = true;
+#pragma unroll
+        for (int q = 0; q < RPL; q++) {
+            same_t = same_t && tmask[q] == c_t[q];
+            same_dir = same_dir && onmask[q] == c_on[q];
+            opp_dir = opp_dir && onmask[q] == (c_t[q] & ~c_on[q]);
+        }
+        if (!(same_t && (same_dir || opp_dir)) || c_nb > 2) {
+            long long v = 0;
+            bool t_l[RPL], on_l[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL; q++) {
+                t_l[q] = (tmask[q] >> lane) & 1ull;
+                on_l[q] = (onmask[q] >> lane) & 1ull;
+                v += t_l[q] ? (on_l[q] ? dfx[q] : -dfx[q]) : 0;
+            }
+            const long long vs = wave_sum_i64(v);
             c_vs = ((long long)__builtin_amdgcn_readfirstlane((int)(vs >> 32)) << 32) |
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vs);
             c_nb = 0;
             if (a.diff_cnt) {
-                const int cv = t_l ? (on_l ? deg : -deg) : 0;
-                unsigned long long pending = tmask;
-                while (pending) {
-                    const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bucket, __builtin_ctzll(pending));
-                    const bool same = t_l && bucket == bb;
-                    const int cs = __builtin_amdgcn_readfirstlane(wave_sum_i32(same ? cv : 0));
+                unsigned long long pending[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; q++) pending[q] = tmask[q];
+                while (true) {
+                    // bin of the first read still pending
+                    uint32_t bb = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = RPL - 1; q >= 0; q--)
+                        if (pending[q]) bb = (uint32_t)__builtin_amdgcn_readlane((int)bucket[q], __builtin_ctzll(pending[q]));
+                    if (bb == 0xFFFFFFFFu) break;
+                    int cv = 0;
+#pragma unroll
+                    for (int q = 0; q < RPL; q++) {
+                        const bool same = t_l[q] && bucket[q] == bb;
+                        cv += same ? (on_l[q] ? deg[q] : -deg[q]) : 0;
+                        pending[q] &= ~__ballot(same);
+                    }
+                    const int cs = __builtin_amdgcn_readfirstlane(wave_sum_i32(cv));
                     if (c_nb < 2) { c_b[c_nb] = bb; c_cs[c_nb] = cs; }
                     else if (lane == 0) atomicAdd(&a.diff_cnt[(size_t)p * EPP_BINS + bb], cs);
                     c_nb++;
-                    pending &= ~__ballot(same);
                 }
             }
-            c_t = tmask;
-            c_on = onmask;
-        } else if (opp_dir) {
+#pragma unroll
+            for (int q = 0; q < RPL; q++) { c_t[q] = tmask[q]; c_on[q] = onmask[q]; }
+        } else if (!same_dir) {
             c_vs = -c_vs;
             c_cs[0] = -c_cs[0];
             c_cs[1] = -c_cs[1];
-            c_on = onmask;
+#pragma unroll
+            for (int q = 0; q < RPL; q++) c_on[q] = onmask[q];
         }
         if (lane == 0) {
             atomicAdd(&a.diff_score[p], (unsigned long long)c_vs);
@@ -314,25 +358,40 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
         }
     };
 
-    // the nodes [p_prev, p) carry the current distance
+    // the nodes [p_prev, p) carry the current distances
     auto credit = [&](uint32_t p) {
         const uint32_t gap = p - p_prev;
         if (gap == 0) return;
         if (PASS == 1) {
-            cnt = D < mn ? 0u : cnt;
-            mn = min(mn, D);
-            cnt += D == mn ? gap : 0u;
-        } else {
-            const unsigned long long match_mask = __ballot(D == best);
-            const unsigned long long tmask = match_mask ^ open_mask;
-            if (tmask) {
-                flip(tmask, tmask & match_mask, p_prev);
-                open_mask = match_mask;
+#pragma unroll
+            for (int q = 0; q < RPL; q++) {
+                cnt[q] = D[q] < mn[q] ? 0u : cnt[q];
+                mn[q] = min(mn[q], D[q]);
+                cnt[q] += D[q] == mn[q] ? gap : 0u;
             }
-            if (match_mask & list_mask) {
-                if (((match_mask & list_mask) >> lane) & 1ull) {
-                    for (uint32_t q = 0; q < gap; q++) a.epp_nodes[list_at + q] = p_prev + q;
-                    list_at += gap;
+        } else {
+            unsigned long long match_mask[RPL], tmask[RPL], onmask[RPL];
+            unsigned long long any_t = 0, any_l = 0;
+#pragma unroll
+            for (int q = 0; q < RPL; q++) {
+                match_mask[q] = __ballot(D[q] == best[q]);
+                tmask[q] = match_mask[q] ^ open_mask[q];
+                onmask[q] = tmask[q] & match_mask[q];
+                any_t |= tmask[q];
+                any_l |= match_mask[q] & list_mask[q];
+            }
+            if (any_t) {
+                flip(tmask, onmask, p_prev);
+#pragma unroll
+                for (int q = 0; q < RPL; q++) open_mask[q] = match_mask[q];
+            }
+            if (any_l) {
+#pragma unroll
+                for (int q = 0; q < RPL; q++) {
+                    if (((match_mask[q] & list_mask[q]) >> lane) & 1ull) {
+                        for (uint32_t x = 0; x < gap; x++) a.epp_nodes[list_at[q] + x] = p_prev + x;
+                        list_at[q] += gap;
+                    }
                 }
             }
         }
@@ -376,37 +435,49 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
             credit(ep);
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)c_pos, (int)j);
             const uint32_t ei = (uint32_t)__builtin_amdgcn_readlane((int)c_info, (int)j);
-            const uint32_t o = pos - rs;
-            const bool in_win = o <= span_r;                   // only inside the read's own window (:56,60)
-            int d = (int)(int8_t)(ei & 0xFF);
+            const int dref = (int)(int8_t)(ei & 0xFF);
             if ((m_hit >> j) & 1ull) {
-                // some read of the tile lists this position: each lane looks its own allele up
-                const uint32_t oo = in_win ? o : 0;
-                const uint32_t al = (tab[(oo >> 3) * 64 + lane] >> ((oo & 7) * 4)) & 15u;
+                // some read of the tile lists this position: each read looks its own allele up
                 const uint32_t mut = (ei >> 8) & 15u, pare = (ei >> 12) & 15u;
-                int dl = (int)(mut != al) - (int)(pare != al);
-                if ((ei >> 16) & 1u) dl = -dl;
-                dl = al == 15u ? 0 : dl;                       // N matches anything (:68)
-                d = al ? dl : d;
+#pragma unroll
+                for (int q = 0; q < RPL; q++) {
+                    const uint32_t o = pos - rs[q];
+                    const bool in_win = o <= span_r[q];        // only inside the read's own window (:56,60)
+                    const uint32_t oo = in_win ? o : 0;
+                    const uint32_t al = (tab[((oo >> 3) * RPL + q) * 64 + lane] >> ((oo & 7) * 4)) & 15u;
+                    int dl = (int)(mut != al) - (int)(pare != al);
+                    if ((ei >> 16) & 1u) dl = -dl;
+                    dl = al == 15u ? 0 : dl;                   // N matches anything (:68)
+                    const int d = al ? dl : dref;
+                    D[q] += in_win ? d : 0;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RPL; q++) D[q] += (pos - rs[q] <= span_r[q]) ? dref : 0;
             }
-            D += in_win ? d : 0;
         }
     }
     credit(p_end);
     if (PASS == 1) {
-        a.part_min[row] = mn;
-        a.part_cnt[row] = cnt;
-        a.part_net[row] = D;
-    } else if (open_mask) {
-        flip(open_mask, 0ull, p_end);          // ranges still open at the chunk's end stop at its last node
+#pragma unroll
+        for (int q = 0; q < RPL; q++) {
+            a.part_min[row0 + q * 64] = mn[q];
+            a.part_cnt[row0 + q * 64] = cnt[q];
+            a.part_net[row0 + q * 64] = D[q];
+        }
+    } else {
+        unsigned long long any_o = 0, zero[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; q++) { any_o |= open_mask[q]; zero[q] = 0; }
+        if (any_o) flip(open_mask, zero, p_end);   // ranges still open at the chunk's end stop at its last node
     }
 }
 
 // one thread per sorted read
-__global__ __launch_bounds__(256) void k_epp_combine(EppSweepArgs a, uint32_t tiles_per_group) {
+__global__ __launch_bounds__(256) void k_epp_combine(EppSweepArgs a, uint32_t tiles_per_group, uint32_t rpl) {
     const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (sidx >= a.R) return;
-    const uint32_t t = sidx >> 6, lane = sidx & 63;
+    const uint32_t t = sidx / (64 * rpl), q = (sidx / 64) % rpl, lane = sidx & 63;
     const EppGroup gr = a.groups[t / tiles_per_group];
     const uint32_t tl = t - gr.tile0;
     const uint32_t r = a.order[sidx];
@@ -416,7 +487,7 @@ __global__ __launch_bounds__(256) void k_epp_combine(EppSweepArgs a, uint32_t ti
     int best = INT_INF;
     uint32_t mult = 0;
     for (uint32_t c = 0; c < gr.nchunks; c++) {
-        const size_t row = ((size_t)gr.job0 + (size_t)c * gr.ntiles + tl) * 64 + lane;
+        const size_t row = (((size_t)gr.job0 + (size_t)c * gr.ntiles + tl) * rpl + q) * 64 + lane;
         const int mn = a.part_min[row];
         if (mn != INT_INF) {
             const int v = D + mn;
@@ -429,7 +500,7 @@ __global__ __launch_bounds__(256) void k_epp_combine(EppSweepArgs a, uint32_t ti
     }
     uint32_t cursor = 0;
     for (uint32_t c = 0; c < gr.nchunks; c++) {
-        const size_t row = ((size_t)gr.job0 + (size_t)c * gr.ntiles + tl) * 64 + lane;
+        const size_t row = (((size_t)gr.job0 + (size_t)c * gr.ntiles + tl) * rpl + q) * 64 + lane;
         const int mn = a.part_min[row];
         const uint32_t cn = a.part_cnt[row];
         a.part_cnt[row] = cursor;
@@ -593,23 +664,23 @@ hipError_t launch_epp_select_scatter(const uint32_t* ev_word, const uint32_t* ev
                        G, nblk, cnt, st_word, st_node);
     return hipGetLastError();
 }
-hipError_t launch_epp_sweep(const EppSweepArgs& a, int pass, uint32_t lds_bytes, hipStream_t stream) {
-    if (a.n_jobs == 0) return hipSuccess;
-    hipError_t e;
-    if (pass == 1) {
-        e = hipFuncSetAttribute((const void*)k_epp_sweep<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_epp_sweep<1>, dim3(a.n_jobs), dim3(64), lds_bytes, stream, a);
-    } else {
-        e = hipFuncSetAttribute((const void*)k_epp_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_epp_sweep<2>, dim3(a.n_jobs), dim3(64), lds_bytes, stream, a);
-    }
+template <int PASS, int RPL>
+static hipError_t launch_sweep_variant(const EppSweepArgs& a, uint32_t lds_bytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_epp_sweep<PASS, RPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_epp_sweep<PASS, RPL>), dim3(a.n_jobs), dim3(64), lds_bytes, stream, a);
     return hipGetLastError();
 }
-hipError_t launch_epp_combine(const EppSweepArgs& a, uint32_t tiles_per_group, hipStream_t stream) {
+hipError_t launch_epp_sweep(const EppSweepArgs& a, int pass, uint32_t rpl, uint32_t lds_bytes, hipStream_t stream) {
+    if (a.n_jobs == 0) return hipSuccess;
+    if (rpl == 1) return pass == 1 ? launch_sweep_variant<1, 1>(a, lds_bytes, stream) : launch_sweep_variant<2, 1>(a, lds_bytes, stream);
+    if (rpl == 4) return pass == 1 ? launch_sweep_variant<1, 4>(a, lds_bytes, stream) : launch_sweep_variant<2, 4>(a, lds_bytes, stream);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_epp_combine(const EppSweepArgs& a, uint32_t tiles_per_group, uint32_t rpl, hipStream_t stream) {
     if (a.R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_epp_combine, dim3((a.R + 255) / 256), dim3(256), 0, stream, a, tiles_per_group);
+    hipLaunchKernelGGL(k_epp_combine, dim3((a.R + 255) / 256), dim3(256), 0, stream, a, tiles_per_group, rpl);
     return hipGetLastError();
 }
 size_t epp_finish_scratch_bytes(uint32_t N) {
