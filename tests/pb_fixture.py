@@ -112,3 +112,45 @@ def write_vcf(path, sample_names, samples, compress=False):
         lines.append(f"NC_045512v2\t{p}\t.\t{NUC[row['ref']]}\t{alts}\t.\t.\t.\tGT\t{gts}")
     data = ("\n".join(lines) + "\n").encode()
     (gzip.open if compress else open)(path, "wb").write(data)
+
+
+def _sam_schema():
+    """/root/reference/sam.proto (package Sam) declared at run time."""
+    fd = descriptor_pb2.FileDescriptorProto()
+    fd.name = "sam.proto"
+    fd.package = "Sam"
+    fd.syntax = "proto3"
+    O, R = _F.LABEL_OPTIONAL, _F.LABEL_REPEATED
+
+    def msg(name, fields):
+        m = fd.message_type.add()
+        m.name = name
+        for (fname, num, ftype, label, tname) in fields:
+            f = m.field.add()
+            f.name, f.number, f.type, f.label = fname, num, ftype, label
+            if tname:
+                f.type_name = tname
+    msg("read_info", [("read", 1, _F.TYPE_STRING, O, ""), ("start_idx", 3, _F.TYPE_INT32, O, ""),
+                      ("content", 6, _F.TYPE_STRING, O, ""), ("degree", 5, _F.TYPE_INT32, O, "")])
+    msg("column_info", [("column_name", 1, _F.TYPE_STRING, O, ""), ("input_columns", 2, _F.TYPE_STRING, R, "")])
+    msg("sam", [("reads", 1, _F.TYPE_MESSAGE, R, ".Sam.read_info"), ("reverse_columns", 2, _F.TYPE_MESSAGE, R, ".Sam.column_info")])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("Sam.sam"))
+
+
+Sam = _sam_schema()
+
+
+def write_reads_pb(path, reads, reverse_columns=None):
+    """reads = list of (name, start_idx (1-based), content over ACGTN_, degree), the message
+    `wepp sam2PB` writes (sam::dump_proto, src/WEPP/sam2pb.cpp:111-147)."""
+    d = Sam()
+    for (name, start, content, degree) in reads:
+        r = d.reads.add()
+        r.read, r.start_idx, r.content, r.degree = name, int(start), content, int(degree)
+    for col, inputs in (reverse_columns or {}).items():
+        c = d.reverse_columns.add()
+        c.column_name = col
+        c.input_columns.extend(inputs)
+    open(path, "wb").write(d.SerializeToString())

@@ -1,6 +1,7 @@
 // mat.cpp -- see mat.hpp.  Independent implementation of the reference's MAT
 // interface subset (citations are to /root/reference/src/mutation_annotated_tree.cpp).
 #include "mat.hpp"
+#include "pbwire.hpp"
 
 #include <zlib.h>
 
@@ -155,6 +156,32 @@ std::vector<Node*> Tree::depth_first_expansion(Node* node) const {
 }
 
 // ---- strings --------------------------------------------------------------------
+void Tree::uncondense_leaves() {
+    for (auto& cn : condensed_nodes) {
+        Node* n = get_node(cn.first);
+        if (!n) continue;
+        Node* par = n->parent ? n->parent : n;
+        const size_t num_samples = cn.second.size();
+        if (num_samples > 1 && !n->mutations.empty()) {
+            all_nodes.erase(n->identifier);
+            n->identifier = new_internal_node_id();
+            all_nodes[n->identifier] = n;
+            for (size_t s = 0; s < num_samples; s++) create_node(cn.second[s], n, -1.0f);
+        } else if (num_samples > 1) {
+            all_nodes.erase(n->identifier);
+            n->identifier = cn.second[0];
+            all_nodes[n->identifier] = n;
+            for (size_t s = 1; s < num_samples; s++) create_node(cn.second[s], par, n->branch_length);
+        } else if (num_samples == 1) {
+            all_nodes.erase(n->identifier);
+            n->identifier = cn.second[0];
+            all_nodes[n->identifier] = n;
+        }
+    }
+    condensed_nodes.clear();
+    condensed_leaves.clear();
+}
+
 void string_split(std::string const& s, char delim, std::vector<std::string>& words) {
     size_t start = 0;
     for (;;) {
@@ -242,54 +269,12 @@ std::string get_newick_string(const Tree& T) {
     return out + ";";
 }
 
-// ---- file helpers -------------------------------------------------------------------
-static std::string slurp(std::string const& filename, const char* what) {
-    // gzopen reads plain files transparently, so one path serves .pb and .pb.gz / .vcf and .vcf.gz
-    gzFile f = gzopen(filename.c_str(), "rb");
-    if (!f) throw mat_error(std::string("ERROR: Could not open the ") + what + " file: " + filename + "!");
-    std::string data;
-    char buf[1 << 16];
-    int got;
-    while ((got = gzread(f, buf, sizeof buf)) > 0) data.append(buf, (size_t)got);
-    gzclose(f);
-    if (got < 0) throw mat_error(std::string("ERROR: Could not read the ") + what + " file: " + filename + "!");
-    return data;
-}
-
 // ---- protobuf wire format (parsimony.proto) ---------------------------------------------
+using pbwire::slurp;
+using pbwire::Wire;
+using pbwire::put_varint;
+using pbwire::put_len;
 namespace {
-struct Wire {
-    const uint8_t* p;
-    const uint8_t* end;
-    bool eof() const { return p >= end; }
-    uint64_t varint() {
-        uint64_t v = 0;
-        for (int shift = 0; shift < 64; shift += 7) {
-            if (p >= end) throw mat_error("truncated varint in .pb");
-            uint8_t b = *p++;
-            v |= (uint64_t)(b & 0x7F) << shift;
-            if (!(b & 0x80)) return v;
-        }
-        throw mat_error("malformed varint in .pb");
-    }
-    Wire sub() {
-        uint64_t len = varint();
-        if (len > (uint64_t)(end - p)) throw mat_error("truncated field in .pb");
-        Wire w{p, p + len};
-        p += len;
-        return w;
-    }
-    void skip(uint32_t wt) {
-        switch (wt) {
-        case 0: varint(); break;
-        case 1: if (end - p < 8) throw mat_error("truncated .pb"); p += 8; break;
-        case 2: sub(); break;
-        case 5: if (end - p < 4) throw mat_error("truncated .pb"); p += 4; break;
-        default: throw mat_error("unsupported wire type in .pb");
-        }
-    }
-};
-
 struct PbMut { int32_t position = 0, ref_nuc = 0, par_nuc = 0; std::vector<int8_t> mut_nuc; std::string chrom; };
 
 PbMut parse_mut(Wire w) {
@@ -308,15 +293,6 @@ PbMut parse_mut(Wire w) {
     return m;
 }
 
-void put_varint(std::string& o, uint64_t v) {
-    while (v >= 0x80) { o.push_back((char)(v | 0x80)); v >>= 7; }
-    o.push_back((char)v);
-}
-void put_len(std::string& o, uint32_t field, const std::string& payload) {
-    put_varint(o, (field << 3) | 2);
-    put_varint(o, payload.size());
-    o += payload;
-}
 }  // namespace
 
 Tree load_mutation_annotated_tree(std::string const& filename) {

@@ -75,6 +75,8 @@ class Tree {   // mutation_annotated_tree.hpp:104-152
     std::vector<Node*> breadth_first_expansion(std::string nid = "") const;
     std::vector<Node*> depth_first_expansion(Node* node = nullptr) const;   // also sets dfs_idx / dfs_end_idx
     size_t size() const { return all_nodes.size(); }
+    // condensed identical-sequence leaves back into separate leaves (mutation_annotated_tree.cpp:1224-1272)
+    void uncondense_leaves();
 
   private:
     std::unordered_map<std::string, Node*> all_nodes;
