@@ -71,3 +71,46 @@ def test_two_rank_sharded_placement_equals_unsharded(tmp_path, oracle):
     assert (got["best_bfs_j"] == want["best_j"]).all()
     assert (got["num_best"] == want["num_best"]).all()
     assert (got["flags"] == want["has_unique"]).all()
+
+
+def _epp_worker(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import epp_model
+    from wepp_amd.sharding import epp_allreduce, shard_epp_reads
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = w.generate_tree(41, 600, genome_len=800)
+    reads = g.reads(42, 90, read_len=100, amplicon_len=200, amplicon_step=150, p_substitution=0.01, p_n=0.02,
+                    windows=True, max_degree=4)
+    mine = shard_epp_reads(reads, rank, world)
+    fv = w.FlatView(g.tree)
+    local = epp_model.epp_map(fv.get("epp_word"), fv.get("epp_node"), g.tree.n_nodes, mine, 800)
+    full = epp_allreduce(local, mine, 800, dist)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(dict(mp=local["max_parsimony"], mult=local["multiplicity"]), gathered, dst=0)
+    if rank == 0:
+        np.savez(out_path, score=full["score"], counts=full["counts"], divergence=full["divergence"],
+                 mp=np.concatenate([x["mp"] for x in gathered]), mult=np.concatenate([x["mult"] for x in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_epp_allreduce_equals_unsharded_oracle(tmp_path, oracle):
+    """cartesian_map sharded over reads: two gloo ranks map their halves (Python model of the
+    sweep standing in for the GPU), all-reduce the per-haplotype scores / read counts, and the
+    result equals the oracle's unsharded run."""
+    out = str(tmp_path / "epp.npz")
+    port = 29500 + (os.getpid() % 2000) + 1
+    mp.spawn(_epp_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    g = w.generate_tree(41, 600, genome_len=800)
+    reads = g.reads(42, 90, read_len=100, amplicon_len=200, amplicon_step=150, p_substitution=0.01, p_n=0.02,
+                    windows=True, max_degree=4)
+    want = oracle.OracleTree(g.tree).epp_map(reads, genome_size=800)
+    assert (got["mp"] == want["max_parsimony"]).all() and (got["mult"] == want["multiplicity"]).all()
+    assert np.allclose(got["score"], want["score"], rtol=1e-12, atol=1e-15)
+    assert (got["counts"] == want["counts"]).all()
+    assert np.array_equal(got["divergence"], want["divergence"], equal_nan=True)

@@ -5,6 +5,12 @@ src/usher_common.cpp:649), so rank g of W places the contiguous slice
 [R*g/W, R*(g+1)/W) against its own replica of the MAT and the per-rank results
 are concatenated in rank order on the host.  There is no data-path collective;
 torch.distributed (RCCL or gloo) is used only to gather the small result arrays.
+
+WEPP's own placer (wepp_filter::cartesian_map, src/WEPP/initial_filter.cpp:140-239) is
+different: reads still shard, but every read adds to the scores and per-bin read counts of
+the haplotypes it maps to, so the per-haplotype arrays of the ranks must be SUMMED -- the one
+real exchange step on these paths, an all-reduce (RCCL over xGMI on GPUs) of N doubles and
+N x 50 ints (epp_allreduce below).
 """
 import numpy as np
 
@@ -39,3 +45,46 @@ def gather_results(local, dist=None, dst=0):
     if dist.get_rank() != dst:
         return None
     return {f: np.concatenate([g[f] for g in gathered]) for f in RESULT_FIELDS}
+
+
+def shard_epp_reads(reads, rank, world):
+    """Contiguous shard of an EppReads batch."""
+    from .api import EppReads
+    lo, hi = shard_bounds(reads.n_reads, rank, world)
+    base = reads.slice(lo, hi)
+    return EppReads(base.read_off, base.read_word, reads.start[lo:hi], reads.end[lo:hi], reads.degree[lo:hi])
+
+
+def epp_true_read_counts(reads, genome_size):
+    """arena::build_range_trees, src/WEPP/arena.cpp:137-147: degrees per read-start bin."""
+    bins = np.minimum(reads.start // (genome_size // 50), 49)
+    return np.bincount(bins, weights=reads.degree, minlength=50).astype(np.int64)
+
+
+def epp_divergence(counts, true_counts):
+    """haplotype::dist_divergence, src/WEPP/initial_filter.cpp:224-233."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        prop = counts.astype(np.float64) / true_counts.astype(np.float64)[None, :]
+        over = np.count_nonzero(prop > 0.5 / 100, axis=1)
+        return over / np.float64(np.count_nonzero(true_counts))
+
+
+def epp_allreduce(local, local_reads, genome_size, dist=None, device=None):
+    """Combine the per-rank results of Mat.epp_map(shard, ..., want_counts=True) into the
+    whole-batch haplotype arrays on every rank: score and mapped_read_counts are summed over
+    the ranks (all-reduce; on `device` when the backend is RCCL), the divergence is recomputed
+    from the summed counts.  Per-read arrays stay per shard (gather_results-style
+    concatenation is the caller's choice).  `dist` = initialised torch.distributed or None."""
+    true_counts = epp_true_read_counts(local_reads, genome_size)
+    score, counts = np.array(local["score"], np.float64), np.array(local["counts"], np.int32)
+    if dist is not None and dist.get_world_size() > 1:
+        import torch
+        dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+        ts = torch.from_numpy(score).to(dev)
+        tc = torch.from_numpy(counts).to(dev)
+        tt = torch.from_numpy(true_counts).to(dev)
+        dist.all_reduce(ts)
+        dist.all_reduce(tc)
+        dist.all_reduce(tt)
+        score, counts, true_counts = ts.cpu().numpy(), tc.cpu().numpy(), tt.cpu().numpy()
+    return dict(score=score, counts=counts, divergence=epp_divergence(counts, true_counts), true_read_counts=true_counts)
