@@ -143,6 +143,24 @@ int wepp_imputed_mutations(wepp_mat_t *mat, const uint32_t *read_off, const uint
                            uint32_t n_reads, const uint32_t *best_bfs_j, uint32_t *imp_off,
                            int32_t *imp_pos, uint8_t *imp_nuc, uint64_t capacity);
 
+/* ---- excess mutations of (sample, node) pairs --------------------------------------- *
+ * node_excess_mutations[j] as mapper2_body appends it with compute_vecs for sample
+ * pair_read[i] at the node with BFS index pair_bfs_j[i]: first the node's own mutations the
+ * sample shares (src/usher_mapper.cpp:223-228, :253-258), then the sample's own alleles the
+ * node's genotype does not offer (:357-388, sample order), then back-mutations to the
+ * reference (:394-446, position order).  usher prints the first `score` entries for the
+ * optimal nodes in the last column of parsimony-scores.tsv (src/usher_common.cpp:555-574).
+ * exc_off[n_pairs + 1] is the CSR over the pairs; entry q is
+ * MAT::Mutation{position exc_pos[q], ref_nuc exc_ref[q], par_nuc exc_par[q], mut_nuc exc_mut[q]};
+ * par_nuc of a node's own mutation is the true parent allele (what Mutation::par_nuc holds
+ * in a consistent MAT).  WEPP_ELIMIT (exc_off filled with the needed sizes) when capacity is
+ * too small.  Not listed: masked root mutations that carry non-zero nucleotides (the .pb
+ * loader zeroes them, src/mutation_annotated_tree.cpp:566-571). */
+int wepp_excess_mutations(wepp_mat_t *mat, const uint32_t *read_off, const uint32_t *read_word, uint32_t n_reads,
+                          uint32_t n_pairs, const uint32_t *pair_read, const uint32_t *pair_bfs_j,
+                          uint64_t *exc_off, int32_t *exc_pos, uint8_t *exc_ref, uint8_t *exc_par, uint8_t *exc_mut,
+                          uint64_t capacity);
+
 /* Same computation with every buffer already resident on the handle's device
  * (device pointers); work is enqueued on `hip_stream` (a hipStream_t, NULL =
  * the default stream) and NOT synchronised on return.  n_read_words =

@@ -16,9 +16,9 @@
  * restatement of the cited reference code.
  *
  * What is restated (file:line relative to /root/reference/src):
- *   o_mapper2_body()      usher_mapper.cpp:168-506  (mapper2_body, score path;
- *                         the excess/imputed mutation vectors of
- *                         compute_vecs=true are not produced)
+ *   o_mapper2_body()      usher_mapper.cpp:168-506  (mapper2_body; the excess / imputed
+ *                         mutation vectors of compute_vecs=true are filled when the
+ *                         caller provides them)
  *   o_place_sample()      usher_common.cpp:339-446  (per-sample loop: BFS
  *                         expansion, initial best state :364-381, pass 1
  *                         :386-411, pass 2 :413-446)
@@ -167,6 +167,8 @@ typedef struct {
     int *has_unique;
     omut *imputed_mutations;    /* compute_vecs: std::vector<MAT::Mutation>* (capacity >= |S|), or NULL */
     int *n_imputed;
+    omut *excess_mutations;     /* compute_vecs: std::vector<MAT::Mutation>* (capacity >= |S| + path), or NULL */
+    int *n_excess;
 } o_mapper2_input;
 
 typedef struct { omut *v; int n, cap; int *pos; } anc_vec;
@@ -238,6 +240,8 @@ static void o_mapper2_body(o_mapper2_input *input, int compute_parsimony_scores,
                             m.mut_nuc = anc_nuc;
                             m.is_missing = 0;
                             anc_push(anc, &m);                 /* :223-224 */
+                            if (input->imputed_mutations != NULL && input->excess_mutations)      /* :226-228 */
+                                input->excess_mutations[(*input->n_excess)++] = m;
                             found = 1;
                             num_common_mut++;
                             break;
@@ -255,6 +259,8 @@ static void o_mapper2_body(o_mapper2_input *input, int compute_parsimony_scores,
                     m.mut_nuc = anc_nuc;
                     m.is_missing = 0;
                     anc_push(anc, &m);                         /* :253-254 */
+                    if (input->imputed_mutations != NULL && input->excess_mutations)              /* :256-258 */
+                        input->excess_mutations[(*input->n_excess)++] = m;
                     num_common_mut++;
                 } else {
                     has_unique = 1;
@@ -330,6 +336,7 @@ static void o_mapper2_body(o_mapper2_input *input, int compute_parsimony_scores,
             if (compute_vecs && ((m1.mut_nuc & (m1.mut_nuc - 1)) != 0))            /* :376-378 */
                 input->imputed_mutations[(*input->n_imputed)++] = m;
             if (m.mut_nuc != m.par_nuc) {                      /* :379 */
+                if (compute_vecs && input->excess_mutations) input->excess_mutations[(*input->n_excess)++] = m;   /* :380-382 */
                 set_difference += 1;
                 if (!compute_parsimony_scores && (set_difference > best_set_difference)) return;
             }
@@ -361,6 +368,8 @@ static void o_mapper2_body(o_mapper2_input *input, int compute_parsimony_scores,
             if (m.mut_nuc != m.par_nuc) {
                 set_difference += 1;
                 if (!compute_parsimony_scores && (set_difference > best_set_difference)) return;
+                if (input->imputed_mutations != NULL && input->excess_mutations)                      /* :440-442 */
+                    input->excess_mutations[(*input->n_excess)++] = m;
             }
         }
     }
@@ -443,6 +452,8 @@ static void fill_input(o_mapper2_input *inp, const otree *T, o_best_state *st, c
     inp->best_distance = &inp->distance;
     inp->imputed_mutations = NULL;
     inp->n_imputed = NULL;
+    inp->excess_mutations = NULL;
+    inp->n_excess = NULL;
 }
 
 /* One sample against the whole tree.  print_parsimony_scores != 0 reproduces
@@ -721,6 +732,43 @@ int oracle_imputed_at_node(const otree *T, int nS, const int32_t *s_pos, const u
     for (int i = 0; i < n_imp; i++) { out_pos[i] = imp[i].position; out_nuc[i] = (uint8_t)imp[i].mut_nuc; }
     free(scratch.v); free(scratch.pos); free(imp); free(nhu); free(st.best_j_vec.v); free(S);
     return n_imp;
+}
+
+/* node_excess_mutations[j] with compute_vecs = true (usher_common.cpp:393,411 in -p mode,
+ * :431,446 in pass 2), in the order mapper2_body appends: first the node's own mutations that
+ * the sample shares (usher_mapper.cpp:223-228, :253-258 -- not parsimony-increasing, but that is
+ * where the reference puts them), then the sample's own alleles the genotype does not offer
+ * (:357-388, in sample order), then the back-mutations to the reference (:394-446, in position
+ * order of the ancestral set).  Output capacity: nS + number of mutations on the root path. */
+int oracle_excess_at_node(const otree *T, int nS, const int32_t *s_pos, const uint8_t *s_ref,
+                          const uint8_t *s_mut, const uint8_t *s_missing, uint32_t j, int capacity,
+                          int32_t *out_pos, uint8_t *out_ref, uint8_t *out_par, uint8_t *out_mut) {
+    omut *S = (omut *)calloc((size_t)(nS ? nS : 1), sizeof(omut));
+    for (int i = 0; i < nS; i++) {
+        S[i].position = s_pos[i]; S[i].ref_nuc = (int8_t)s_ref[i]; S[i].par_nuc = (int8_t)s_ref[i];
+        S[i].mut_nuc = (int8_t)s_mut[i]; S[i].is_missing = s_missing[i];
+    }
+    o_best_state st;
+    uint8_t *nhu = (uint8_t *)calloc((size_t)T->n, 1);
+    np_state_init(&st, T, nS, nhu);
+    st.best_set_difference = 0x3fffffff;
+    omut *imp = (omut *)calloc((size_t)(nS ? nS : 1), sizeof(omut));
+    omut *exc = (omut *)calloc((size_t)(capacity > 0 ? capacity : 1), sizeof(omut));
+    int n_imp = 0, n_exc = 0;
+    anc_vec scratch = {0, 0, 0, 0};
+    o_mapper2_input inp;
+    fill_input(&inp, T, &st, S, nS, j, NULL);
+    inp.imputed_mutations = imp;
+    inp.n_imputed = &n_imp;
+    inp.excess_mutations = exc;
+    inp.n_excess = &n_exc;
+    o_mapper2_body(&inp, 0, &scratch);
+    for (int i = 0; i < n_exc; i++) {
+        out_pos[i] = exc[i].position; out_ref[i] = (uint8_t)exc[i].ref_nuc; out_par[i] = (uint8_t)exc[i].par_nuc;
+        out_mut[i] = (uint8_t)exc[i].mut_nuc;
+    }
+    free(scratch.v); free(scratch.pos); free(imp); free(exc); free(nhu); free(st.best_j_vec.v); free(S);
+    return n_exc;
 }
 
 /* ======================================================================== *

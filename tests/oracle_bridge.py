@@ -47,6 +47,8 @@ def lib():
         L.oracle_place_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         L.oracle_imputed_at_node.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_excess_at_node.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [
+            ctypes.c_uint32, ctypes.c_int] + [ctypes.c_void_p] * 4
         L.oracle_mapper_body.argtypes = [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_int] + [ctypes.c_void_p] * 5
         L.oracle_place_batch_nodepar.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         L.oracle_epp_map.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32] + [ctypes.c_void_p] * 12 + [
@@ -129,6 +131,18 @@ class OracleTree:
         c = lib().oracle_imputed_at_node(self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8),
                                          _p(missing if n else z8), int(bfs_j), _p(op), _p(on))
         return list(zip(op[:c].tolist(), on[:c].tolist()))
+
+    def excess_at_node(self, pos, ref, mut, missing, bfs_j, capacity=4096):
+        """node_excess_mutations[bfs_j] with compute_vecs: list of (position, ref, par, mut)."""
+        pos = np.ascontiguousarray(pos, np.int32); ref = np.ascontiguousarray(ref, np.uint8)
+        mut = np.ascontiguousarray(mut, np.uint8); missing = np.ascontiguousarray(missing, np.uint8)
+        n = len(pos)
+        op = np.zeros(capacity, np.int32); orf = np.zeros(capacity, np.uint8)
+        opa = np.zeros(capacity, np.uint8); om = np.zeros(capacity, np.uint8)
+        z32 = np.zeros(1, np.int32); z8 = np.zeros(1, np.uint8)
+        c = lib().oracle_excess_at_node(self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8),
+                                        _p(missing if n else z8), int(bfs_j), capacity, _p(op), _p(orf), _p(opa), _p(om))
+        return list(zip(op[:c].tolist(), orf[:c].tolist(), opa[:c].tolist(), om[:c].tolist()))
 
     def mapper_body(self, ref_nuc, var_node, var_nuc):
         """One VCF row through the Fitch-Sankoff mapper_body: list of (node id, par_nuc, mut_nuc)."""

@@ -304,3 +304,35 @@ def test_full_size_properties(oracle):
     assert (res.score[:6] == want["score"]).all() and (res.best_bfs_j[:6] == want["best_j"]).all()
     assert (res.num_best[:6] == want["num_best"]).all() and (res.has_unique[:6] == want["has_unique"]).all()
     mat.close()
+
+
+@pytest.mark.gpu
+def test_excess_mutations_vs_oracle(oracle):
+    """node_excess_mutations (usher_mapper.cpp:223-228, :253-258, :357-388, :394-446 with
+    compute_vecs) for every (sample, node) pair of small random trees: same mutations, same order."""
+    rng = np.random.default_rng(606)
+    n_lists = n_muts = 0
+    for it in range(25):
+        # masked root mutations with non-zero nucleotides are the documented exception
+        tree, ref = ft.random_tree(rng, p_root_masked=0.0)
+        samples = [ft.random_sample(rng, ref) for _ in range(6)]
+        reads = ft.reads_from_samples(samples)
+        mat = w.Mat(tree)
+        ot = oracle.OracleTree(tree)
+        n = tree.n_nodes
+        pr = np.repeat(np.arange(len(samples), dtype=np.uint32), n)
+        pj = np.tile(np.arange(n, dtype=np.uint32), len(samples))
+        got = mat.excess_mutations(reads, pr, pj)
+        for q, S in enumerate(samples):
+            cols = list(zip(*S)) if S else ([], [], [], [])
+            full = ot.place_sample(*cols, per_node_scores=True)
+            for j in range(n):
+                want = ot.excess_at_node(*cols, j)
+                assert got[q * n + j] == want, (it, q, j)
+                # shared mutations of the node first, then what the score counts (nodes that do not
+                # compete report score + 1, :500-505)
+                assert len(want) >= full["node_scores"][j] - 1
+                n_lists += 1
+                n_muts += len(want)
+        mat.close()
+    assert n_lists > 3000 and n_muts > 5000

@@ -173,3 +173,22 @@ def test_wepp_usher_end_to_end(tmp_path, oracle):
     assert [int(b[2]) for b in block] == o["node_scores"].tolist()
     assert [b[1] for b in block] == [newname[int(i)] for i in bfs]
     assert all((b[4] == "y") == (int(b[2]) == o["score"]) for b in block)
+    # last column: "N/A" for non-optimal nodes, "*" for a zero score, else the first `score` entries of
+    # node_excess_mutations as par+position+mut (usher_common.cpp:555-574, Mutation::get_string)
+    n_lists = 0
+    for q in range(40):
+        Sq = [_as_vcf_reader_sees(e) for e in samples[q]]
+        cols = list(zip(*Sq)) if Sq else ([], [], [], [])
+        oq = ot.place_sample(*cols, per_node_scores=True)
+        blk = [l.split("\t") for l in lines[1 + q * 300: 1 + (q + 1) * 300]]
+        for k, b in enumerate(blk):
+            sc = int(oq["node_scores"][k])
+            if sc != oq["score"]:
+                assert b[5] == "N/A"
+            elif sc == 0:
+                assert b[5] == "*"
+            else:
+                want = ot.excess_at_node(*cols, k)[:sc]
+                assert b[5] == ",".join(f"{pbf.NUC.get(pa, 'N')}{p}{pbf.NUC.get(mu, 'N')}" for (p, _, pa, mu) in want), (q, k)
+                n_lists += 1
+    assert n_lists > 40

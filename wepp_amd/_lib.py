@@ -114,6 +114,8 @@ _SIGS = {
     "wepp_mat_bfs_order": (ctypes.c_int, [_V, _V]),
     "wepp_place_batch": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, _V, _V, _V, _V, _V]),
     "wepp_imputed_mutations": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, _V, _V, _V, _V, ctypes.c_uint64]),
+    "wepp_excess_mutations": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, ctypes.c_uint32, _V, _V, _V, _V, _V, _V, _V,
+                                             ctypes.c_uint64]),
     "wepp_place_batch_device": (
         ctypes.c_int,
         [_V, _V, _V, ctypes.c_uint32, ctypes.c_uint64, _V, _V, _V, _V, _V],

@@ -333,6 +333,27 @@ class Mat:
             res.per_node_scores = pns
         return res
 
+    def excess_mutations(self, reads, pair_read, pair_bfs_j):
+        """wepp_excess_mutations: per (read, node) pair the list of (position, ref, par, mut)."""
+        pr = np.ascontiguousarray(pair_read, np.uint32); pj = np.ascontiguousarray(pair_bfs_j, np.uint32)
+        n = int(pr.shape[0])
+        off = np.zeros(n + 1, np.uint64)
+        rw = reads.read_word if reads.read_word.size else np.zeros(1, np.uint32)
+        cap = 0
+        while True:
+            pos = np.zeros(max(cap, 1), np.int32); ref = np.zeros(max(cap, 1), np.uint8)
+            par = np.zeros(max(cap, 1), np.uint8); mut = np.zeros(max(cap, 1), np.uint8)
+            rc = lib.wepp_excess_mutations(self._h, _ptr(reads.read_off), _ptr(rw), reads.n_reads, n, _ptr(pr), _ptr(pj),
+                                           _ptr(off), _ptr(pos), _ptr(ref), _ptr(par), _ptr(mut), cap)
+            if rc == 4 and int(off[n]) > cap:
+                cap = int(off[n])
+                continue
+            check(rc)
+            break
+        return [list(zip(pos[int(off[i]):int(off[i + 1])].tolist(), ref[int(off[i]):int(off[i + 1])].tolist(),
+                         par[int(off[i]):int(off[i + 1])].tolist(), mut[int(off[i]):int(off[i + 1])].tolist()))
+                for i in range(n)]
+
     def dfs_order(self):
         """Caller node id of the haplotype with arena (pre-order) index k."""
         out = np.zeros(self.n_nodes, np.uint32)

@@ -460,3 +460,66 @@ done:
     if (d_nuc) (void)hipFree(d_nuc);
     return rc;
 }
+
+extern "C" int wepp_excess_mutations(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word,
+                                     uint32_t n_reads, uint32_t n_pairs, const uint32_t* pair_read,
+                                     const uint32_t* pair_bfs_j, uint64_t* exc_off, int32_t* exc_pos, uint8_t* exc_ref,
+                                     uint8_t* exc_par, uint8_t* exc_mut, uint64_t capacity) {
+    if (!mat || !read_off || !exc_off) return set_error(WEPP_EINVAL, "null argument");
+    exc_off[0] = 0;
+    if (n_pairs == 0) return WEPP_OK;
+    if (!pair_read || !pair_bfs_j) return set_error(WEPP_EINVAL, "null argument");
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        if (pair_read[i] >= n_reads) return set_error(WEPP_EINVAL, "pair_read out of range");
+        if (pair_bfs_j[i] >= mat->dev.N) return set_error(WEPP_EINVAL, "pair_bfs_j out of range");
+    }
+    const uint64_t nw = read_off[n_reads];
+    if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
+    HIP_TRY(hipSetDevice(mat->device));
+    uint32_t *d_off = nullptr, *d_word = nullptr, *d_pr = nullptr, *d_pj = nullptr, *d_cnt = nullptr, *d_out = nullptr;
+    unsigned long long* d_ooff = nullptr;
+    std::vector<uint32_t> counts(n_pairs), packed;
+    std::vector<unsigned long long> ooff(n_pairs);
+    uint64_t total = 0;
+    int rc = WEPP_OK;
+    hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pr, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pj, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, (size_t)n_pairs * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ooff, (size_t)n_pairs * 8);
+    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
+    e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nw) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_pr, pair_read, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_pj, pair_bfs_j, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_excess(mat->dev, d_off, d_word, d_pr, d_pj, n_pairs, nullptr, d_cnt, nullptr, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(counts.data(), d_cnt, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = hip_fail(e, "excess-mutation count"); goto done; }
+    for (uint32_t i = 0; i < n_pairs; i++) { ooff[i] = total; total += counts[i]; exc_off[i + 1] = total; }
+    if (total > capacity) { rc = set_error(WEPP_ELIMIT, "excess-mutation buffers too small: need " + std::to_string(total)); goto done; }
+    if (total == 0) goto done;
+    if (!exc_pos || !exc_ref || !exc_par || !exc_mut) { rc = set_error(WEPP_EINVAL, "null output array"); goto done; }
+    e = hipMalloc((void**)&d_out, total * 4);
+    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
+    e = hipMemcpy(d_ooff, ooff.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_excess(mat->dev, d_off, d_word, d_pr, d_pj, n_pairs, d_ooff, d_cnt, d_out, nullptr);
+    packed.resize(total);
+    if (e == hipSuccess) e = hipMemcpy(packed.data(), d_out, total * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rc = hip_fail(e, "excess-mutation kernel"); goto done; }
+    for (uint64_t q = 0; q < total; q++) {
+        exc_pos[q] = (int32_t)(packed[q] & 0xFFFFFu);
+        exc_ref[q] = (uint8_t)((packed[q] >> 20) & 15u);
+        exc_par[q] = (uint8_t)((packed[q] >> 24) & 15u);
+        exc_mut[q] = (uint8_t)((packed[q] >> 28) & 15u);
+    }
+done:
+    if (d_off) (void)hipFree(d_off);
+    if (d_word) (void)hipFree(d_word);
+    if (d_pr) (void)hipFree(d_pr);
+    if (d_pj) (void)hipFree(d_pj);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (d_ooff) (void)hipFree(d_ooff);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}

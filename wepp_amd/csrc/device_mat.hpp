@@ -106,6 +106,11 @@ hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t*
 hipError_t launch_imputed(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
                           const uint32_t* d_best_bfs_j, const uint32_t* d_pairs, uint32_t n_pairs,
                           uint8_t* d_nuc, hipStream_t stream);
+// excess mutations of (read, node) pairs: d_out_off == nullptr counts into d_counts, else emits packed
+// words pos:20 | ref:4 | par:4 | mut:4 at d_out + d_out_off[pair]
+hipError_t launch_excess(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                         const uint32_t* d_pair_read, const uint32_t* d_pair_bfs_j, uint32_t n_pairs,
+                         const unsigned long long* d_out_off, uint32_t* d_counts, uint32_t* d_out, hipStream_t stream);
 hipError_t sweep_set_max_lds(uint32_t bytes);
 
 // layout of tier_info (uint32): [0..8) counts, [8..16) max entries of one read, [16..25) offsets into the list

@@ -831,6 +831,129 @@ __global__ void k_imputed(DevMAT m, const uint32_t* __restrict__ read_off, const
 }
 
 // -----------------------------------------------------------------------------
+// k_excess: node_excess_mutations of a (sample, node) pair as mapper2_body appends them with
+// compute_vecs -- usher prints the first `score` of them for the optimal nodes in the last
+// column of parsimony-scores.tsv (usher_common.cpp:555-574):
+//   (0) the node's own mutations the sample shares (usher_mapper.cpp:223-228, :253-258),
+//   (1) the sample's alleles that E does not offer, in sample order (:357-388),
+//   (2) E's non-reference alleles at positions the sample does not list, in position
+//       order (:394-446),
+// E = the genotype the scorer sees at the node: its own shared mutations (none when the node
+// is masked, all of them for the root), then the most recent mutation per position on the
+// path above.  One thread per pair, run twice: count, then emit at the offsets the host
+// derived from the counts.
+// -----------------------------------------------------------------------------
+namespace {
+// does the node's own mutation `tw` enter E for a sample entry `s` (NONE = position not listed)?
+__device__ __forceinline__ bool own_in_E(uint32_t tw, uint32_t s) {
+    if (s == NONE) return tw_mut(tw) == tw_ref(tw);                 // :245 back-mutation to the reference
+    return !rw_missing(s) && (rw_mut(s) & tw_mut(tw)) != 0;         // :211-216 (a missing base shares but is not recorded)
+}
+// allele of E at `pos` (0 = none); s = the sample's entry at pos or NONE
+__device__ uint32_t allele_of_E(const DevMAT& m, uint32_t d, uint32_t pos, uint32_t s) {
+    bool first = true;
+    for (;;) {
+        const uint32_t st = m.nstat[d];
+        const bool root = st & NS_ROOT_DEV;
+        if (!first || root || !(st & NS_MASKED_DEV)) {
+            for (uint32_t w = m.node_woff[d]; w < m.node_woff[d + 1]; w++) {
+                const uint32_t tw = m.words[w];
+                if (w_pos(tw) != pos) continue;
+                if (first && !root && !own_in_E(tw, s)) break;
+                return tw_mut(tw);
+            }
+        }
+        if (root) return 0;
+        d = m.parent_dfs[d];
+        first = false;
+    }
+}
+}  // namespace
+
+__global__ void k_excess(DevMAT m, const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                         const uint32_t* __restrict__ pair_read, const uint32_t* __restrict__ pair_bfs_j,
+                         uint32_t n_pairs, const unsigned long long* __restrict__ out_off, uint32_t* __restrict__ counts,
+                         uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const bool emit = out_off != nullptr;
+    uint32_t* o = emit ? out + out_off[i] : nullptr;
+    const uint32_t r = pair_read[i];
+    const uint32_t s0 = read_off[r], k = read_off[r + 1] - s0;
+    const uint32_t d0 = m.bfs2dfs[pair_bfs_j[i]];
+    const uint32_t st0 = m.nstat[d0];
+    const bool root0 = st0 & NS_ROOT_DEV;
+    uint32_t n = 0;
+    // (0) the node's own shared mutations
+    if (!root0 && !(st0 & NS_MASKED_DEV)) {
+        for (uint32_t w = m.node_woff[d0]; w < m.node_woff[d0 + 1]; w++) {
+            const uint32_t tw = m.words[w];
+            if (!own_in_E(tw, find_entry(read_word, s0, k, w_pos(tw)))) continue;
+            const uint32_t par = tw_par(tw) ? tw_par(tw) : tw_ref(tw);
+            if (emit) o[n] = w_pos(tw) | (tw_ref(tw) << 20) | (par << 24) | (tw_mut(tw) << 28);
+            n++;
+        }
+    }
+    // (1) the sample's own alleles
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t s = read_word[s0 + j];
+        if (rw_missing(s)) continue;
+        const uint32_t pos = w_pos(s), a = rw_mut(s), sref = rw_ref(s);
+        const uint32_t anc = allele_of_E(m, d0, pos, s);
+        const bool found_pos = anc != 0, found = found_pos && (a & anc) != 0, has_ref = (a & sref) != 0;
+        if (found || (!found_pos && has_ref)) continue;
+        const uint32_t mnuc = has_ref ? sref : (a & (0u - a));
+        const uint32_t par = found_pos ? anc : sref;
+        if (mnuc == par) continue;
+        if (emit) o[n] = pos | (sref << 20) | (par << 24) | (mnuc << 28);
+        n++;
+    }
+    // (2) back-mutations: E's alleles at positions the sample does not list
+    const uint32_t n1 = n;
+    uint32_t d = d0;
+    bool first = true;
+    for (;;) {
+        const uint32_t st = m.nstat[d];
+        const bool root = st & NS_ROOT_DEV;
+        if (!first || root || !(st & NS_MASKED_DEV)) {
+            for (uint32_t w = m.node_woff[d]; w < m.node_woff[d + 1]; w++) {
+                const uint32_t tw = m.words[w];
+                const uint32_t pos = w_pos(tw), mut = tw_mut(tw), ref = tw_ref(tw);
+                if (mut == ref) continue;                                   // :421
+                if (find_entry(read_word, s0, k, pos) != NONE) continue;   // :417-419, :423
+                if (first && !root) continue;     // an own mutation at an unlisted position is in E only as mut == ref
+                // E keeps the most recent mutation of a position only
+                bool earlier = false;
+                {
+                    uint32_t e = d0;
+                    bool ef = true;
+                    while (e != d && !earlier) {
+                        const uint32_t est = m.nstat[e];
+                        if (!ef || !(est & NS_MASKED_DEV))
+                            for (uint32_t x = m.node_woff[e]; x < m.node_woff[e + 1]; x++)
+                                if (w_pos(m.words[x]) == pos && (!ef || own_in_E(m.words[x], NONE))) earlier = true;
+                        e = m.parent_dfs[e];
+                        ef = false;
+                    }
+                }
+                if (earlier) continue;
+                if (emit) {
+                    // insertion by position among the back-mutations
+                    uint32_t q = n;
+                    while (q > n1 && (o[q - 1] & 0xFFFFFu) > pos) { o[q] = o[q - 1]; q--; }
+                    o[q] = pos | (ref << 20) | (mut << 24) | (ref << 28);
+                }
+                n++;
+            }
+        }
+        if (root) break;
+        d = m.parent_dfs[d];
+        first = false;
+    }
+    if (!emit) counts[i] = n;
+}
+
+// -----------------------------------------------------------------------------
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
@@ -918,6 +1041,15 @@ hipError_t launch_imputed(const DevMAT& m, const uint32_t* d_read_off, const uin
     if (n_pairs == 0) return hipSuccess;
     hipLaunchKernelGGL(k_imputed, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, m, d_read_off, d_read_word,
                        d_best_bfs_j, d_pairs, n_pairs, d_nuc);
+    return hipGetLastError();
+}
+
+hipError_t launch_excess(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                         const uint32_t* d_pair_read, const uint32_t* d_pair_bfs_j, uint32_t n_pairs,
+                         const unsigned long long* d_out_off, uint32_t* d_counts, uint32_t* d_out, hipStream_t stream) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_excess, dim3((n_pairs + 127) / 128), dim3(128), 0, stream, m, d_read_off, d_read_word,
+                       d_pair_read, d_pair_bfs_j, n_pairs, d_out_off, d_counts, d_out);
     return hipGetLastError();
 }
 

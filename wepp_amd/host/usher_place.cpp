@@ -97,6 +97,36 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
             return 1;
         }
     }
+    // excess mutations of the optimal nodes (last column of parsimony-scores.tsv, :555-574)
+    std::vector<uint64_t> exc_off(1, 0);
+    std::vector<int32_t> exc_pos;
+    std::vector<uint8_t> exc_ref, exc_par, exc_mut;
+    std::vector<size_t> exc_first(R + 1, 0);      // first pair of sample q (its optimal nodes in BFS order)
+    if (print_parsimony_scores) {
+        std::vector<uint32_t> pair_read, pair_node;
+        for (uint32_t q = 0; q < R; q++) {
+            exc_first[q] = pair_read.size();
+            const int32_t* nsd = node_sd.data() + (size_t)q * total_nodes;
+            for (size_t k = 0; k < total_nodes; k++)
+                if (nsd[k] == best_sd[q] && nsd[k] != 0) { pair_read.push_back(q); pair_node.push_back((uint32_t)k); }
+        }
+        exc_first[R] = pair_read.size();
+        exc_off.assign(pair_read.size() + 1, 0);
+        uint64_t cap = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            exc_pos.resize(cap + 1); exc_ref.resize(cap + 1); exc_par.resize(cap + 1); exc_mut.resize(cap + 1);
+            int rc = wepp_excess_mutations(mat, read_off.data(), read_word.data(), R, (uint32_t)pair_read.size(),
+                                           pair_read.data(), pair_node.data(), exc_off.data(), exc_pos.data(),
+                                           exc_ref.data(), exc_par.data(), exc_mut.data(), cap);
+            if (rc == WEPP_ELIMIT && attempt == 0 && exc_off.back() > cap) { cap = exc_off.back(); continue; }
+            if (rc != WEPP_OK) {
+                fprintf(stderr, "ERROR: %s\n", wepp_last_error());
+                wepp_mat_destroy(mat);
+                return 1;
+            }
+            break;
+        }
+    }
     wepp_mat_destroy(mat);
 
     FileCloser stats, scores;
@@ -164,12 +194,26 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
                     sample.c_str(), best_set_difference, nb);                                  // :468-469
             if (scores.f) {
                 const int32_t* nsd = node_sd.data() + (size_t)q * total_nodes;
+                size_t pair = exc_first[q];
                 for (size_t k = 0; k < total_nodes; k++) {                                     // :555-574
                     const bool optimal = nsd[k] == best_set_difference;
                     fprintf(scores.f, "%s\t%s\t%d\t\t%c\t", sample.c_str(), bfs[k]->identifier.c_str(), nsd[k], optimal ? 'y' : 'n');
                     if (!optimal) fprintf(scores.f, "N/A");
                     else if (nsd[k] == 0) fprintf(scores.f, "*");
-                    // the mutation list of a non-zero optimal node needs the pass-2 vectors (not produced yet)
+                    else {
+                        // the reference prints the first node_set_difference[k] entries of the vector (which
+                        // starts with the shared mutations of the node); it reads past the end when the
+                        // vector is shorter (a node that does not compete reports score + 1,
+                        // usher_mapper.cpp:500-505) -- here the loop stops at the end
+                        const uint64_t end = std::min<uint64_t>(exc_off[pair + 1], exc_off[pair] + (uint64_t)nsd[k]);
+                        for (uint64_t i = exc_off[pair]; i < end; i++) {
+                            MAT::Mutation m;
+                            m.position = exc_pos[i]; m.ref_nuc = (int8_t)exc_ref[i];
+                            m.par_nuc = (int8_t)exc_par[i]; m.mut_nuc = (int8_t)exc_mut[i];
+                            fprintf(scores.f, "%s%s", m.get_string().c_str(), i + 1 < end ? "," : "");
+                        }
+                        pair++;
+                    }
                     fprintf(scores.f, "\n");
                 }
             }
