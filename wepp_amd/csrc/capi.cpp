@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -98,6 +99,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         ds.cp_stride = st.cp_stride;
         ds.ncp = (uint32_t)st.cp_off.size() - 1;
         ds.eager = (i + 1 < f.streams.size()) ? 1u : 0u;
+        ds.tier = (uint32_t)i;
         UP(ds.nkey, st.nkey) UP(ds.nstat, st.nstat) UP(ds.blk_node0, st.blk_node0) UP(ds.blk_eoff, st.blk_eoff)
         UP(ds.blk_sum, st.blk_sum) UP(ds.ev_word, st.ev_word) UP(ds.ev_meta, st.ev_meta) UP(ds.ev_lb, st.ev_lb) UP(ds.cp_off, st.cp_off)
         UP(ds.cp_word, st.cp_word)
@@ -274,14 +276,17 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         pc = pr + (size_t)p.nchunks * p.count;
     };
     uint32_t order[MAX_STREAMS], n_plain = 0, n_other = 0, others[MAX_STREAMS];
+    // WEPP_SWEEP_UNFUSED=1 (profiling aid): one launch per plan, back to back on `stream`, so that a
+    // kernel trace shows the time of every stream's sweep; results are identical
+    static const bool unfused = getenv("WEPP_SWEEP_UNFUSED") && getenv("WEPP_SWEEP_UNFUSED")[0] == '1';
     for (uint32_t i = 0; i < np; i++) {
-        if (plans[i].s_in_lds && !plans[i].dense) order[n_plain++] = i;
+        if (plans[i].s_in_lds && !plans[i].dense && !unfused) order[n_plain++] = i;
         else others[n_other++] = i;
         passes += plans[i].ntiles;                                   // every tile sweeps its stream once
         bytes += (uint64_t)plans[i].ntiles * mat->stream_bytes[plans[i].t];
     }
     std::sort(order, order + n_plain, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
-    const bool fork = n_other > 0 && (n_plain > 0 || n_other > 1);
+    const bool fork = !unfused && n_other > 0 && (n_plain > 0 || n_other > 1);
     if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
     for (uint32_t k = 0; k < n_other; k++) {
         const Plan& p = plans[others[k]];

@@ -20,6 +20,7 @@ constexpr uint32_t WEPP_FLAG_HAS_UNIQUE_DEV = WEPP_FLAG_HAS_UNIQUE;
 struct DevStream {
     uint32_t n, NB, cp_stride, ncp;
     uint32_t eager;   // 1 on crown streams: fetch node data as soon as a block has a hit
+    uint32_t tier;    // index of the stream in the handle (profiling counters)
     const int64_t* nkey;
     const uint32_t* nstat;
     const uint32_t* blk_node0;
@@ -80,6 +81,10 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
 #ifndef WEPP_DENSE_WAVES
 #define WEPP_DENSE_WAVES 8
 #endif
+#ifndef WEPP_SWEEP_WAVES
+#define WEPP_SWEEP_WAVES 1
+#endif
+constexpr uint32_t SWEEP_WAVES = WEPP_SWEEP_WAVES;            // independent sweeps (waves) per workgroup of k_sweep_multi
 constexpr uint32_t DENSE_WAVES_PER_WG = WEPP_DENSE_WAVES;     // waves sharing one tile's LDS index in the dense variant
 // LDS bytes of a k_sweep workgroup: bitmap + read words (+ dense: sorted keys + owners + accumulators)
 inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense) {

@@ -395,11 +395,13 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
     // base(n) > theta(read), so a read only needs the
     // crown {base <= theta} closed under ancestors.
     {
-        static const int32_t taus[] = {2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 19, 23, 27};
+        // theta(read) = score(root) + |S| >= base(root): the ladder is relative to the root's static score
+        static const int32_t dtaus[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 19, 23, 27};
         std::vector<uint8_t> keep(N);
         std::vector<uint32_t> sel;
         size_t prev = 0;
-        for (int32_t tau : taus) {
+        for (int32_t dtau : dtaus) {
+            const int32_t tau = f.root_base + dtau;
             if (f.streams.size() + 1 >= MAX_STREAMS) break;
             for (uint32_t d = 0; d < N; d++) keep[d] = base[d] <= tau;
             keep[0] = 1;

@@ -38,11 +38,31 @@ namespace wepp {
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// -DWEPP_SWEEP_STATS: per-stream event counters of the sweep (a profiling build, never shipped):
+// [tier][0] block visits, [1] blocks with a bitmap hit, [2] hit events, [3] (hit event, read) matches,
+// [4] node-by-node evaluations, [5] of which reached the reduction, [6] blocks with a summary update, [7] waves
+#ifdef WEPP_SWEEP_STATS
+__device__ unsigned long long g_sweep_stats[MAX_STREAMS * 8];
+#define STAT_DECL uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 1}
+#define STAT_ADD(i, v) st_[i] += (uint32_t)(v)
+#define STAT_FLUSH(tier)                                                                      \
+    if (lane == 0)                                                                            \
+        for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_sweep_stats[(tier) * 8 + i_], (unsigned long long)st_[i_])
+#else
+#define STAT_DECL
+#define STAT_ADD(i, v)
+#define STAT_FLUSH(tier)
+#endif
 #ifndef WEPP_DENSE_MIN_HITS
 #define WEPP_DENSE_MIN_HITS 3
 #endif
 constexpr int DENSE_MIN_HITS = WEPP_DENSE_MIN_HITS;   // hit events per block from which the lane = event lookup pays
 constexpr uint32_t DENSE_WAVES = wepp::DENSE_WAVES_PER_WG;
+#ifndef WEPP_OWN_WORDS
+#define WEPP_OWN_WORDS 4
+#endif
+constexpr uint32_t OWN_WORDS = WEPP_OWN_WORDS;        // read words per lane kept in registers by the plain sweep
 
 // ---- word field helpers ------------------------------------------------------
 // tree / event word: pos:20 | ref idx:2 | par:4 | mut:4 | exit | leaf (flatmat.hpp)
@@ -200,27 +220,37 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
 // S_IN_LDS: the tile's read words are staged in LDS (else read from global memory: reads
 // longer than MAX_TILE_ENTRIES words).  DENSE: additionally keep a tile-sorted position
 // index in LDS and resolve blocks with many hit events with lane = event (long reads).
+// Plain LDS variant (short reads): the first OWN_WORDS words of a lane's read also sit in registers,
+// so that an event whose position is in the tile's bitmap costs every read a few compares instead
+// of a binary search through LDS (99.6 % of 150 bp reads list at most four positions; longer
+// ones search the rest of their words in LDS).
 template <bool S_IN_LDS, bool DENSE>
 __device__ __forceinline__ void sweep_tile(
-    const DevStream& m, uint32_t wg, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
-    const uint32_t* __restrict__ read_off,
+    const DevStream& m, uint32_t wg, uint32_t lds_word0, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
+    uint32_t key_cap, const uint32_t* __restrict__ read_off,
     const uint32_t* __restrict__ read_word, const int32_t* __restrict__ root_score,
     const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
-    // A workgroup = one tile of reads.  Plain variant: one wave, one chunk of the stream.
-    // DENSE variant: DENSE_WAVES waves share the tile's LDS structures (so that the larger
-    // footprint does not cost occupancy) and each sweeps its own chunk.
+    constexpr bool OWN = S_IN_LDS && !DENSE;
+    // Plain variant: one wave = one tile of reads and one chunk of the stream; `wg` is the wave's
+    // index among the sweeps of its plan and lds_word0 the start of its private LDS region (the
+    // waves of a workgroup never interact: they are grouped only because a CU holds at most 16
+    // LDS-using workgroups, i.e. 4 waves per SIMD with single-wave workgroups).
+    // DENSE variant: a workgroup = one tile; its DENSE_WAVES waves share the tile's LDS structures
+    // (so that the larger footprint does not cost occupancy) and each sweeps its own chunk.
     // LDS: [bm_words] bitmap | [ent_cap] read words (tile order) | DENSE only: [key_cap, pow2]
     // tile-sorted keys pos:19|idx:13 | [ent_cap] owner lane of each entry (bytes) | per wave [3*64] accumulators
     constexpr uint32_t NW = DENSE ? DENSE_WAVES : 1;
     extern __shared__ uint32_t lds[];
-    uint32_t* bitmap = lds;
-    uint32_t* S_lds = lds + bm_words;
+    uint32_t* bitmap = lds + lds_word0;
+    uint32_t* S_lds = bitmap + bm_words;
     uint32_t* skey = S_lds + ent_cap;
     uint8_t* owner = reinterpret_cast<uint8_t*>(skey + key_cap);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wv = threadIdx.x >> 6;
+    // wave-uniform values are pinned to scalar registers: block offsets, summaries and loop
+    // control then run on the scalar unit
+    const uint32_t wv = DENSE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
     int* acc = reinterpret_cast<int*>(owner + ent_cap) + wv * 192;   // net[64], H[64], bound[64] of this wave
 
     const uint32_t tile = wg % ntiles;
@@ -240,8 +270,15 @@ __device__ __forceinline__ void sweep_tile(
         if (lane >= (uint32_t)d) incl += o;
     }
     const uint32_t lds_off = incl - my_k;
+    // plain variant: the wave's LDS operations complete in program order, so a compiler fence is
+    // all the set-up needs; the dense variant's waves share the structures and take a barrier
+    auto tile_sync = [&]() {
+        if (DENSE) __syncthreads();
+        else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    };
+    const uint32_t tid = DENSE ? threadIdx.x : lane;
 
-    for (uint32_t i = threadIdx.x; i < bm_words; i += 64 * NW) bitmap[i] = 0;
+    for (uint32_t i = tid; i < bm_words; i += 64 * NW) bitmap[i] = 0;
     // bm_words is a power of two >= (max_pos >> 5) + 1: positions beyond the tree's
     // last mutated site (and the padding word) alias into the map; a false positive
     // only costs a failed lookup in the reads.
@@ -253,7 +290,7 @@ __device__ __forceinline__ void sweep_tile(
         for (uint32_t i = threadIdx.x; i < n2; i += 64 * NW) skey[i] = 0xFFFFFFFFu;
         for (uint32_t i = lane; i < 192; i += 64) acc[i] = 0;
     }
-    __syncthreads();
+    tile_sync();
     if (wv == 0) {
         for (uint32_t j = 0; j < my_k; j++) {
             const uint32_t w = read_word[so + j];
@@ -266,7 +303,7 @@ __device__ __forceinline__ void sweep_tile(
             if (p <= max_pos) atomicOr(&bitmap[(p >> 5) & bm_mask], 1u << (p & 31));
         }
     }
-    __syncthreads();
+    tile_sync();
     // tile-wide position index: bitonic sort of the keys (once per tile, by the whole workgroup)
     if (DENSE) {
         for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
@@ -288,6 +325,30 @@ __device__ __forceinline__ void sweep_tile(
     const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : read_word;
     const uint32_t my_off = S_IN_LDS ? lds_off : so;
     auto bit = [&](uint32_t pos) -> bool { return (bitmap[(pos >> 5) & bm_mask] >> (pos & 31)) & 1u; };
+
+    // OWN: the first OWN_WORDS words of this lane's read and their positions (an impossible
+    // position where the read is shorter); tile_long = some read of the tile lists more
+    uint32_t ow[OWN_WORDS], op[OWN_WORDS];
+#pragma unroll
+    for (uint32_t j = 0; j < OWN_WORDS; j++) { ow[j] = NONE; op[j] = NONE; }
+    bool tile_long = false;
+    if (OWN) {
+#pragma unroll
+        for (uint32_t j = 0; j < OWN_WORDS; j++)
+            if (my_k > j) { ow[j] = S_lds[lds_off + j]; op[j] = w_pos(ow[j]); }
+        tile_long = __ballot(my_k > OWN_WORDS) != 0;
+    }
+    // this lane's read word at position P (wave-uniform), or NONE
+    auto own_entry = [&](uint32_t P) -> uint32_t {
+        if (!OWN) return have ? find_entry(S, my_off, my_k, P) : NONE;
+        uint32_t s = NONE;
+#pragma unroll
+        for (uint32_t j = 0; j < OWN_WORDS; j++) s = (op[j] == P) ? ow[j] : s;
+        if (tile_long) {
+            if (my_k > OWN_WORDS && s == NONE) s = find_entry(S, my_off + OWN_WORDS, my_k - OWN_WORDS, P);
+        }
+        return s;
+    };
 
     // c for "no mutation anywhere on the path": every non-missing entry is
     // compared with its own reference allele (usher_mapper.cpp:302-305,342).
@@ -312,7 +373,7 @@ __device__ __forceinline__ void sweep_tile(
                 const int l = __builtin_ctzll(hm);
                 hm &= hm - 1;
                 const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-                const uint32_t s = find_entry(S, my_off, my_k, w_pos(wl));
+                const uint32_t s = own_entry(w_pos(wl));
                 if (s != NONE) c += enter_delta(wl, s);
             }
         }
@@ -320,10 +381,12 @@ __device__ __forceinline__ void sweep_tile(
 
     // best score of this lane's read.  It starts one above the root's score: the root always
     // competes, so nothing worse can win or tie -- every chunk prunes against that bound from
-    // its first block on (a chunk that finds nothing reports count 0 and loses in k_finalize)
-    int bs = have ? root_score[rd] + 1 : 0x7FFFFFFF;
+    // its first block on (a chunk that finds nothing reports count 0 and loses in k_finalize).
+    // Idle lanes of a partial tile hold INT_MIN: no block ever looks useful to them.
+    int bs = have ? root_score[rd] + 1 : (int)0x80000000;
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
+    STAT_DECL;
 
     // ---- node-by-node evaluation of one block for read r (lane = node) ----------
     // Everything it needs was fetched when the first hit of the block was seen:
@@ -336,10 +399,28 @@ __device__ __forceinline__ void sweep_tile(
         const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
         const int c_r = __builtin_amdgcn_readlane(c, r);
         const int bs_r = __builtin_amdgcn_readlane(bs, r);
+        uint32_t r_ow[OWN_WORDS], r_op[OWN_WORDS];             // read r's first words (wave-uniform)
+#pragma unroll
+        for (uint32_t j = 0; j < OWN_WORDS; j++) {
+            r_ow[j] = (uint32_t)__builtin_amdgcn_readlane((int)ow[j], r);
+            r_op[j] = (uint32_t)__builtin_amdgcn_readlane((int)op[j], r);
+        }
         int cadd = 0, adj = 0, dcom = 0;
         bool touched = false;
         auto apply = [&](uint32_t w, uint32_t mt) {
-            const uint32_t sw = bit(w_pos(w)) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
+            uint32_t sw;
+            if (OWN) {
+                // read r's first two words come from its lane's registers (uniform), the rest from LDS
+                const uint32_t p = w_pos(w);
+                sw = NONE;
+#pragma unroll
+                for (uint32_t j = 0; j < OWN_WORDS; j++) sw = (p == r_op[j]) ? r_ow[j] : sw;
+                if (k_r > OWN_WORDS) {
+                    if (sw == NONE && bit(p)) sw = find_entry(S, off_r + OWN_WORDS, k_r - OWN_WORDS, p);
+                }
+            } else {
+                sw = bit(w_pos(w)) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
+            }
             unsigned long long hm = __ballot(sw != NONE);
             while (hm) {
                 const int l = __builtin_ctzll(hm);
@@ -358,9 +439,12 @@ __device__ __forceinline__ void sweep_tile(
                         const bool is_root = (n0 + o) == 0;
                         cadd += (lane > o || (is_root && lane == o)) ? delta : 0;
                     }
+                    int a1 = 0, a2 = 0;
+                    own_adjust(wl, sl, a1, a2);            // uniform
                     if (lane == o) {
                         touched = true;
-                        own_adjust(wl, sl, adj, dcom);
+                        adj += a1;
+                        dcom += a2;
                     }
                 }
             }
@@ -386,7 +470,9 @@ __device__ __forceinline__ void sweep_tile(
             elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
         } else elig = st & NS_ELIG0_DEV;
         elig = elig && (lane < sum.nn);
+        STAT_ADD(4, 1);
         if (__ballot(elig && score <= bs_r)) {
+            STAT_ADD(5, 1);
             const int smin = wave_min_i32(elig ? score : 0x7FFFFFFF);
             const bool at_min = elig && score == smin;
             const uint32_t cntb = (uint32_t)__popcll(__ballot(at_min));
@@ -401,12 +487,30 @@ __device__ __forceinline__ void sweep_tile(
     // ---- one block: lane = read ----------------------------------------------------
     // w0/w1 = this lane's two words of the block's first 128 events (W_PAD beyond e1)
     auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, const BlkSum sum) {
+        const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
+        STAT_ADD(0, 1);
+        STAT_ADD(1, (hm0 | hm1) ? 1 : 0);
+        STAT_ADD(2, __popcll(hm0) + __popcll(hm1));
+        // reads without an event in this block: one summary update (a block without statically
+        // eligible nodes has base = SCORE_INF and never passes the test)
+        auto summary_update = [&](bool untouched) {
+            const int s = sum.base + c;
+            const bool take = untouched && s <= bs;
+            STAT_ADD(6, __ballot(take) ? 1 : 0);
+            if (__ballot(take)) {              // rare once a good node has been seen: skipped wave-wide
+                if (take) {
+                    if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
+                    else { cnt += sum.cnt; br = min(br, sum.rank); }
+                }
+            }
+        };
         int net = 0, H = 0, lbmin = 0x3FFFFFFF;
         bool touched = false;
-        // for a hit event, every read looks the position up in its own entries; lbl = lower
+        // for a hit event, the reads that list its position take its delta; lbl = lower
         // bound of the static score of the nodes this event can affect in the block
         auto light_hit = [&](uint32_t wl, int lbl) {
-            const uint32_t s = have ? find_entry(S, my_off, my_k, w_pos(wl)) : NONE;
+            const uint32_t s = own_entry(w_pos(wl));
+            STAT_ADD(3, __popcll(__ballot(s != NONE)));
             if (s != NONE) {
                 const int d = enter_delta(wl, s);
                 const int ad = d < 0 ? -d : d;
@@ -417,18 +521,7 @@ __device__ __forceinline__ void sweep_tile(
                 else { net += d; H += ad + 1; }
             }
         };
-        const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
-        // per-event bounds of this lane's two events.  Crown streams interleave low- and
-        // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
-        // on the whole-tree stream the block minimum already prunes ~95 % and costs no load.
-        uint32_t lb0 = (uint32_t)max(sum.min_all, 0), lb1 = lb0;
-        if (m.eager && (hm0 | hm1) && e0 + 2 * lane < e1) {
-            const uint32_t ll = *reinterpret_cast<const uint16_t*>(m.ev_lb + e0 + 2 * lane);
-            lb0 = ll & 0xFFu;
-            lb1 = ll >> 8;
-        }
-        // a block with a hit may need the node-by-node evaluation: fetch what it reads
-        // now, so that the loads overlap the lookups below
+        const bool any_hit = (hm0 | hm1) != 0 || e1 - e0 > 128;   // wave-uniform; false for ~3 blocks in 4
         uint32_t m0 = 0, m1 = 0, st = 0;
         int64_t key = 0;
         bool fetched = false;
@@ -441,105 +534,113 @@ __device__ __forceinline__ void sweep_tile(
             if (lane < sum.nn) { key = m.nkey[sum.node0 + lane]; st = m.nstat[sum.node0 + lane]; }
             fetched = true;
         };
-        // crown streams hold only low-score nodes, so a hit nearly always ends in the
-        // node-by-node path: start its loads before the lookups.  On the whole-tree
-        // stream the bound prunes ~95 % of the hits and the loads are issued on demand.
-        if (m.eager && (hm0 | hm1)) fetch_nodes();
-        unsigned long long hm;
-        if (DENSE && __popcll(hm0) + __popcll(hm1) >= DENSE_MIN_HITS) {
-            // many hit events (long reads): lane = event.  Every lane looks its event up in
-            // the tile-sorted key array and adds its contribution to the owning read's
-            // accumulators in LDS; all events of the block are resolved together.
-            // both events of the lane are searched in one loop: two independent chains of
-            // dependent LDS reads in flight instead of one
-            const uint32_t p0 = w_pos(w0), p1 = w_pos(w1);
-            const uint32_t want0 = p0 << 13, want1 = p1 << 13;
-            uint32_t lo0 = 0, lo1 = 0;
-            for (uint32_t step = n2 >> 1; step > 0; step >>= 1) {          // lower_bound, n2 is a power of two
-                const uint32_t k0 = skey[lo0 + step - 1], k1 = skey[lo1 + step - 1];
-                if (k0 < want0) lo0 += step;
-                if (k1 < want1) lo1 += step;
+        if (any_hit) {
+            // per-event bounds of this lane's two events.  Crown streams interleave low- and
+            // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
+            // on the whole-tree stream the block minimum already prunes ~95 % and costs no load.
+            uint32_t lb0 = (uint32_t)max(sum.min_all, 0), lb1 = lb0;
+            if (m.eager && (hm0 | hm1) && e0 + 2 * lane < e1) {
+                const uint32_t ll = *reinterpret_cast<const uint16_t*>(m.ev_lb + e0 + 2 * lane);
+                lb0 = ll & 0xFFu;
+                lb1 = ll >> 8;
             }
-            auto dense_apply = [&](uint32_t w, uint32_t p, uint32_t lb, uint32_t i, bool act) {
-                while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 13) == p)) {
-                    const uint32_t kv = skey[min(i, n2 - 1)];
-                    if (act && i < n2 && (kv >> 13) == p) {
-                        const uint32_t idx = kv & 8191u;
-                        const int d = enter_delta(w, S_lds[idx]);
-                        const int ad = d < 0 ? -d : d;
-                        int dn, dh;
-                        if (w & W_EXIT_DEV) { dn = -d; dh = ad; }
-                        else if (w & W_LEAF_DEV) { dn = 0; dh = 1; }
-                        else { dn = d; dh = ad + 1; }
-                        const uint32_t o = owner[idx];
-                        if (dn) atomicAdd(&acc[o], dn);
-                        if (dh) atomicAdd(&acc[64 + o], dh);
-                        // touched marker + running min of the events' bounds (max of 2^30 - lb)
-                        atomicMax(&acc[128 + o], 0x40000000 - (int)lb);
-                    }
-                    i++;
+            // crown streams hold only low-score nodes, so a hit nearly always ends in the
+            // node-by-node path: start its loads before the lookups.  On the whole-tree
+            // stream the bound prunes ~95 % of the hits and the loads are issued on demand.
+            if (m.eager && (hm0 | hm1)) fetch_nodes();
+            unsigned long long hm;
+            if (DENSE && __popcll(hm0) + __popcll(hm1) >= DENSE_MIN_HITS) {
+                // many hit events (long reads): lane = event.  Every lane looks its event up in
+                // the tile-sorted key array and adds its contribution to the owning read's
+                // accumulators in LDS; all events of the block are resolved together.
+                // both events of the lane are searched in one loop: two independent chains of
+                // dependent LDS reads in flight instead of one
+                const uint32_t p0 = w_pos(w0), p1 = w_pos(w1);
+                const uint32_t want0 = p0 << 13, want1 = p1 << 13;
+                uint32_t lo0 = 0, lo1 = 0;
+                for (uint32_t step = n2 >> 1; step > 0; step >>= 1) {          // lower_bound, n2 is a power of two
+                    const uint32_t k0 = skey[lo0 + step - 1], k1 = skey[lo1 + step - 1];
+                    if (k0 < want0) lo0 += step;
+                    if (k1 < want1) lo1 += step;
                 }
-            };
-            dense_apply(w0, p0, lb0, lo0, (hm0 >> lane) & 1ull);
-            dense_apply(w1, p1, lb1, lo1, (hm1 >> lane) & 1ull);
-            // the accumulators belong to this wave alone; its LDS operations complete in
-            // program order, the barriers only stop the compiler from reordering them
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (acc[128 + lane]) {
-                touched = true;
-                lbmin = 0x40000000 - acc[128 + lane];
-                net = acc[lane];
-                H = acc[64 + lane];
-                acc[lane] = 0;
-                acc[64 + lane] = 0;
-                acc[128 + lane] = 0;
+                auto dense_apply = [&](uint32_t w, uint32_t p, uint32_t lb, uint32_t i, bool act) {
+                    while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 13) == p)) {
+                        const uint32_t kv = skey[min(i, n2 - 1)];
+                        if (act && i < n2 && (kv >> 13) == p) {
+                            const uint32_t idx = kv & 8191u;
+                            const int d = enter_delta(w, S_lds[idx]);
+                            const int ad = d < 0 ? -d : d;
+                            int dn, dh;
+                            if (w & W_EXIT_DEV) { dn = -d; dh = ad; }
+                            else if (w & W_LEAF_DEV) { dn = 0; dh = 1; }
+                            else { dn = d; dh = ad + 1; }
+                            const uint32_t o = owner[idx];
+                            if (dn) atomicAdd(&acc[o], dn);
+                            if (dh) atomicAdd(&acc[64 + o], dh);
+                            // touched marker + running min of the events' bounds (max of 2^30 - lb)
+                            atomicMax(&acc[128 + o], 0x40000000 - (int)lb);
+                        }
+                        i++;
+                    }
+                };
+                dense_apply(w0, p0, lb0, lo0, (hm0 >> lane) & 1ull);
+                dense_apply(w1, p1, lb1, lo1, (hm1 >> lane) & 1ull);
+                // the accumulators belong to this wave alone; its LDS operations complete in
+                // program order, the barriers only stop the compiler from reordering them
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (acc[128 + lane]) {
+                    touched = true;
+                    lbmin = 0x40000000 - acc[128 + lane];
+                    net = acc[lane];
+                    H = acc[64 + lane];
+                    acc[lane] = 0;
+                    acc[64 + lane] = 0;
+                    acc[128 + lane] = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                hm = hm0;
+                while (hm) {
+                    const int l = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l), __builtin_amdgcn_readlane((int)lb0, l));
+                }
+                hm = hm1;
+                while (hm) {
+                    const int l = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l), __builtin_amdgcn_readlane((int)lb1, l));
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            hm = hm0;
-            while (hm) {
-                const int l = __builtin_ctzll(hm);
-                hm &= hm - 1;
-                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w0, l), __builtin_amdgcn_readlane((int)lb0, l));
-            }
-            hm = hm1;
-            while (hm) {
-                const int l = __builtin_ctzll(hm);
-                hm &= hm - 1;
-                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w1, l), __builtin_amdgcn_readlane((int)lb1, l));
+            for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
+                const uint32_t w = (e + lane < e1) ? m.ev_word[e + lane] : W_PAD_DEV;
+                hm = __ballot(bit(w_pos(w)));
+                while (hm) {
+                    const int l = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    light_hit((uint32_t)__builtin_amdgcn_readlane((int)w, l), min(sum.min_all, 0));   // overflow events: block bound
+                }
             }
         }
-        for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
-            const uint32_t w = (e + lane < e1) ? m.ev_word[e + lane] : W_PAD_DEV;
-            hm = __ballot(bit(w_pos(w)));
-            while (hm) {
-                const int l = __builtin_ctzll(hm);
-                hm &= hm - 1;
-                light_hit((uint32_t)__builtin_amdgcn_readlane((int)w, l), min(sum.min_all, 0));   // overflow events: block bound
-            }
-        }
-        // reads without an event in this block: one summary update
-        if (!touched && sum.base != SCORE_INF_DEV) {
-            const int s = sum.base + c;
-            if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
-            else if (s == bs) { cnt += sum.cnt; br = min(br, sum.rank); }
-        }
+        summary_update(!touched);
         // reads with events: a node changed by the events scores at least
         // (min of the events' bounds) + c - H (|delta| per event bounds c, -1 per enter bounds
         // the node's own adjustment), a node they leave alone at least base + c.  Unless one
         // of the two can reach the current best, only c moves on; otherwise evaluate the
         // block node by node
-        const bool heavy = touched && ((lbmin + c - H <= bs) || (sum.base != SCORE_INF_DEV && sum.base + c <= bs));
-        unsigned long long hv = __ballot(heavy);
-        while (hv) {
-            const int r = __builtin_ctzll(hv);
-            hv &= hv - 1;
-            if (!fetched) fetch_nodes();
-            heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r);
+        if (any_hit) {
+            const bool heavy = touched && ((lbmin + c - H <= bs) || (sum.base + c <= bs));
+            unsigned long long hv = __ballot(heavy);
+            while (hv) {
+                const int r = __builtin_ctzll(hv);
+                hv &= hv - 1;
+                if (!fetched) fetch_nodes();
+                heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r);
+            }
+            c += net;
         }
-        if (touched) c += net;
     };
 
     // ---- the sweep: groups of 60 blocks (their 61 event offsets sit in one
@@ -566,6 +667,7 @@ __device__ __forceinline__ void sweep_tile(
         }
     }
 
+    STAT_FLUSH(m.tier);
     if (have) {
         const size_t o = (size_t)chunk * n_list + r0 + lane;
         part_score[o] = bs;
@@ -582,23 +684,28 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
     const int32_t* __restrict__ root_score, const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
-    sweep_tile<S_IN_LDS, DENSE>(m, blockIdx.x, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, root_score,
+    sweep_tile<S_IN_LDS, DENSE>(m, blockIdx.x, 0u, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, root_score,
                                 list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
 }
 
-// all the plain (short-read) plans of one placement call in ONE launch: the workgroups of
-// the different streams run side by side instead of queueing behind the hardware queues
-__global__ __launch_bounds__(64) void k_sweep_multi(SweepPlans pl, uint32_t bm_words, uint32_t max_pos,
-                                                    const uint32_t* __restrict__ read_off,
-                                                    const uint32_t* __restrict__ read_word,
-                                                    const int32_t* __restrict__ root_score) {
+// all the plain (short-read) plans of one placement call in ONE launch: the sweeps of the
+// different streams run side by side instead of queueing behind the hardware queues.  A
+// workgroup is SWEEP_WAVES independent waves, each with its own (tile, chunk) and LDS region.
+__global__ __launch_bounds__(64 * SWEEP_WAVES) void k_sweep_multi(SweepPlans pl, uint32_t bm_words, uint32_t max_pos,
+                                                                  uint32_t lds_words_per_wave,
+                                                                  const uint32_t* __restrict__ read_off,
+                                                                  const uint32_t* __restrict__ read_word,
+                                                                  const int32_t* __restrict__ root_score) {
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t unit = blockIdx.x * SWEEP_WAVES + wv;
+    if (unit >= pl.p[pl.n - 1].wg_end) return;
     uint32_t p = 0;
-    while (p + 1 < pl.n && blockIdx.x >= pl.p[p].wg_end) p++;
+    while (p + 1 < pl.n && unit >= pl.p[p].wg_end) p++;
     const SweepPlanDev& q = pl.p[p];
     const uint32_t wg0 = p ? pl.p[p - 1].wg_end : 0;
-    sweep_tile<true, false>(q.st, blockIdx.x - wg0, bm_words, max_pos, q.ent_cap, 0u, read_off, read_word, root_score,
-                            q.list,
-                            q.n_list, q.T, q.ntiles, q.bpc, q.part_score, q.part_rank, q.part_cnt);
+    sweep_tile<true, false>(q.st, unit - wg0, wv * lds_words_per_wave, bm_words, max_pos, q.ent_cap, 0u, read_off,
+                                  read_word, root_score, q.list, q.n_list, q.T, q.ntiles, q.bpc, q.part_score,
+                                  q.part_rank, q.part_cnt);
 }
 
 // -----------------------------------------------------------------------------
@@ -995,8 +1102,11 @@ hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint3
                               const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
                               hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sweep_multi, dim3(pl.p[pl.n - 1].wg_end), dim3(64), lds_bytes, stream, pl, m.bm_words,
-                       m.max_pos, d_read_off, d_read_word, root_score);
+    // lds_bytes = the largest request of one sweep; every wave of a workgroup gets that much
+    const uint32_t units = pl.p[pl.n - 1].wg_end;
+    hipLaunchKernelGGL(k_sweep_multi, dim3((units + SWEEP_WAVES - 1) / SWEEP_WAVES), dim3(64 * SWEEP_WAVES),
+                       lds_bytes * SWEEP_WAVES, stream, pl, m.bm_words, m.max_pos, lds_bytes / 4, d_read_off, d_read_word,
+                       root_score);
     return hipGetLastError();
 }
 
@@ -1052,6 +1162,17 @@ hipError_t launch_excess(const DevMAT& m, const uint32_t* d_read_off, const uint
                        d_pair_read, d_pair_bfs_j, n_pairs, d_out_off, d_counts, d_out);
     return hipGetLastError();
 }
+
+#ifdef WEPP_SWEEP_STATS
+extern "C" int wepp_debug_sweep_stats(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_stats), sizeof(unsigned long long) * MAX_STREAMS * 8) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long zero[MAX_STREAMS * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_stats), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 hipError_t sweep_set_max_lds(uint32_t bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)k_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
