@@ -12,7 +12,7 @@ pids=()
 for f in flatmat gen errors flat_debug capi fitch_capi epp_capi; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.cpp -o $OUT/$f.o & pids+=($!)
 done
-for f in place_kernels fitch_kernels epp_kernels; do
+for f in place_kernels sort_reads fitch_kernels epp_kernels; do
   /opt/rocm/bin/hipcc $FLAGS --offload-arch=gfx950 -c $SRC/$f.hip -o $OUT/$f.o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -172,6 +172,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
 
     // ---- workspace: [tier_of R bytes][list R][root_score R][partials: sum over tiers of nchunks*count*12] ----
     // The partials are sized for the worst case once the per-tier counts are known.
+    bool ws_moved = false;
     auto grow = [&](size_t need) -> int {
         if (need <= mat->ws_bytes) return WEPP_OK;
         if (mat->ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(mat->ws); mat->ws = nullptr; mat->ws_bytes = 0; }
@@ -179,32 +180,61 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         hipError_t e = hipMalloc(&mat->ws, need);
         if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
         mat->ws_bytes = need;
+        ws_moved = true;
         return WEPP_OK;
     };
     const size_t tier_bytes = ((size_t)n_reads + 255) & ~(size_t)255;
     const size_t list_bytes = (((size_t)n_reads * 4) + 255) & ~(size_t)255;
+    // WEPP_SORT_READS=0 (A/B aid): keep the caller's read order on the whole-tree stream too
+    static const bool sort_reads = !(getenv("WEPP_SORT_READS") && getenv("WEPP_SORT_READS")[0] == '0');
+    size_t sort_temp = 0;
+    if (sort_reads) HIP_TRY(sort_reads_temp_bytes(n_reads, &sort_temp));
+    sort_temp = (sort_temp + 255) & ~(size_t)255;
+    // fixed part of the workspace: tier | list | root_score | sort keys in/out | sort values | sort temp
+    const size_t fixed_bytes = tier_bytes + 2 * list_bytes + (sort_reads ? 3 * list_bytes + sort_temp : 0);
     {
-        // before routing only the first two regions are needed; reserve a typical partial size too
-        int rc = grow(tier_bytes + 2 * list_bytes + (size_t)n_reads * 12 * 2);
+        // before routing only the fixed regions are needed; reserve a typical partial size too
+        int rc = grow(fixed_bytes + (size_t)n_reads * 12 * 2);
         if (rc != WEPP_OK) return rc;
     }
-    uint8_t* tier_of = (uint8_t*)mat->ws;
-    uint32_t* list = (uint32_t*)((char*)mat->ws + tier_bytes);
-    int32_t* root_score = (int32_t*)((char*)mat->ws + tier_bytes + list_bytes);
+    uint8_t* tier_of = nullptr;
+    uint32_t *list = nullptr, *key_in = nullptr, *key_out = nullptr, *val_in = nullptr;
+    int32_t* root_score = nullptr;
+    void* sort_tmp = nullptr;
+    auto carve = [&]() {
+        char* p = (char*)mat->ws;
+        tier_of = (uint8_t*)p; p += tier_bytes;
+        list = (uint32_t*)p; p += list_bytes;
+        root_score = (int32_t*)p; p += list_bytes;
+        if (sort_reads) {
+            key_in = (uint32_t*)p; p += list_bytes;
+            key_out = (uint32_t*)p; p += list_bytes;
+            val_in = (uint32_t*)p; p += list_bytes;   // the sorted list of the whole-tree stream
+            sort_tmp = p;
+        }
+    };
+    carve();
     uint32_t* tier_info = mat->d_info;
     uint32_t* blk_counts = mat->d_info + TI_WORDS;
 
-    // ---- route the reads to streams ------------------------------------------------
-    HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
-    HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score, blk_counts,
-                         tier_info, stream));
-    HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
+    // ---- route the reads to streams ------------------------------------------------------
+    auto route = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score, blk_counts,
+                             tier_info, stream));
+        HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
+        return WEPP_OK;
+    };
+    {
+        int rc = route();
+        if (rc != WEPP_OK) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const uint32_t* info = mat->h_info;
 
     // ---- plan the launches ---------------------------------------------------------
-    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; };
+    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; const uint32_t* lst; };
     Plan plans[MAX_STREAMS];
     uint32_t np = 0;
     size_t part_total = 0;
@@ -248,20 +278,27 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         part_total += (size_t)p.nchunks * count * 12;
     }
     {
-        int rc = grow(tier_bytes + 2 * list_bytes + part_total);
+        ws_moved = false;
+        int rc = grow(fixed_bytes + part_total);
         if (rc != WEPP_OK) return rc;
-        tier_of = (uint8_t*)mat->ws;
-        if ((uint32_t*)((char*)mat->ws + tier_bytes) != list) {
+        if (ws_moved) {
             // the workspace moved: redo the (cheap) routing into the new buffer
-            list = (uint32_t*)((char*)mat->ws + tier_bytes);
-            root_score = (int32_t*)((char*)mat->ws + tier_bytes + list_bytes);
-            HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
-            HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score,
-                                 blk_counts, tier_info, stream));
-            HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
+            carve();
+            rc = route();
+            if (rc != WEPP_OK) return rc;
         }
     }
-    char* part_base = (char*)mat->ws + tier_bytes + 2 * list_bytes;
+    char* part_base = (char*)mat->ws + fixed_bytes;
+    for (uint32_t i = 0; i < np; i++) {
+        Plan& p = plans[i];
+        p.lst = list + p.off;
+        // the reads that sweep the whole tree go by first listed position (sort_reads.hip)
+        if (sort_reads && p.t + 1 == ns && p.count >= SORT_MIN_READS) {
+            HIP_TRY(launch_first_pos(list + p.off, p.count, d_read_off, d_read_word, key_in, stream));
+            HIP_TRY(launch_sort_reads(key_in, key_out, list + p.off, val_in, p.count, sort_tmp, sort_temp, stream));
+            p.lst = val_in;
+        }
+    }
 
     // ---- sweeps (timed as a group) + finalizes ------------------------------------------
     // The plain (short-read) plans are fused into ONE launch, longest chunks first; dense
@@ -294,10 +331,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
-        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, root_score, list + p.off, p.count, p.T,
+        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, root_score, p.lst, p.count, p.T,
                              p.ntiles,
                              p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
-        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + p.off, p.count, p.nchunks, ps, pr, pc,
+        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, p.lst, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
         if (fork) {
             HIP_TRY(hipEventRecord(mat->join_ev[k], q));
@@ -311,7 +348,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             const Plan& p = plans[order[k]];
             SweepPlanDev& d = pl.p[k];
             d.st = mat->streams[p.t];
-            d.list = list + p.off;
+            d.list = p.lst;
             d.n_list = p.count;
             d.T = p.T;
             d.ntiles = p.ntiles;

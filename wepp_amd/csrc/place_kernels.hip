@@ -213,6 +213,20 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
 }
 
 // -----------------------------------------------------------------------------
+// k_first_pos: sort key of the reads of one stream's list = first listed position (reads that
+// list nothing first).  Sorted by it, the reads of a tile list the same or neighbouring
+// positions: the tile looks at an event of the stream once per DISTINCT position, every read
+// that lists it takes the delta in the same instructions, and equal reads are evaluated once.
+// -----------------------------------------------------------------------------
+__global__ void k_first_pos(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ read_off,
+                            const uint32_t* __restrict__ read_word, uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = list[i], so = read_off[r];
+    keys[i] = (read_off[r + 1] > so) ? w_pos(read_word[so]) + 1u : 0u;
+}
+
+// -----------------------------------------------------------------------------
 // The sweep.  grid = ntiles * nchunks single-wave workgroups.
 // LDS: [bm_words] position bitmap of the tile, then (S_IN_LDS) the tile's read
 // words.  part_* receive one (score, rank, count) per (chunk, read).
@@ -392,8 +406,10 @@ __device__ __forceinline__ void sweep_tile(
     // Everything it needs was fetched when the first hit of the block was seen:
     // w0/w1 + m0/m1 = this lane's two events and their node offsets, key/st = this
     // lane's node.
+    // grp = the lanes whose read is word for word the read of lane r (they hold the same c, bs, br,
+    // cnt at every point of the sweep): the evaluation is done once and its outcome taken by all
     auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t m0,
-                          uint32_t m1, int64_t key, uint32_t st, int r) {
+                          uint32_t m1, int64_t key, uint32_t st, int r, unsigned long long grp) {
         const uint32_t n0 = sum.node0;
         const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
         const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
@@ -477,7 +493,7 @@ __device__ __forceinline__ void sweep_tile(
             const bool at_min = elig && score == smin;
             const uint32_t cntb = (uint32_t)__popcll(__ballot(at_min));
             const uint32_t rmin = wave_min_u32(at_min ? rank : 0xFFFFFFFFu);
-            if (lane == (uint32_t)r) {
+            if ((grp >> lane) & 1ull) {
                 if (smin < bs) { bs = smin; br = rmin; cnt = cntb; }
                 else if (smin == bs) { cnt += cntb; br = min(br, rmin); }
             }
@@ -635,9 +651,21 @@ __device__ __forceinline__ void sweep_tile(
             unsigned long long hv = __ballot(heavy);
             while (hv) {
                 const int r = __builtin_ctzll(hv);
-                hv &= hv - 1;
+                // reads of the tile identical to read r (sorted batches put them side by side)
+                unsigned long long grp = 1ull << r;
+                if (OWN) {
+                    const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
+                    if (k_r <= OWN_WORDS) {
+                        bool same = my_k == k_r;
+#pragma unroll
+                        for (uint32_t j = 0; j < OWN_WORDS; j++)
+                            same = same && ow[j] == (uint32_t)__builtin_amdgcn_readlane((int)ow[j], r);
+                        grp = __ballot(same) & hv;
+                    }
+                }
+                hv &= ~grp;
                 if (!fetched) fetch_nodes();
-                heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r);
+                heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r, grp);
             }
             c += net;
         }
@@ -1068,6 +1096,13 @@ hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint3
                         uint32_t* tier_info, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
                        n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info);
+    return hipGetLastError();
+}
+
+hipError_t launch_first_pos(const uint32_t* list, uint32_t n, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                            uint32_t* keys, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_first_pos, dim3((n + 255) / 256), dim3(256), 0, stream, list, n, d_read_off, d_read_word, keys);
     return hipGetLastError();
 }
 

@@ -1,0 +1,27 @@
+// sort_reads.hip -- orders the reads that sweep the whole-tree stream by first listed position
+// (keys from k_first_pos, place_kernels.hip) with rocPRIM's device radix sort, a library
+// primitive.  Only used when that stream holds enough reads for a sweep to cost more than the sort.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "device_mat.hpp"
+
+namespace wepp {
+
+hipError_t sort_reads_temp_bytes(uint32_t n, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, SORT_KEY_BITS, nullptr);
+}
+
+hipError_t launch_sort_reads(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, SORT_KEY_BITS,
+                                     stream);
+}
+
+}  // namespace wepp
