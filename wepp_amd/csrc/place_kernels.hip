@@ -240,13 +240,14 @@ __global__ void k_first_pos(const uint32_t* __restrict__ list, uint32_t n, const
 // ones search the rest of their words in LDS).
 template <bool S_IN_LDS, bool DENSE>
 __device__ __forceinline__ void sweep_tile(
-    const DevStream& m, uint32_t wg, uint32_t lds_word0, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
+    const DevStream& ms, uint32_t wg, uint32_t lds_word0, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
     uint32_t key_cap, const uint32_t* __restrict__ read_off,
     const uint32_t* __restrict__ read_word, const int32_t* __restrict__ root_score,
     const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
     constexpr bool OWN = S_IN_LDS && !DENSE;
+    const DevStream& m = ms;
     // Plain variant: one wave = one tile of reads and one chunk of the stream; `wg` is the wave's
     // index among the sweeps of its plan and lds_word0 the start of its private LDS region (the
     // waves of a workgroup never interact: they are grouped only because a CU holds at most 16
@@ -514,12 +515,19 @@ __device__ __forceinline__ void sweep_tile(
             const bool take = untouched && s <= bs;
             STAT_ADD(6, __ballot(take) ? 1 : 0);
             if (__ballot(take)) {              // rare once a good node has been seen: skipped wave-wide
+                __builtin_amdgcn_sched_barrier(0);   // keeps the update behind a real branch (no if-conversion)
                 if (take) {
                     if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
                     else { cnt += sum.cnt; br = min(br, sum.rank); }
                 }
             }
         };
+        const bool any_hit = (hm0 | hm1) != 0 || e1 - e0 > 128;   // wave-uniform; false for most blocks
+        if (!any_hit) {
+            summary_update(true);
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);     // the hit path stays out of line of the fast path
         int net = 0, H = 0, lbmin = 0x3FFFFFFF;
         bool touched = false;
         // for a hit event, the reads that list its position take its delta; lbl = lower
@@ -537,7 +545,6 @@ __device__ __forceinline__ void sweep_tile(
                 else { net += d; H += ad + 1; }
             }
         };
-        const bool any_hit = (hm0 | hm1) != 0 || e1 - e0 > 128;   // wave-uniform; false for ~3 blocks in 4
         uint32_t m0 = 0, m1 = 0, st = 0;
         int64_t key = 0;
         bool fetched = false;
@@ -550,7 +557,7 @@ __device__ __forceinline__ void sweep_tile(
             if (lane < sum.nn) { key = m.nkey[sum.node0 + lane]; st = m.nstat[sum.node0 + lane]; }
             fetched = true;
         };
-        if (any_hit) {
+        {
             // per-event bounds of this lane's two events.  Crown streams interleave low- and
             // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
             // on the whole-tree stream the block minimum already prunes ~95 % and costs no load.
@@ -646,7 +653,7 @@ __device__ __forceinline__ void sweep_tile(
         // the node's own adjustment), a node they leave alone at least base + c.  Unless one
         // of the two can reach the current best, only c moves on; otherwise evaluate the
         // block node by node
-        if (any_hit) {
+        {
             const bool heavy = touched && ((lbmin + c - H <= bs) || (sum.base + c <= bs));
             unsigned long long hv = __ballot(heavy);
             while (hv) {
