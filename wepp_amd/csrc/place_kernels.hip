@@ -103,15 +103,25 @@ __device__ __forceinline__ void own_adjust(uint32_t w, uint32_t s, int& adj_scor
     adj_common += actual_common - static_common;
 }
 
+// wave-wide minimum, returned wave-uniform: four DPP row shifts leave the minimum of every row of
+// 16 lanes in its last lane, four readlanes and scalar mins finish (no LDS permutes)
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
-    return v;
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31);
+    const int c = __builtin_amdgcn_readlane(v, 47), d = __builtin_amdgcn_readlane(v, 63);
+    return min(min(a, b), min(c, d));
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o < v ? o : v; }
-    return v;
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xF, 0xF, false));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return min(min(a, b), min(c, d));
 }
 
 // lower_bound over a position-sorted slice of read words; returns the entry
@@ -503,7 +513,8 @@ __device__ __forceinline__ void sweep_tile(
 
     // ---- one block: lane = read ----------------------------------------------------
     // w0/w1 = this lane's two words of the block's first 128 events (W_PAD beyond e1)
-    auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, const BlkSum sum) {
+    // lbw = this lane's two per-event bounds (crown streams; fetched with the event words)
+    auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t lbw, const BlkSum sum) {
         const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
         STAT_ADD(0, 1);
         STAT_ADD(1, (hm0 | hm1) ? 1 : 0);
@@ -522,7 +533,11 @@ __device__ __forceinline__ void sweep_tile(
                 }
             }
         };
+#ifdef WEPP_EXP_NO_HITS     // timing experiment only (wrong results): every block takes the no-hit path
+        const bool any_hit = false;
+#else
         const bool any_hit = (hm0 | hm1) != 0 || e1 - e0 > 128;   // wave-uniform; false for most blocks
+#endif
         if (!any_hit) {
             summary_update(true);
             return;
@@ -562,10 +577,9 @@ __device__ __forceinline__ void sweep_tile(
             // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
             // on the whole-tree stream the block minimum already prunes ~95 % and costs no load.
             uint32_t lb0 = (uint32_t)max(sum.min_all, 0), lb1 = lb0;
-            if (m.eager && (hm0 | hm1) && e0 + 2 * lane < e1) {
-                const uint32_t ll = *reinterpret_cast<const uint16_t*>(m.ev_lb + e0 + 2 * lane);
-                lb0 = ll & 0xFFu;
-                lb1 = ll >> 8;
+            if (m.eager) {
+                lb0 = lbw & 0xFFu;
+                lb1 = lbw >> 8;
             }
             // crown streams hold only low-score nodes, so a hit nearly always ends in the
             // node-by-node path: start its loads before the lookups.  On the whole-tree
@@ -656,6 +670,9 @@ __device__ __forceinline__ void sweep_tile(
         {
             const bool heavy = touched && ((lbmin + c - H <= bs) || (sum.base + c <= bs));
             unsigned long long hv = __ballot(heavy);
+#ifdef WEPP_EXP_NO_HEAVY   // timing experiment only (wrong results): no node-by-node evaluation
+            hv = 0;
+#endif
             while (hv) {
                 const int r = __builtin_ctzll(hv);
                 // reads of the tile identical to read r (sorted batches put them side by side)
@@ -688,17 +705,24 @@ __device__ __forceinline__ void sweep_tile(
 #pragma unroll
             for (int q = 0; q < 5; q++) e[q] = (uint32_t)__builtin_amdgcn_readlane((int)eo_vec, (int)min(j + q, ng));
             uint2 ww[4];
+            uint32_t lbw[4];
             BlkSum sm[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t idx = e[q] + 2 * lane;
                 ww[q] = make_uint2(W_PAD_DEV, W_PAD_DEV);
-                if (idx < e[q + 1]) ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idx);
+                lbw[q] = 0;
+                if (idx < e[q + 1]) {
+                    ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idx);
+                    // crown streams: a hit nearly always needs the per-event bounds; fetching them
+                    // here keeps a dependent load (and its wait) off the hit path
+                    if (m.eager) lbw[q] = *reinterpret_cast<const uint16_t*>(m.ev_lb + idx);
+                }
                 sm[q] = m.blk_sum[min(bb + j + q, m.NB - 1)];
             }
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (j + q < ng) process_block(e[q], e[q + 1], ww[q].x, ww[q].y, sm[q]);
+                if (j + q < ng) process_block(e[q], e[q + 1], ww[q].x, ww[q].y, lbw[q], sm[q]);
         }
     }
 
