@@ -45,12 +45,17 @@ def test_oracle_mapper_body_hand_cases(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["sets", "scores"])
 @pytest.mark.parametrize("chunks", [None, 2, 5, 17])
-def test_fitch_kernels_vs_oracle(oracle, chunks, monkeypatch):
+def test_fitch_kernels_vs_oracle(oracle, chunks, form, monkeypatch):
     """chunks: how many waves share one walk of the tree (None = the library's choice, 1 for
-    trees this small); nodes spanning chunk boundaries go through the stitch kernel."""
+    trees this small); nodes spanning chunk boundaries go through the stitch kernel.
+    form: the forward pass on optimal sets (packed 16-bit counters; the default whenever every
+    observed allele set is non-empty) or on the four integer scores (the general form)."""
     if chunks:
         monkeypatch.setenv("WEPP_FITCH_CHUNKS", str(chunks))
+    if form == "scores":
+        monkeypatch.setenv("WEPP_FITCH_SCORES", "1")
     rng = np.random.default_rng(2024)
     total = 0
     for it in range(30):
@@ -116,6 +121,37 @@ def test_fitch_rebuilds_the_mutations_of_a_generated_tree(oracle):
         assert got == want and (s[k:k + len(want)] == r).all(), r
         k += len(want)
     assert k == len(s) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunks", [None, 3])
+def test_fitch_empty_allele_sets_take_the_score_form(oracle, chunks, monkeypatch):
+    """A row that observes an EMPTY allele set on some node (mask 0: every base costs num_nodes,
+    usher_mapper.cpp:57-62) drives sums past num_nodes, where the clamp of :98 binds: such calls
+    must fall back to the integer-score kernels and still equal the oracle."""
+    if chunks:
+        monkeypatch.setenv("WEPP_FITCH_CHUNKS", str(chunks))
+    rng = np.random.default_rng(77)
+    for it in range(12):
+        tree, _ = ft.random_tree(rng, n_nodes=int(rng.integers(3, 120)), max_muts=0, root_muts=False, p_masked=0.0,
+                                 p_root_masked=0.0)
+        n_rows = int(rng.integers(1, 70))
+        site_ref, var_off, var_node, var_nuc = _random_rows(rng, tree, n_rows, p_var=0.3, p_internal=0.1)
+        if len(var_nuc) == 0:
+            continue
+        zero = rng.random(len(var_nuc)) < 0.3
+        zero[int(rng.integers(0, len(var_nuc)))] = True
+        var_nuc = np.where(zero, 0, var_nuc).astype(np.uint8)
+        s, nd, par, mut = w.fitch_sites(tree, site_ref, var_off, var_node, var_nuc)
+        ot = oracle.OracleTree(tree)
+        k = 0
+        for r in range(n_rows):
+            a, b = int(var_off[r]), int(var_off[r + 1])
+            want = ot.mapper_body(int(site_ref[r]), var_node[a:b].astype(np.int32), var_nuc[a:b])
+            got = [(int(nd[i]), int(par[i]), int(mut[i])) for i in range(k, k + len(want))]
+            assert (s[k:k + len(want)] == r).all() and got == want, (it, r)
+            k += len(want)
+        assert k == len(s)
 
 
 @pytest.mark.gpu

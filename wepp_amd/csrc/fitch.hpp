@@ -29,8 +29,14 @@ constexpr uint32_t FITCH_MAX_DEPTH = 140;   // (depth + 1) KiB of LDS per wave
 // inh_part / out_part: [nbatches][C][max_depth + 1][64] int4 scratch each
 hipError_t launch_fitch_forward(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
                                 uint8_t* tables, int4* inh_part, int4* out_part, hipStream_t stream);
+// set form (fitch_kernels.hip): valid when every observed allele set is non-empty and no node has
+// more than FITCH_SETS_MAX_CHILDREN children; scratch is uint2 per (chunk, level, row); tables then
+// hold "not optimal" masks (launch_fitch_backward with masks = true)
+constexpr uint32_t FITCH_SETS_MAX_CHILDREN = 32767;
+hipError_t launch_fitch_forward_sets(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
+                                     uint8_t* tables, uint2* inh_part, uint2* out_part, hipStream_t stream);
 hipError_t launch_fitch_backward(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
-                                 const uint8_t* tables, unsigned long long* out_count, uint64_t capacity, uint2* out,
-                                 hipStream_t stream);
+                                 const uint8_t* tables, bool masks, unsigned long long* out_count, uint64_t capacity,
+                                 uint2* out, hipStream_t stream);
 
 }  // namespace wepp

@@ -55,7 +55,13 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (f.max_depth > FITCH_MAX_DEPTH)
         return set_error(WEPP_ELIMIT, "tree depth " + std::to_string(f.max_depth) + " exceeds the LDS stack (" +
                                           std::to_string(FITCH_MAX_DEPTH) + ")");
-    std::vector<uint32_t> meta(N), id2dfs(N), depth(N, 0);
+    std::vector<uint32_t> meta(N), id2dfs(N), depth(N, 0), nchild(N, 0);
+    uint32_t max_children = 0;
+    for (uint32_t d = 1; d < N; d++) max_children = std::max(max_children, ++nchild[f.parent_dfs[d]]);
+    // the set form of the forward pass needs non-empty allele sets (checked per row below) and 15-bit counters
+    bool sets_ok = max_children <= FITCH_SETS_MAX_CHILDREN;
+    if (const char* env = std::getenv("WEPP_FITCH_SCORES"))      // test hook: force the score form
+        if (env[0] == '1') sets_ok = false;
     for (uint32_t d = 0; d < N; d++) {
         if (d) depth[d] = depth[f.parent_dfs[d]] + 1;
         meta[d] = depth[d] | ((f.nstat[d] & NS_LEAF) ? 0x80000000u : 0u);
@@ -102,6 +108,7 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         for (uint32_t k = var_off[s]; k < var_off[s + 1]; k++) {
             if (var_node[k] >= N) return set_error(WEPP_EINVAL, "var_node out of range");
             row.emplace_back(id2dfs[var_node[k]], var_nuc[k]);
+            if ((var_nuc[k] & 15) == 0) sets_ok = false;     // no base allowed: the scores leave the set form's range
         }
         // a node named twice in a row: the later entry wins, as the later assignment does at usher_mapper.cpp:57-62
         std::stable_sort(row.begin(), row.end(), [](const std::pair<uint32_t, uint8_t>& a,
@@ -156,10 +163,13 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     FitchSites fs{n_sites, d_ref.as<uint8_t>(), d_voff.as<uint32_t>(), d_vdfs.as<uint32_t>(), d_vnuc.as<uint8_t>()};
     for (uint32_t b0 = 0; b0 < nbatches; b0 += group) {
         const uint32_t nb = std::min(group, nbatches - b0);
-        e = launch_fitch_forward(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_inh.as<int4>(), d_outp.as<int4>(), nullptr);
+        if (sets_ok)
+            e = launch_fitch_forward_sets(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_inh.as<uint2>(), d_outp.as<uint2>(), nullptr);
+        else
+            e = launch_fitch_forward(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_inh.as<int4>(), d_outp.as<int4>(), nullptr);
         if (e == hipSuccess)
-            e = launch_fitch_backward(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_count.as<unsigned long long>(), capacity,
-                                      d_out.as<uint2>(), nullptr);
+            e = launch_fitch_backward(ft, fs, b0, nb, d_tables.as<uint8_t>(), sets_ok, d_count.as<unsigned long long>(),
+                                      capacity, d_out.as<uint2>(), nullptr);
         if (e != hipSuccess) return hipf(e, "Fitch-Sankoff kernels");
     }
     unsigned long long cnt = 0;
