@@ -45,15 +45,20 @@ def test_oracle_mapper_body_hand_cases(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["sets", "scores"])
+@pytest.mark.parametrize("form", ["levels", "sets", "scores"])
 @pytest.mark.parametrize("chunks", [None, 2, 5, 17])
 def test_fitch_kernels_vs_oracle(oracle, chunks, form, monkeypatch):
     """chunks: how many waves share one walk of the tree (None = the library's choice, 1 for
     trees this small); nodes spanning chunk boundaries go through the stitch kernel.
-    form: the forward pass on optimal sets (packed 16-bit counters; the default whenever every
-    observed allele set is non-empty) or on the four integer scores (the general form)."""
+    form: "levels" = level-synchronous kernels on optimal sets (the default whenever every observed
+    allele set is non-empty; `chunks` does not apply), "sets" = the same arithmetic on the DFS
+    stack, "scores" = the four integer scores on the DFS stack (the general form)."""
     if chunks:
+        if form == "levels":
+            pytest.skip("chunks only exist in the DFS stack forms")
         monkeypatch.setenv("WEPP_FITCH_CHUNKS", str(chunks))
+    if form != "levels":
+        monkeypatch.setenv("WEPP_FITCH_DFS", "1")
     if form == "scores":
         monkeypatch.setenv("WEPP_FITCH_SCORES", "1")
     rng = np.random.default_rng(2024)

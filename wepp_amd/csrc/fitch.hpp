@@ -23,6 +23,22 @@ struct FitchSites {
     const uint8_t* var_nuc;     // allele masks
 };
 
+// level-synchronous form: the tree in BFS order
+struct FitchLevels {
+    uint32_t N, n_levels;
+    const uint32_t* coff;           // [N + 1] children of node i = BFS indices [coff[i], coff[i + 1]) (BFS keeps siblings together)
+    const uint32_t* parent;         // [N] BFS index of the parent (root: 0)
+};
+#ifndef WEPP_FITCH_LEVEL_CHUNK
+#define WEPP_FITCH_LEVEL_CHUNK 256
+#endif
+constexpr uint32_t FITCH_LEVEL_CHUNK = WEPP_FITCH_LEVEL_CHUNK;   // consecutive nodes of a level per wave (measured: 256 beats 512, 2048, 8192 -- many short waves fill the chip level by level)
+
+#ifndef WEPP_FITCH_LEVEL_WAVES
+#define WEPP_FITCH_LEVEL_WAVES 4
+#endif
+constexpr uint32_t FITCH_LEVEL_WAVES = WEPP_FITCH_LEVEL_WAVES;   // independent waves per workgroup of the level kernels
+
 constexpr uint32_t FITCH_MAX_DEPTH = 140;   // (depth + 1) KiB of LDS per wave
 
 // forward = chunk-parallel pass + stitch of the nodes that span chunk boundaries;
@@ -35,6 +51,11 @@ hipError_t launch_fitch_forward(const FitchTree& t, const FitchSites& s, uint32_
 constexpr uint32_t FITCH_SETS_MAX_CHILDREN = 32767;
 hipError_t launch_fitch_forward_sets(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
                                      uint8_t* tables, uint2* inh_part, uint2* out_part, hipStream_t stream);
+// level-synchronous form (the default when the set form is valid): `bytes` = [nbatches][N][64] in BFS
+// order; FitchSites::var_dfs then holds BFS indices; emitted node indices are BFS indices
+hipError_t launch_fitch_levels(const FitchLevels& t, const uint32_t* h_level_off, const FitchSites& s, uint32_t batch0,
+                               uint32_t nbatches, uint8_t* bytes, unsigned long long* out_count, uint64_t capacity,
+                               uint2* out, hipStream_t stream);
 hipError_t launch_fitch_backward(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
                                  const uint8_t* tables, bool masks, unsigned long long* out_count, uint64_t capacity,
                                  uint2* out, hipStream_t stream);

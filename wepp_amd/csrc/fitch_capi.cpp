@@ -92,9 +92,15 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         for (uint32_t d = chunk_start[c]; d < chunk_start[c + 1]; d++) mn = std::min(mn, depth[d]);
         chunk_min[c] = mn;
     }
-    // rows: reference base index, tree samples sorted by DFS index
+    // rows: reference base index, tree samples sorted by node index (BFS for the level-synchronous
+    // form, DFS for the two stack forms)
     const uint64_t nv = var_off[n_sites];
     if (nv && (!var_node || !var_nuc)) return set_error(WEPP_EINVAL, "null variant arrays");
+    for (uint64_t k = 0; k < nv; k++)
+        if ((var_nuc[k] & 15) == 0) sets_ok = false;     // no base allowed: the scores leave the set forms' range
+    bool levels = sets_ok;
+    if (const char* env = std::getenv("WEPP_FITCH_DFS"))          // test hook: force the DFS stack forms
+        if (env[0] == '1') levels = false;
     std::vector<uint8_t> ref_idx(n_sites), vnuc(nv);
     std::vector<uint32_t> vdfs(nv);
     std::vector<std::pair<uint32_t, uint8_t>> row;
@@ -107,8 +113,8 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         row.clear();
         for (uint32_t k = var_off[s]; k < var_off[s + 1]; k++) {
             if (var_node[k] >= N) return set_error(WEPP_EINVAL, "var_node out of range");
-            row.emplace_back(id2dfs[var_node[k]], var_nuc[k]);
-            if ((var_nuc[k] & 15) == 0) sets_ok = false;     // no base allowed: the scores leave the set form's range
+            const uint32_t dd = id2dfs[var_node[k]];
+            row.emplace_back(levels ? f.dfs2bfs[dd] : dd, var_nuc[k]);
         }
         // a node named twice in a row: the later entry wins, as the later assignment does at usher_mapper.cpp:57-62
         std::stable_sort(row.begin(), row.end(), [](const std::pair<uint32_t, uint8_t>& a,
@@ -131,11 +137,30 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (e != hipSuccess) return hipf(e, "hipSetDevice");
 
     DevBuf d_meta, d_ref, d_voff, d_vdfs, d_vnuc, d_tables, d_count, d_out, d_cs, d_cd, d_cm, d_co, d_inh, d_outp;
+    DevBuf d_lcoff, d_lpar;
+    // level-synchronous form: the topology in BFS order (levels and sibling groups are contiguous)
+    std::vector<uint32_t> level_off, l_coff, l_par;
+    if (levels) {
+        std::vector<uint32_t> bfs2dfs(N);
+        for (uint32_t d = 0; d < N; d++) bfs2dfs[f.dfs2bfs[d]] = d;
+        l_coff.assign((size_t)N + 1, 0); l_par.assign(N, 0);
+        for (uint32_t bidx = 0; bidx < N; bidx++) {
+            const uint32_t d = bfs2dfs[bidx];
+            if (bidx == 0 || depth[d] != depth[bfs2dfs[bidx - 1]]) level_off.push_back(bidx);
+            if (d == 0) continue;
+            const uint32_t pb = f.dfs2bfs[f.parent_dfs[d]];
+            l_par[bidx] = pb;
+            l_coff[pb + 1]++;                              // BFS visits a node's children consecutively, parents in order
+        }
+        l_coff[0] = 1;                                     // the first child (if any) is BFS node 1
+        for (uint32_t i = 0; i < N; i++) l_coff[i + 1] += l_coff[i];
+        level_off.push_back(N);
+    }
     const uint32_t nbatches = (n_sites + 63) / 64;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     // per batch of 64 rows: the decision tables and the two partial-sum scratch arrays
-    const size_t part_bytes = (size_t)C * D * 64 * 16;
+    const size_t part_bytes = levels ? 0 : (size_t)C * D * 64 * 16;
     const size_t per_batch = (size_t)N * 64 + 2 * part_bytes;
     const size_t budget = free_b / 2;
     const uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nbatches, budget / std::max<size_t>(per_batch, 1)));
@@ -145,7 +170,8 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         (e = d_inh.alloc(part_bytes * group)) != hipSuccess || (e = d_outp.alloc(part_bytes * group)) != hipSuccess ||
         (e = d_cs.alloc((C + 1) * 4)) != hipSuccess || (e = d_cd.alloc((C + 1) * 4)) != hipSuccess ||
         (e = d_cm.alloc(C * 4)) != hipSuccess || (e = d_co.alloc(chunk_open.size() * 4)) != hipSuccess ||
-        (e = d_count.alloc(8)) != hipSuccess || (e = d_out.alloc(std::max<uint64_t>(capacity, 1) * 8)) != hipSuccess)
+        (e = d_count.alloc(8)) != hipSuccess || (e = d_out.alloc(std::max<uint64_t>(capacity, 1) * 8)) != hipSuccess ||
+        (e = d_lcoff.alloc(l_coff.size() * 4)) != hipSuccess || (e = d_lpar.alloc(l_par.size() * 4)) != hipSuccess)
         return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     e = hipMemcpy(d_meta.p, meta.data(), (size_t)N * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_ref.p, ref_idx.data(), n_sites, hipMemcpyHostToDevice);
@@ -157,12 +183,21 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (e == hipSuccess) e = hipMemcpy(d_cm.p, chunk_min.data(), C * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_co.p, chunk_open.data(), chunk_open.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_count.p, 0, 8);
+    if (e == hipSuccess && levels) e = hipMemcpy(d_lcoff.p, l_coff.data(), l_coff.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && levels) e = hipMemcpy(d_lpar.p, l_par.data(), l_par.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipf(e, "upload");
+    FitchLevels fl{N, levels ? (uint32_t)level_off.size() - 1 : 0, d_lcoff.as<uint32_t>(), d_lpar.as<uint32_t>()};
     FitchTree ft{N, f.max_depth, C, d_meta.as<uint32_t>(), d_cs.as<uint32_t>(), d_cd.as<uint32_t>(),
                  d_cm.as<uint32_t>(), d_co.as<uint32_t>()};
     FitchSites fs{n_sites, d_ref.as<uint8_t>(), d_voff.as<uint32_t>(), d_vdfs.as<uint32_t>(), d_vnuc.as<uint8_t>()};
     for (uint32_t b0 = 0; b0 < nbatches; b0 += group) {
         const uint32_t nb = std::min(group, nbatches - b0);
+        if (levels) {
+            e = launch_fitch_levels(fl, level_off.data(), fs, b0, nb, d_tables.as<uint8_t>(), d_count.as<unsigned long long>(),
+                                    capacity, d_out.as<uint2>(), nullptr);
+            if (e != hipSuccess) return hipf(e, "Fitch-Sankoff kernels");
+            continue;
+        }
         if (sets_ok)
             e = launch_fitch_forward_sets(ft, fs, b0, nb, d_tables.as<uint8_t>(), d_inh.as<uint2>(), d_outp.as<uint2>(), nullptr);
         else
@@ -185,14 +220,16 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     // rows in order; inside a row, nodes in BFS order (the order mapper_body visits them, :115)
     std::vector<uint64_t> order(cnt);
     std::iota(order.begin(), order.end(), 0ull);
+    // the level-synchronous kernels report BFS indices, the stack forms DFS indices
+    auto bfs_of = [&](uint32_t y) { return levels ? (y & 0x0FFFFFFFu) : f.dfs2bfs[y & 0x0FFFFFFFu]; };
     std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
         if (raw[a].x != raw[b].x) return raw[a].x < raw[b].x;
-        return f.dfs2bfs[raw[a].y & 0x0FFFFFFFu] < f.dfs2bfs[raw[b].y & 0x0FFFFFFFu];
+        return bfs_of(raw[a].y) < bfs_of(raw[b].y);
     });
     for (uint64_t i = 0; i < cnt; i++) {
         const uint2 r = raw[order[i]];
         out_site[i] = r.x;
-        out_node[i] = f.dfs2id[r.y & 0x0FFFFFFFu];
+        out_node[i] = levels ? f.bfs2id[r.y & 0x0FFFFFFFu] : f.dfs2id[r.y & 0x0FFFFFFFu];
         out_par[i] = (uint8_t)(1u << ((r.y >> 28) & 3u));
         out_mut[i] = (uint8_t)(1u << ((r.y >> 30) & 3u));
     }

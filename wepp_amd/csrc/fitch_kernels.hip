@@ -520,6 +520,262 @@ __global__ __launch_bounds__(64) void k_fitch_backward(FitchTree t, FitchSites s
     if (qn) flush();
 }
 
+// -----------------------------------------------------------------------------
+// Level-synchronous form (the default).  Nodes in BFS order: a level is a contiguous range, the
+// children of a node are contiguous, and byte [node][row] of a batch of 64 rows holds the node's
+// "not optimal" mask (up pass) and later its state (down pass).  One launch per tree level, each
+// wave takes FITCH_LEVEL_CHUNK consecutive nodes of the level for one batch of rows (lane = row):
+//   up   (deepest level first): x = counters of the node's allowed set, + the packed
+//        [j not optimal] of every child (64-byte loads, consecutive for consecutive children),
+//        close -> mask byte.  No stack, no LDS: the waves of a level are independent.
+//   down (root first): state = keep the parent's state if it is optimal, else the lowest optimal
+//        base (:130-143); the byte is overwritten with the state; a mutation is queued where the
+//        state differs from the parent's (:145-156).
+// Same validity range as the set form above (non-empty allele sets, <= 32767 children).
+// -----------------------------------------------------------------------------
+// Output bytes of 64 consecutive nodes are staged in LDS ([node][row]) and written as dwords, 16
+// wave-stores per window instead of 64 byte-stores: on CDNA loads and stores share one in-order
+// counter (vmcnt), so a store issued per node makes the next batch of prefetched loads wait for its
+// acknowledgement; a burst per window costs one such drain per 64 nodes.
+struct RowStage {
+    uint8_t* lds;        // [64][64]
+    uint8_t* by;         // the batch's [node][row] bytes
+    uint32_t wb, end, lane;
+    __device__ __forceinline__ void flush() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nv = min(64u, end - wb);
+#pragma unroll 4
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t n = j * 4 + (lane >> 4), q = lane & 15u;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(lds + n * 64 + q * 4);
+            if (n < nv) *reinterpret_cast<uint32_t*>(by + (size_t)(wb + n) * 64 + q * 4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // nodes arrive in increasing order
+    __device__ __forceinline__ void put(uint32_t d, uint32_t v) {
+        while (d >= wb + 64) { flush(); wb += 64; }
+        lds[(d - wb) * 64 + lane] = (uint8_t)v;
+    }
+    __device__ __forceinline__ void finish() { if (wb < end) flush(); }
+};
+
+__global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels t, FitchSites s, uint32_t batch0,
+                                                                     uint32_t lev_a, uint32_t lev_b, uint32_t nchunks,
+                                                                     uint32_t nunits, uint8_t* __restrict__ bytes) {
+    // FITCH_LEVEL_WAVES independent waves per workgroup (a CU holds at most 16 LDS-using workgroups)
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[FITCH_LEVEL_WAVES][64 * 64];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t unit = blockIdx.x * FITCH_LEVEL_WAVES + wv;
+    if (unit >= nunits) return;
+    const uint32_t bl = unit / nchunks;
+    const uint32_t ch = unit % nchunks;
+    const uint32_t a = lev_a + ch * FITCH_LEVEL_CHUNK, b = min(lev_b, a + FITCH_LEVEL_CHUNK);
+    const uint32_t site = (batch0 + bl) * 64 + lane;
+    const bool have = site < s.n_sites;
+    const uint32_t ref = have ? s.ref_idx[site] : 0;
+    uint8_t* by = bytes + (size_t)bl * t.N * 64;
+    RowStage st{stage_all[wv], by, a, b, lane};
+
+    // this row's observations inside [a, b): sorted by BFS index; a two-deep queue, so that the load
+    // that refills it has a whole inter-observation gap to land
+    uint32_t vp = have ? s.var_off[site] : 0;
+    const uint32_t vend = have ? s.var_off[site + 1] : 0;
+    {
+        uint32_t lo = vp, hi = vend;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s.var_dfs[mid] < a) lo = mid + 1; else hi = mid;
+        }
+        vp = lo;
+    }
+    uint32_t vnext = vp < vend ? s.var_dfs[vp] : 0xFFFFFFFFu;
+    uint32_t vnuc = vp < vend ? s.var_nuc[vp] : 0;
+    uint32_t vnext2 = vp + 1 < vend ? s.var_dfs[vp + 1] : 0xFFFFFFFFu;
+    uint32_t vnuc2 = vp + 1 < vend ? s.var_nuc[vp + 1] : 0;
+    // observed allele set of node d for this row (nodes are visited in increasing BFS index)
+    auto observed = [&](uint32_t d, uint32_t& allowed) -> bool {
+        const bool is_var = vnext == d;
+        allowed = vnuc & 15u;
+        if (__ballot(is_var)) {
+            if (is_var) {
+                vp++;
+                vnext = vnext2;
+                vnuc = vnuc2;
+                vnext2 = vp + 1 < vend ? s.var_dfs[vp + 1] : 0xFFFFFFFFu;
+                vnuc2 = vp + 1 < vend ? s.var_nuc[vp + 1] : 0;
+            }
+        }
+        return is_var;
+    };
+    const uint32_t leaf_notopt = ~(1u << ref) & 15u;           // a leaf without an observation: reference base only (:36-45)
+    uint32_t next_node = a;                                    // nodes below it are done
+    auto leaves_until = [&](uint32_t p) {                      // the nodes in [next_node, p) have no child
+        for (uint32_t d = next_node; d < p; d++) {
+            uint32_t allowed;
+            const bool is_var = observed(d, allowed);
+            st.put(d, is_var ? (~allowed & 15u) : leaf_notopt);
+        }
+    };
+    // The children of the nodes [a, b) are the contiguous range [coff[a], coff[b]) of the level
+    // below: one stream of bytes cut into sibling groups by their parent index.  Two groups of
+    // FITCH_BACK_UNROLL bytes are in flight: the next group is requested before the current one is used.
+    const uint32_t c_begin = t.coff[a], c_end = t.coff[b];
+    uint32_t cur_par = 0xFFFFFFFFu;
+    X2 x = {0u, 0u};
+    auto close_par = [&]() {
+        X2 dl;
+        st.put(cur_par, x_close(x, dl));
+    };
+    auto load_group = [&](uint32_t c, uint32_t (&mb)[FITCH_BACK_UNROLL]) {
+#pragma unroll
+        for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) mb[u] = by[(size_t)min(c + u, c_end - 1) * 64 + lane];
+    };
+    uint32_t pv = 0;                                           // parent indices of 64 consecutive children
+    auto use_group = [&](uint32_t c, const uint32_t (&mb)[FITCH_BACK_UNROLL]) {
+#pragma unroll
+        for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) {
+            if (c + u >= c_end) break;
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pv, (int)((c + u - c_begin) & 63u));
+            if (p != cur_par) {                                    // uniform: a new sibling group
+                if (cur_par != 0xFFFFFFFFu) close_par();
+                leaves_until(p);
+                uint32_t allowed;
+                const bool is_var = observed(p, allowed);
+                x = is_var ? x_init(allowed) : X2{0u, 0u};
+                cur_par = p;
+                next_node = p + 1;
+            }
+            const X2 dx = x_delta_of_notopt(mb[u]);
+            x.a = pk_add(x.a, dx.a);
+            x.b = pk_add(x.b, dx.b);
+        }
+    };
+    static_assert(64 % (2 * FITCH_BACK_UNROLL) == 0, "two groups per step, whole steps per 64 children");
+    if (c_begin < c_end) {
+        uint32_t mbA[FITCH_BACK_UNROLL], mbB[FITCH_BACK_UNROLL];
+        load_group(c_begin, mbA);
+        for (uint32_t c = c_begin; c < c_end; c += 2 * FITCH_BACK_UNROLL) {
+            if (((c - c_begin) & 63u) == 0) {                      // the parent indices of the next 64 children
+                pv = (c + lane < c_end) ? t.parent[c + lane] : 0;
+            }
+            load_group(c + FITCH_BACK_UNROLL, mbB);
+            use_group(c, mbA);
+            load_group(c + 2 * FITCH_BACK_UNROLL, mbA);
+            use_group(c + FITCH_BACK_UNROLL, mbB);
+        }
+    }
+    if (cur_par != 0xFFFFFFFFu) close_par();
+    leaves_until(b);
+    st.finish();
+}
+
+__global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLevels t, FitchSites s, uint32_t batch0,
+                                                                       uint32_t lev_a, uint32_t lev_b, uint32_t nchunks,
+                                                                       uint32_t nunits, uint8_t* __restrict__ bytes,
+                                                                       unsigned long long* __restrict__ out_count,
+                                                                       uint64_t capacity, uint2* __restrict__ out) {
+    __shared__ uint2 queue_all[FITCH_LEVEL_WAVES][FITCH_QUEUE];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[FITCH_LEVEL_WAVES][64 * 64];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t unit = blockIdx.x * FITCH_LEVEL_WAVES + wv;
+    if (unit >= nunits) return;
+    uint2* queue = queue_all[wv];
+    const uint32_t bl = unit / nchunks;
+    const uint32_t ch = unit % nchunks;
+    const uint32_t a = lev_a + ch * FITCH_LEVEL_CHUNK, b = min(lev_b, a + FITCH_LEVEL_CHUNK);
+    const uint32_t site = (batch0 + bl) * 64 + lane;
+    const bool have = site < s.n_sites;
+    const uint32_t ref = have ? s.ref_idx[site] : 0;
+    uint8_t* by = bytes + (size_t)bl * t.N * 64;
+    RowStage st{stage_all[wv], by, a, b, lane};
+    uint32_t qn = 0;                                        // uniform
+    auto flush = [&]() {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(out_count, (unsigned long long)qn);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        for (uint32_t i = lane; i < qn; i += 64)
+            if (base + i < capacity) out[base + i] = queue[i];
+        qn = 0;
+    };
+    // mask bytes of the next nodes and the states of their parents (the level above, final): two
+    // groups in flight, the next one requested before the current one is used; siblings read the same line
+    uint32_t pv = 0;
+    auto load_group = [&](uint32_t d, uint32_t (&tb)[FITCH_BACK_UNROLL], uint32_t (&ps)[FITCH_BACK_UNROLL]) {
+#pragma unroll
+        for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) {
+            const uint32_t dd = min(d + u, b - 1);
+            tb[u] = by[(size_t)dd * 64 + lane];
+            // parent indices of the 64-node window that holds dd (pv is refreshed at window starts,
+            // before the first group of the window is requested)
+            ps[u] = by[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)pv, (int)((dd - a) & 63u)) * 64 + lane];
+        }
+    };
+    auto use_group = [&](uint32_t d0, const uint32_t (&tb)[FITCH_BACK_UNROLL], const uint32_t (&ps)[FITCH_BACK_UNROLL]) {
+#pragma unroll
+        for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) {
+            const uint32_t d = d0 + u;
+            if (d >= b) break;
+            const uint32_t par_state = (d == 0) ? ref : ps[u];                          // :119-128
+            const uint32_t state = next_state<true>(tb[u], par_state);
+            st.put(d, state);
+            const bool emit = have && state != par_state;                              // :145-156
+            const unsigned long long mask = __ballot(emit);
+            if (mask) {
+                if (emit) {
+                    const uint32_t at = qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    queue[at] = make_uint2(site, d | (par_state << 28) | (state << 30));
+                }
+                qn += (uint32_t)__popcll(mask);
+                if (qn > FITCH_QUEUE - 64) flush();
+            }
+        }
+    };
+    // windows of 64 nodes (one vector of parent indices each), 64 / FITCH_BACK_UNROLL groups per window;
+    // the first group of the next window is requested at the end of the current one
+    uint32_t tbA[FITCH_BACK_UNROLL], psA[FITCH_BACK_UNROLL], tbB[FITCH_BACK_UNROLL], psB[FITCH_BACK_UNROLL];
+    for (uint32_t w0 = a; w0 < b; w0 += 64) {
+        pv = (w0 + lane < b) ? t.parent[w0 + lane] : 0;
+        load_group(w0, tbA, psA);
+#pragma unroll 1
+        for (uint32_t g = 0; g < 64; g += 2 * FITCH_BACK_UNROLL) {
+            if (w0 + g >= b) break;
+            load_group(w0 + g + FITCH_BACK_UNROLL, tbB, psB);
+            use_group(w0 + g, tbA, psA);
+            if (g + 2 * FITCH_BACK_UNROLL < 64) load_group(w0 + g + 2 * FITCH_BACK_UNROLL, tbA, psA);
+            use_group(w0 + g + FITCH_BACK_UNROLL, tbB, psB);
+        }
+    }
+    st.finish();
+    if (qn) flush();
+}
+
+hipError_t launch_fitch_levels(const FitchLevels& t, const uint32_t* h_level_off, const FitchSites& s, uint32_t batch0,
+                               uint32_t nbatches, uint8_t* bytes, unsigned long long* out_count, uint64_t capacity,
+                               uint2* out, hipStream_t stream) {
+    for (uint32_t l = t.n_levels; l-- > 0;) {                 // up: deepest level first
+        const uint32_t a = h_level_off[l], b = h_level_off[l + 1];
+        const uint32_t nch = (b - a + FITCH_LEVEL_CHUNK - 1) / FITCH_LEVEL_CHUNK;
+        const uint32_t units = nch * nbatches;
+        hipLaunchKernelGGL(k_fitch_up, dim3((units + FITCH_LEVEL_WAVES - 1) / FITCH_LEVEL_WAVES), dim3(64 * FITCH_LEVEL_WAVES),
+                           0, stream, t, s, batch0, a, b, nch, units, bytes);
+    }
+    for (uint32_t l = 0; l < t.n_levels; l++) {               // down: root first
+        const uint32_t a = h_level_off[l], b = h_level_off[l + 1];
+        const uint32_t nch = (b - a + FITCH_LEVEL_CHUNK - 1) / FITCH_LEVEL_CHUNK;
+        const uint32_t units = nch * nbatches;
+        hipLaunchKernelGGL(k_fitch_down, dim3((units + FITCH_LEVEL_WAVES - 1) / FITCH_LEVEL_WAVES),
+                           dim3(64 * FITCH_LEVEL_WAVES), 0, stream, t, s, batch0, a, b, nch, units, bytes, out_count, capacity,
+                           out);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_fitch_forward_sets(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
                                      uint8_t* tables, uint2* inh_part, uint2* out_part, hipStream_t stream) {
     const uint32_t lds = (t.max_depth + 1) * 64 * 8 + (t.max_depth + 2) * 4;
