@@ -53,6 +53,31 @@ def test_fuzz_trees_vs_oracle(oracle, tile):
         mat.close()
 
 
+@pytest.mark.parametrize("crowns", [True, False])
+def test_duplicate_reads_and_sorted_batches(oracle, crowns):
+    """Batches with many word-for-word equal reads (one node-by-node evaluation serves all the equal
+    reads of a tile) in shuffled and in position-sorted order, on trees small enough for ties; with
+    >= 4096 reads on the whole-tree stream the library sorts them by first position itself."""
+    rng = np.random.default_rng(4242 + int(crowns))
+    for it in range(6):
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(30, 400)), genome=80)
+        base = [ft.random_sample(rng, ref, genome=80, max_k=int(rng.integers(1, 7))) for _ in range(60)]
+        samples = []
+        for smp in base:
+            samples += [smp] * int(rng.integers(1, 160))
+        order = rng.permutation(len(samples))
+        shuffled = [samples[i] for i in order]
+        assert len(shuffled) >= 4096
+        by_pos = sorted(shuffled, key=lambda e: (e[0][0] if e else -1, len(e)))
+        mat = w.Mat(tree)
+        mat.set_use_crowns(crowns)
+        ot = oracle.OracleTree(tree)
+        for name, batch in (("shuffled", shuffled), ("sorted", by_pos)):
+            reads = ft.reads_from_samples(batch)
+            assert_same(mat.place_batch(reads), ot.place_batch(reads, 8), f"dups {it} {name} crowns={crowns}")
+        mat.close()
+
+
 def test_per_node_scores_mode_vs_oracle(oracle):
     """--write-parsimony-scores-per-node: all N values per read (usher_common.cpp:403-409)."""
     rng = np.random.default_rng(321)
