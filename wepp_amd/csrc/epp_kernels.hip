@@ -42,29 +42,51 @@ constexpr uint32_t W_EXIT_BIT = 1u << 30;
 constexpr uint32_t PAD_WORD = 0x000FFFFFu;
 constexpr int INT_INF = 0x7FFFFFFF;
 
+// Wave-wide reductions, returned wave-uniform: four DPP row shifts leave the result of every row of
+// 16 lanes in its last lane, four readlanes and scalar operations finish (no LDS permutes).
+#define WEPP_DPP_SHR(old, x, n) __builtin_amdgcn_update_dpp((int)(old), (int)(x), 0x110 + (n), 0xF, 0xF, false)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o < v ? o : v; }
-    return v;
+    v = min(v, (uint32_t)WEPP_DPP_SHR(-1, v, 1));
+    v = min(v, (uint32_t)WEPP_DPP_SHR(-1, v, 2));
+    v = min(v, (uint32_t)WEPP_DPP_SHR(-1, v, 4));
+    v = min(v, (uint32_t)WEPP_DPP_SHR(-1, v, 8));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return min(min(a, b), min(c, d));
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o > v ? o : v; }
-    return v;
+    v = max(v, (uint32_t)WEPP_DPP_SHR(0, v, 1));
+    v = max(v, (uint32_t)WEPP_DPP_SHR(0, v, 2));
+    v = max(v, (uint32_t)WEPP_DPP_SHR(0, v, 4));
+    v = max(v, (uint32_t)WEPP_DPP_SHR(0, v, 8));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += WEPP_DPP_SHR(0, v, 1);
+    v += WEPP_DPP_SHR(0, v, 2);
+    v += WEPP_DPP_SHR(0, v, 4);
+    v += WEPP_DPP_SHR(0, v, 8);
+    return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) +
+           __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const int lo = __shfl_xor((int)(uint32_t)v, m, 64), hi = __shfl_xor((int)(v >> 32), m, 64);
-        v += (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+#define WEPP_SUM64_STEP(n)                                                                                   \
+    {                                                                                                        \
+        const uint32_t lo = (uint32_t)WEPP_DPP_SHR(0, (uint32_t)v, n), hi = (uint32_t)WEPP_DPP_SHR(0, (uint32_t)(v >> 32), n); \
+        v += (long long)(((unsigned long long)hi << 32) | lo);                                               \
     }
-    return v;
+    WEPP_SUM64_STEP(1) WEPP_SUM64_STEP(2) WEPP_SUM64_STEP(4) WEPP_SUM64_STEP(8)
+#undef WEPP_SUM64_STEP
+    long long r = 0;
+#pragma unroll
+    for (int l = 15; l < 64; l += 16)
+        r += (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l));
+    return r;
 }
+#undef WEPP_DPP_SHR
 // groups that may hold position p: ws ascending, we_max = running maximum of we
 __device__ __forceinline__ void candidate_groups(const uint32_t* ws, const uint32_t* wemax, uint32_t G, uint32_t p,
                                                  uint32_t& g_lo, uint32_t& g_hi_excl) {

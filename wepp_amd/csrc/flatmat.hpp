@@ -78,7 +78,12 @@ struct Stream {
     // reaches block i*cp_stride (node blk_node0[..]-1 unless it closes there, and its ancestors)
     std::vector<uint32_t> cp_off;      // [ncp+1]
     std::vector<uint32_t> cp_word;
-    uint64_t stream_bytes() const { return 4ull * E + (uint64_t)NB * (sizeof(BlkSum) + 4); }
+    // bytes one sweep reads whatever the reads are: event words, block offsets and summaries, and -- on
+    // a crown (tau finite), where the per-event bounds are fetched with the event words -- one bound byte
+    // per event; node keys / flags / event offsets are only touched by node-by-node evaluations
+    uint64_t stream_bytes() const {
+        return 4ull * E + (uint64_t)NB * (sizeof(BlkSum) + 4) + (tau != 0x7FFFFFFF ? E : 0ull);
+    }
 };
 
 struct FlatMAT {
