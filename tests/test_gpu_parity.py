@@ -64,7 +64,7 @@ def test_duplicate_reads_and_sorted_batches(oracle, crowns):
         base = [ft.random_sample(rng, ref, genome=80, max_k=int(rng.integers(1, 7))) for _ in range(60)]
         samples = []
         for smp in base:
-            samples += [smp] * int(rng.integers(1, 160))
+            samples += [smp] * int(rng.integers(70, 200))
         order = rng.permutation(len(samples))
         shuffled = [samples[i] for i in order]
         assert len(shuffled) >= 4096

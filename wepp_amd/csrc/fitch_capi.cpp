@@ -45,7 +45,7 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     FlatMAT f;
     std::string err;
     try {
-        int rc = flatten_tree(topo, f, err);
+        int rc = flatten_tree(topo, f, err, /*topology_only=*/true);
         if (rc != WEPP_OK) return set_error(rc, err);
     } catch (const std::bad_alloc&) {
         return set_error(WEPP_ENOMEM, "out of host memory while flattening the tree");
@@ -214,6 +214,34 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (cnt > capacity) return set_error(WEPP_ELIMIT, "output buffers too small: " + std::to_string(cnt) + " mutations");
     if (cnt == 0) return WEPP_OK;
     if (!out_site || !out_node || !out_par || !out_mut) return set_error(WEPP_EINVAL, "null output buffer");
+    if (levels) {
+        // sorted on the device: key = row << 28 | BFS index, 28 + bits(n_sites) key bits
+        uint32_t site_bits = 1;
+        while (site_bits < 32 && (1ull << site_bits) < n_sites) site_bits++;
+        DevBuf d_k0, d_k1, d_v0, d_v1, d_tmp;
+        size_t tmp_bytes = 0;
+        e = sort_u64_u32_temp_bytes(cnt, 28 + site_bits, &tmp_bytes);
+        if (e == hipSuccess && ((e = d_k0.alloc(cnt * 8)) != hipSuccess || (e = d_k1.alloc(cnt * 8)) != hipSuccess ||
+                                (e = d_v0.alloc(cnt * 4)) != hipSuccess || (e = d_v1.alloc(cnt * 4)) != hipSuccess ||
+                                (e = d_tmp.alloc(tmp_bytes)) != hipSuccess))
+            return set_error(WEPP_ENOMEM, std::string("hipMalloc (sort of the mutations): ") + hipGetErrorString(e));
+        if (e == hipSuccess) e = launch_fitch_sort_keys(d_out.as<uint2>(), cnt, d_k0.as<unsigned long long>(), d_v0.as<uint32_t>(), nullptr);
+        if (e == hipSuccess)
+            e = launch_sort_u64_u32(d_k0.as<unsigned long long>(), d_k1.as<unsigned long long>(), d_v0.as<uint32_t>(),
+                                    d_v1.as<uint32_t>(), cnt, 28 + site_bits, d_tmp.p, tmp_bytes, nullptr);
+        std::vector<unsigned long long> keys(cnt);
+        std::vector<uint32_t> vals(cnt);
+        if (e == hipSuccess) e = hipMemcpy(keys.data(), d_k1.p, cnt * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(vals.data(), d_v1.p, cnt * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hipf(e, "sort / D2H copy of the mutations");
+        for (uint64_t i = 0; i < cnt; i++) {
+            out_site[i] = (uint32_t)(keys[i] >> 28);
+            out_node[i] = f.bfs2id[vals[i] & 0x0FFFFFFFu];
+            out_par[i] = (uint8_t)(1u << ((vals[i] >> 28) & 3u));
+            out_mut[i] = (uint8_t)(1u << ((vals[i] >> 30) & 3u));
+        }
+        return WEPP_OK;
+    }
     std::vector<uint2> raw(cnt);
     e = hipMemcpy(raw.data(), d_out.p, cnt * 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hipf(e, "D2H copy of the mutations");

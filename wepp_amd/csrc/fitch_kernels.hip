@@ -755,6 +755,21 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLeve
     if (qn) flush();
 }
 
+__global__ void k_fitch_sort_keys(const uint2* __restrict__ out, uint64_t n, unsigned long long* __restrict__ keys,
+                                  uint32_t* __restrict__ vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 r = out[i];
+    keys[i] = ((unsigned long long)r.x << 28) | (r.y & 0x0FFFFFFFu);
+    vals[i] = r.y;
+}
+
+hipError_t launch_fitch_sort_keys(const uint2* out, uint64_t n, unsigned long long* keys, uint32_t* vals, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fitch_sort_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, keys, vals);
+    return hipGetLastError();
+}
+
 hipError_t launch_fitch_levels(const FitchLevels& t, const uint32_t* h_level_off, const FitchSites& s, uint32_t batch0,
                                uint32_t nbatches, uint8_t* bytes, unsigned long long* out_count, uint64_t capacity,
                                uint2* out, hipStream_t stream) {

@@ -185,7 +185,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
 
 }  // namespace
 
-int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
+int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool topology_only) {
     const uint32_t N = t.n_nodes;
     if (N == 0 || !t.parent || !t.mut_off) { err = "empty tree or null arrays"; return WEPP_EINVAL; }
     if (N >= 0xFFFFFFF0u) { err = "too many nodes"; return WEPP_ELIMIT; }
@@ -374,6 +374,8 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err) {
             open.push_back(d);
         }
     }
+
+    if (topology_only) return WEPP_OK;     // orders, parents, leaf flags: all the Fitch-Sankoff pass needs
 
     // ---- tie-break rank: larger num_leaves first, then larger BFS index -----
     f.rank2dfs.resize(N);

@@ -119,6 +119,7 @@ struct FlatMAT {
 constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of wepp_mat_stats
 
 // Returns WEPP_OK or an error code; `err` receives the message.
-int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err);
+// topology_only: stop after the orders / parents / per-node flags (no tie-break ranks, sweep streams, EPP stream)
+int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err, bool topology_only = false);
 
 }  // namespace wepp

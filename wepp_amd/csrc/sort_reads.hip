@@ -9,6 +9,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "device_mat.hpp"
+#include "fitch.hpp"
 
 namespace wepp {
 
@@ -22,6 +23,19 @@ hipError_t launch_sort_reads(const uint32_t* keys_in, uint32_t* keys_out, const 
                              uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream) {
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, SORT_KEY_BITS,
                                      stream);
+}
+
+// 64-bit keys / 32-bit values (the mutations emitted by the Fitch-Sankoff down pass: key = row | node)
+hipError_t sort_u64_u32_temp_bytes(uint64_t n, uint32_t end_bit, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, *bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, end_bit, nullptr);
+}
+
+hipError_t launch_sort_u64_u32(const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
+                               uint32_t* vals_out, uint64_t n, uint32_t end_bit, void* temp, size_t temp_bytes,
+                               hipStream_t stream) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, stream);
 }
 
 }  // namespace wepp
