@@ -806,7 +806,9 @@ __device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, co
         cnt = csum;
     }
     if (lane != 0) return;
-    const uint32_t d = m.rank2dfs[br];
+    // the root always competes, so some chunk reports it or better; the clamp only keeps a broken
+    // invariant from becoming an out-of-bounds read
+    const uint32_t d = m.rank2dfs[br < m.N ? br : 0u];
     const uint32_t st = m.nstat[d];
     uint32_t hu = 0;
     if (!(st & NS_ROOT_DEV)) {
