@@ -95,8 +95,10 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
 constexpr uint32_t SWEEP_WAVES = WEPP_SWEEP_WAVES;            // independent sweeps (waves) per workgroup of k_sweep_multi
 constexpr uint32_t DENSE_WAVES_PER_WG = WEPP_DENSE_WAVES;     // waves sharing one tile's LDS index in the dense variant
 // LDS bytes of a k_sweep workgroup: bitmap + read words (+ dense: sorted keys + owners + accumulators)
+constexpr uint32_t DENSE_WINDOW = 4096;   // positions behind the tile's smallest one with a direct index into the sorted keys
 inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense) {
-    return bm_words * 4 + ent_cap * (dense ? 5 : 4) + (dense ? key_cap * 4 + DENSE_WAVES_PER_WG * 3 * 64 * 4 : 0);
+    return bm_words * 4 + ent_cap * (dense ? 5 : 4) +
+           (dense ? key_cap * 4 + DENSE_WAVES_PER_WG * 3 * 64 * 4 + DENSE_WINDOW * 2 : 0);
 }
 // read words per tile: the plain variant is bounded by its LDS request, the dense variant by
 // the 13-bit entry index of its sorted keys (pos:19 | idx:13, hence also max_pos < 2^19)

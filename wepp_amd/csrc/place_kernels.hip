@@ -277,6 +277,10 @@ __device__ __forceinline__ void sweep_tile(
     // control then run on the scalar unit
     const uint32_t wv = DENSE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
     int* acc = reinterpret_cast<int*>(owner + ent_cap) + wv * 192;   // net[64], H[64], bound[64] of this wave
+    // DENSE: wtab[p - plo] = index of the first sorted key at position p (0xFFFF = none) for the
+    // DENSE_WINDOW positions from the tile's smallest one: reads of one amplicon (batches sorted by
+    // position) fall inside, and an event then finds its reads with one LDS read instead of a binary search
+    uint16_t* wtab = reinterpret_cast<uint16_t*>(reinterpret_cast<int*>(owner + ent_cap) + NW * 192);
 
     const uint32_t tile = wg % ntiles;
     const uint32_t chunk = (wg / ntiles) * NW + wv;
@@ -343,6 +347,17 @@ __device__ __forceinline__ void sweep_tile(
                 __syncthreads();
             }
         }
+    }
+    uint32_t plo = 0;
+    if (DENSE) {
+        for (uint32_t i = threadIdx.x; i < DENSE_WINDOW; i += 64 * NW) wtab[i] = 0xFFFFu;
+        __syncthreads();
+        plo = n_ent ? (skey[0] >> 13) : 0u;
+        for (uint32_t i = threadIdx.x; i < n_ent; i += 64 * NW) {
+            const uint32_t p = skey[i] >> 13, rel = p - plo;
+            if (rel < DENSE_WINDOW && (i == 0 || (skey[i - 1] >> 13) != p)) wtab[rel] = (uint16_t)i;
+        }
+        __syncthreads();
     }
     // from here on the waves of a workgroup never synchronise with each other again
 
@@ -594,11 +609,20 @@ __device__ __forceinline__ void sweep_tile(
                 // dependent LDS reads in flight instead of one
                 const uint32_t p0 = w_pos(w0), p1 = w_pos(w1);
                 const uint32_t want0 = p0 << 13, want1 = p1 << 13;
-                uint32_t lo0 = 0, lo1 = 0;
-                for (uint32_t step = n2 >> 1; step > 0; step >>= 1) {          // lower_bound, n2 is a power of two
-                    const uint32_t k0 = skey[lo0 + step - 1], k1 = skey[lo1 + step - 1];
-                    if (k0 < want0) lo0 += step;
-                    if (k1 < want1) lo1 += step;
+                const bool act0 = (hm0 >> lane) & 1ull, act1 = (hm1 >> lane) & 1ull;
+                const uint32_t rel0 = p0 - plo, rel1 = p1 - plo;
+                // inside the window: direct index (0xFFFF = no read lists the position: fails `i < n2` below)
+                uint32_t lo0 = (act0 && rel0 < DENSE_WINDOW) ? wtab[rel0] : 0u;
+                uint32_t lo1 = (act1 && rel1 < DENSE_WINDOW) ? wtab[rel1] : 0u;
+                if (__ballot((act0 && rel0 >= DENSE_WINDOW) || (act1 && rel1 >= DENSE_WINDOW))) {
+                    uint32_t b0s = 0, b1s = 0;
+                    for (uint32_t step = n2 >> 1; step > 0; step >>= 1) {      // lower_bound, n2 is a power of two
+                        const uint32_t k0 = skey[b0s + step - 1], k1 = skey[b1s + step - 1];
+                        if (k0 < want0) b0s += step;
+                        if (k1 < want1) b1s += step;
+                    }
+                    if (rel0 >= DENSE_WINDOW) lo0 = b0s;
+                    if (rel1 >= DENSE_WINDOW) lo1 = b1s;
                 }
                 auto dense_apply = [&](uint32_t w, uint32_t p, uint32_t lb, uint32_t i, bool act) {
                     while (__ballot(act && i < n2 && (skey[min(i, n2 - 1)] >> 13) == p)) {
@@ -620,8 +644,8 @@ __device__ __forceinline__ void sweep_tile(
                         i++;
                     }
                 };
-                dense_apply(w0, p0, lb0, lo0, (hm0 >> lane) & 1ull);
-                dense_apply(w1, p1, lb1, lo1, (hm1 >> lane) & 1ull);
+                dense_apply(w0, p0, lb0, lo0, act0);
+                dense_apply(w1, p1, lb1, lo1, act1);
                 // the accumulators belong to this wave alone; its LDS operations complete in
                 // program order, the barriers only stop the compiler from reordering them
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
