@@ -37,6 +37,7 @@ constexpr uint32_t FITCH_LEVEL_CHUNK = WEPP_FITCH_LEVEL_CHUNK;   // consecutive 
 #ifndef WEPP_FITCH_LEVEL_WAVES
 #define WEPP_FITCH_LEVEL_WAVES 4
 #endif
+constexpr uint32_t FITCH_ROWS_PER_LANE = 4;   // level kernels: a batch is 64 * 4 VCF rows, one dword of bytes per lane and node
 constexpr uint32_t FITCH_LEVEL_WAVES = WEPP_FITCH_LEVEL_WAVES;   // independent waves per workgroup of the level kernels
 
 constexpr uint32_t FITCH_MAX_DEPTH = 140;   // (depth + 1) KiB of LDS per wave
@@ -51,8 +52,8 @@ hipError_t launch_fitch_forward(const FitchTree& t, const FitchSites& s, uint32_
 constexpr uint32_t FITCH_SETS_MAX_CHILDREN = 32767;
 hipError_t launch_fitch_forward_sets(const FitchTree& t, const FitchSites& s, uint32_t batch0, uint32_t nbatches,
                                      uint8_t* tables, uint2* inh_part, uint2* out_part, hipStream_t stream);
-// level-synchronous form (the default when the set form is valid): `bytes` = [nbatches][N][64] in BFS
-// order; FitchSites::var_dfs then holds BFS indices; emitted node indices are BFS indices
+// level-synchronous form (the default when the set form is valid): `bytes` = [nbatches][N][256] in BFS
+// order, batches of 256 rows (batch0 / nbatches count those); FitchSites::var_dfs then holds BFS indices; emitted node indices are BFS indices
 hipError_t launch_fitch_levels(const FitchLevels& t, const uint32_t* h_level_off, const FitchSites& s, uint32_t batch0,
                                uint32_t nbatches, uint8_t* bytes, unsigned long long* out_count, uint64_t capacity,
                                uint2* out, hipStream_t stream);

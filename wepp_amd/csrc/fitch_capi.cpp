@@ -156,17 +156,18 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         for (uint32_t i = 0; i < N; i++) l_coff[i + 1] += l_coff[i];
         level_off.push_back(N);
     }
-    const uint32_t nbatches = (n_sites + 63) / 64;
+    const uint32_t rows_per_batch = levels ? 64 * FITCH_ROWS_PER_LANE : 64;
+    const uint32_t nbatches = (n_sites + rows_per_batch - 1) / rows_per_batch;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     // per batch of 64 rows: the decision tables and the two partial-sum scratch arrays
     const size_t part_bytes = levels ? 0 : (size_t)C * D * 64 * 16;
-    const size_t per_batch = (size_t)N * 64 + 2 * part_bytes;
+    const size_t per_batch = (size_t)N * rows_per_batch + 2 * part_bytes;
     const size_t budget = free_b / 2;
     const uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nbatches, budget / std::max<size_t>(per_batch, 1)));
     if ((e = d_meta.alloc((size_t)N * 4)) != hipSuccess || (e = d_ref.alloc(n_sites)) != hipSuccess ||
         (e = d_voff.alloc((size_t)(n_sites + 1) * 4)) != hipSuccess || (e = d_vdfs.alloc(nv * 4)) != hipSuccess ||
-        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_tables.alloc((size_t)N * 64 * group)) != hipSuccess ||
+        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_tables.alloc((size_t)N * rows_per_batch * group)) != hipSuccess ||
         (e = d_inh.alloc(part_bytes * group)) != hipSuccess || (e = d_outp.alloc(part_bytes * group)) != hipSuccess ||
         (e = d_cs.alloc((C + 1) * 4)) != hipSuccess || (e = d_cd.alloc((C + 1) * 4)) != hipSuccess ||
         (e = d_cm.alloc(C * 4)) != hipSuccess || (e = d_co.alloc(chunk_open.size() * 4)) != hipSuccess ||

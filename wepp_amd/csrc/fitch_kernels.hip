@@ -533,40 +533,16 @@ __global__ __launch_bounds__(64) void k_fitch_backward(FitchTree t, FitchSites s
 //        state differs from the parent's (:145-156).
 // Same validity range as the set form above (non-empty allele sets, <= 32767 children).
 // -----------------------------------------------------------------------------
-// Output bytes of 64 consecutive nodes are staged in LDS ([node][row]) and written as dwords, 16
-// wave-stores per window instead of 64 byte-stores: on CDNA loads and stores share one in-order
-// counter (vmcnt), so a store issued per node makes the next batch of prefetched loads wait for its
-// acknowledgement; a burst per window costs one such drain per 64 nodes.
-struct RowStage {
-    uint8_t* lds;        // [64][64]
-    uint8_t* by;         // the batch's [node][row] bytes
-    uint32_t wb, end, lane;
-    __device__ __forceinline__ void flush() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t nv = min(64u, end - wb);
-#pragma unroll 4
-        for (uint32_t j = 0; j < 16; j++) {
-            const uint32_t n = j * 4 + (lane >> 4), q = lane & 15u;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(lds + n * 64 + q * 4);
-            if (n < nv) *reinterpret_cast<uint32_t*>(by + (size_t)(wb + n) * 64 + q * 4) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // nodes arrive in increasing order
-    __device__ __forceinline__ void put(uint32_t d, uint32_t v) {
-        while (d >= wb + 64) { flush(); wb += 64; }
-        lds[(d - wb) * 64 + lane] = (uint8_t)v;
-    }
-    __device__ __forceinline__ void finish() { if (wb < end) flush(); }
-};
+// Four rows per lane (a batch = 256 VCF rows): the byte row of a node is 256 B, every wave load or
+// store moves a whole dword per lane -- 256-byte requests instead of 64-byte ones (one byte per lane
+// left the memory system request-bound at ~2.3 TB/s) -- and the wave-uniform part of a node (offsets,
+// branches, `readlane`s) is shared by four times as many rows.
+constexpr uint32_t FR = FITCH_ROWS_PER_LANE;
+static_assert(FR == 4, "one dword of mask / state bytes per lane");
 
 __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels t, FitchSites s, uint32_t batch0,
                                                                      uint32_t lev_a, uint32_t lev_b, uint32_t nchunks,
                                                                      uint32_t nunits, uint8_t* __restrict__ bytes) {
-    // FITCH_LEVEL_WAVES independent waves per workgroup (a CU holds at most 16 LDS-using workgroups)
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[FITCH_LEVEL_WAVES][64 * 64];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t unit = blockIdx.x * FITCH_LEVEL_WAVES + wv;
@@ -574,65 +550,83 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels
     const uint32_t bl = unit / nchunks;
     const uint32_t ch = unit % nchunks;
     const uint32_t a = lev_a + ch * FITCH_LEVEL_CHUNK, b = min(lev_b, a + FITCH_LEVEL_CHUNK);
-    const uint32_t site = (batch0 + bl) * 64 + lane;
-    const bool have = site < s.n_sites;
-    const uint32_t ref = have ? s.ref_idx[site] : 0;
-    uint8_t* by = bytes + (size_t)bl * t.N * 64;
-    RowStage st{stage_all[wv], by, a, b, lane};
+    uint32_t* by = reinterpret_cast<uint32_t*>(bytes + (size_t)bl * t.N * (64 * FR)) + lane;   // + node * 64: this lane's 4 rows
 
-    // this row's observations inside [a, b): sorted by BFS index; a two-deep queue, so that the load
-    // that refills it has a whole inter-observation gap to land
-    uint32_t vp = have ? s.var_off[site] : 0;
-    const uint32_t vend = have ? s.var_off[site + 1] : 0;
-    {
-        uint32_t lo = vp, hi = vend;
+    // the observations of this lane's rows inside [a, b): sorted by BFS index; two-deep queues, so that
+    // the load that refills one has a whole inter-observation gap to land
+    uint32_t vp[FR], vend[FR], vnext[FR], vnuc[FR], vnext2[FR], vnuc2[FR], leaf_no[FR];
+#pragma unroll
+    for (uint32_t q = 0; q < FR; q++) {
+        const uint32_t site = ((batch0 + bl) * 64 + lane) * FR + q;
+        const bool have = site < s.n_sites;
+        leaf_no[q] = ~(1u << (have ? s.ref_idx[site] : 0)) & 15u;     // a leaf without an observation: reference base only (:36-45)
+        vp[q] = have ? s.var_off[site] : 0;
+        vend[q] = have ? s.var_off[site + 1] : 0;
+        uint32_t lo = vp[q], hi = vend[q];
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             if (s.var_dfs[mid] < a) lo = mid + 1; else hi = mid;
         }
-        vp = lo;
+        vp[q] = lo;
+        vnext[q] = vp[q] < vend[q] ? s.var_dfs[vp[q]] : 0xFFFFFFFFu;
+        vnuc[q] = vp[q] < vend[q] ? s.var_nuc[vp[q]] : 0;
+        vnext2[q] = vp[q] + 1 < vend[q] ? s.var_dfs[vp[q] + 1] : 0xFFFFFFFFu;
+        vnuc2[q] = vp[q] + 1 < vend[q] ? s.var_nuc[vp[q] + 1] : 0;
     }
-    uint32_t vnext = vp < vend ? s.var_dfs[vp] : 0xFFFFFFFFu;
-    uint32_t vnuc = vp < vend ? s.var_nuc[vp] : 0;
-    uint32_t vnext2 = vp + 1 < vend ? s.var_dfs[vp + 1] : 0xFFFFFFFFu;
-    uint32_t vnuc2 = vp + 1 < vend ? s.var_nuc[vp + 1] : 0;
-    // observed allele set of node d for this row (nodes are visited in increasing BFS index)
-    auto observed = [&](uint32_t d, uint32_t& allowed) -> bool {
-        const bool is_var = vnext == d;
-        allowed = vnuc & 15u;
-        if (__ballot(is_var)) {
-            if (is_var) {
-                vp++;
-                vnext = vnext2;
-                vnuc = vnuc2;
-                vnext2 = vp + 1 < vend ? s.var_dfs[vp + 1] : 0xFFFFFFFFu;
-                vnuc2 = vp + 1 < vend ? s.var_nuc[vp + 1] : 0;
+    // observed allele sets of node d for this lane's rows (nodes are visited in increasing BFS index):
+    // bit q of the result = row q observes the node, allowed[q] = its set
+    auto observed = [&](uint32_t d, uint32_t (&allowed)[FR]) -> uint32_t {
+        uint32_t is = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < FR; q++) {
+            allowed[q] = vnuc[q] & 15u;
+            is |= (vnext[q] == d ? 1u : 0u) << q;
+        }
+        if (__ballot(is != 0)) {
+#pragma unroll
+            for (uint32_t q = 0; q < FR; q++) {
+                if ((is >> q) & 1u) {
+                    vp[q]++;
+                    vnext[q] = vnext2[q];
+                    vnuc[q] = vnuc2[q];
+                    vnext2[q] = vp[q] + 1 < vend[q] ? s.var_dfs[vp[q] + 1] : 0xFFFFFFFFu;
+                    vnuc2[q] = vp[q] + 1 < vend[q] ? s.var_nuc[vp[q] + 1] : 0;
+                }
             }
         }
-        return is_var;
+        return is;
     };
-    const uint32_t leaf_notopt = ~(1u << ref) & 15u;           // a leaf without an observation: reference base only (:36-45)
     uint32_t next_node = a;                                    // nodes below it are done
     auto leaves_until = [&](uint32_t p) {                      // the nodes in [next_node, p) have no child
         for (uint32_t d = next_node; d < p; d++) {
-            uint32_t allowed;
-            const bool is_var = observed(d, allowed);
-            st.put(d, is_var ? (~allowed & 15u) : leaf_notopt);
+            uint32_t allowed[FR];
+            const uint32_t is = observed(d, allowed);
+            uint32_t w = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < FR; q++) w |= (((is >> q) & 1u) ? (~allowed[q] & 15u) : leaf_no[q]) << (8 * q);
+            by[(size_t)d * 64] = w;
         }
     };
     // The children of the nodes [a, b) are the contiguous range [coff[a], coff[b]) of the level
-    // below: one stream of bytes cut into sibling groups by their parent index.  Two groups of
-    // FITCH_BACK_UNROLL bytes are in flight: the next group is requested before the current one is used.
+    // below: one stream of byte rows cut into sibling groups by their parent index.  Two groups of
+    // FITCH_BACK_UNROLL rows are in flight: the next group is requested before the current one is used.
     const uint32_t c_begin = t.coff[a], c_end = t.coff[b];
     uint32_t cur_par = 0xFFFFFFFFu;
-    X2 x = {0u, 0u};
+    X2 x[FR];
+#pragma unroll
+    for (uint32_t q = 0; q < FR; q++) x[q] = X2{0u, 0u};
     auto close_par = [&]() {
-        X2 dl;
-        st.put(cur_par, x_close(x, dl));
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < FR; q++) {
+            X2 dl;
+            w |= x_close(x[q], dl) << (8 * q);
+        }
+        by[(size_t)cur_par * 64] = w;
     };
     auto load_group = [&](uint32_t c, uint32_t (&mb)[FITCH_BACK_UNROLL]) {
 #pragma unroll
-        for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) mb[u] = by[(size_t)min(c + u, c_end - 1) * 64 + lane];
+        for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) mb[u] = by[(size_t)min(c + u, c_end - 1) * 64];
     };
     uint32_t pv = 0;                                           // parent indices of 64 consecutive children
     auto use_group = [&](uint32_t c, const uint32_t (&mb)[FITCH_BACK_UNROLL]) {
@@ -643,15 +637,19 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels
             if (p != cur_par) {                                    // uniform: a new sibling group
                 if (cur_par != 0xFFFFFFFFu) close_par();
                 leaves_until(p);
-                uint32_t allowed;
-                const bool is_var = observed(p, allowed);
-                x = is_var ? x_init(allowed) : X2{0u, 0u};
+                uint32_t allowed[FR];
+                const uint32_t is = observed(p, allowed);
+#pragma unroll
+                for (uint32_t q = 0; q < FR; q++) x[q] = ((is >> q) & 1u) ? x_init(allowed[q]) : X2{0u, 0u};
                 cur_par = p;
                 next_node = p + 1;
             }
-            const X2 dx = x_delta_of_notopt(mb[u]);
-            x.a = pk_add(x.a, dx.a);
-            x.b = pk_add(x.b, dx.b);
+#pragma unroll
+            for (uint32_t q = 0; q < FR; q++) {
+                const X2 dx = x_delta_of_notopt((mb[u] >> (8 * q)) & 15u);
+                x[q].a = pk_add(x[q].a, dx.a);
+                x[q].b = pk_add(x[q].b, dx.b);
+            }
         }
     };
     static_assert(64 % (2 * FITCH_BACK_UNROLL) == 0, "two groups per step, whole steps per 64 children");
@@ -670,7 +668,6 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels
     }
     if (cur_par != 0xFFFFFFFFu) close_par();
     leaves_until(b);
-    st.finish();
 }
 
 __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLevels t, FitchSites s, uint32_t batch0,
@@ -679,7 +676,6 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLeve
                                                                        unsigned long long* __restrict__ out_count,
                                                                        uint64_t capacity, uint2* __restrict__ out) {
     __shared__ uint2 queue_all[FITCH_LEVEL_WAVES][FITCH_QUEUE];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[FITCH_LEVEL_WAVES][64 * 64];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t unit = blockIdx.x * FITCH_LEVEL_WAVES + wv;
@@ -688,11 +684,16 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLeve
     const uint32_t bl = unit / nchunks;
     const uint32_t ch = unit % nchunks;
     const uint32_t a = lev_a + ch * FITCH_LEVEL_CHUNK, b = min(lev_b, a + FITCH_LEVEL_CHUNK);
-    const uint32_t site = (batch0 + bl) * 64 + lane;
-    const bool have = site < s.n_sites;
-    const uint32_t ref = have ? s.ref_idx[site] : 0;
-    uint8_t* by = bytes + (size_t)bl * t.N * 64;
-    RowStage st{stage_all[wv], by, a, b, lane};
+    uint32_t* by = reinterpret_cast<uint32_t*>(bytes + (size_t)bl * t.N * (64 * FR)) + lane;
+    const uint32_t site0 = ((batch0 + bl) * 64 + lane) * FR;
+    uint32_t refw = 0;                                      // the four rows' reference bases, one per byte
+    uint32_t have_mask = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < FR; q++) {
+        const bool have = site0 + q < s.n_sites;
+        have_mask |= (have ? 1u : 0u) << q;
+        refw |= (have ? (uint32_t)s.ref_idx[site0 + q] : 0u) << (8 * q);
+    }
     uint32_t qn = 0;                                        // uniform
     auto flush = [&]() {
         unsigned long long base = 0;
@@ -703,17 +704,15 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLeve
             if (base + i < capacity) out[base + i] = queue[i];
         qn = 0;
     };
-    // mask bytes of the next nodes and the states of their parents (the level above, final): two
+    // mask rows of the next nodes and the state rows of their parents (the level above, final): two
     // groups in flight, the next one requested before the current one is used; siblings read the same line
     uint32_t pv = 0;
     auto load_group = [&](uint32_t d, uint32_t (&tb)[FITCH_BACK_UNROLL], uint32_t (&ps)[FITCH_BACK_UNROLL]) {
 #pragma unroll
         for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) {
             const uint32_t dd = min(d + u, b - 1);
-            tb[u] = by[(size_t)dd * 64 + lane];
-            // parent indices of the 64-node window that holds dd (pv is refreshed at window starts,
-            // before the first group of the window is requested)
-            ps[u] = by[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)pv, (int)((dd - a) & 63u)) * 64 + lane];
+            tb[u] = by[(size_t)dd * 64];
+            ps[u] = by[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)pv, (int)((dd - a) & 63u)) * 64];
         }
     };
     auto use_group = [&](uint32_t d0, const uint32_t (&tb)[FITCH_BACK_UNROLL], const uint32_t (&ps)[FITCH_BACK_UNROLL]) {
@@ -721,23 +720,35 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLeve
         for (uint32_t u = 0; u < FITCH_BACK_UNROLL; u++) {
             const uint32_t d = d0 + u;
             if (d >= b) break;
-            const uint32_t par_state = (d == 0) ? ref : ps[u];                          // :119-128
-            const uint32_t state = next_state<true>(tb[u], par_state);
-            st.put(d, state);
-            const bool emit = have && state != par_state;                              // :145-156
-            const unsigned long long mask = __ballot(emit);
-            if (mask) {
-                if (emit) {
-                    const uint32_t at = qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    queue[at] = make_uint2(site, d | (par_state << 28) | (state << 30));
+            const uint32_t psw = (d == 0) ? refw : ps[u];                              // :119-128
+            uint32_t stw = 0, emit_bits = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < FR; q++) {
+                const uint32_t par_state = (psw >> (8 * q)) & 3u;
+                const uint32_t state = next_state<true>((tb[u] >> (8 * q)) & 15u, par_state);
+                stw |= state << (8 * q);
+                emit_bits |= (state != par_state ? 1u : 0u) << q;                      // :145-156
+            }
+            by[(size_t)d * 64] = stw;
+            emit_bits &= have_mask;
+            if (__ballot(emit_bits != 0)) {
+#pragma unroll
+                for (uint32_t q = 0; q < FR; q++) {
+                    const bool emit = (emit_bits >> q) & 1u;
+                    const unsigned long long mask = __ballot(emit);
+                    if (mask) {
+                        if (emit) {
+                            const uint32_t at = qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                            queue[at] = make_uint2(site0 + q, d | (((psw >> (8 * q)) & 3u) << 28) | (((stw >> (8 * q)) & 3u) << 30));
+                        }
+                        qn += (uint32_t)__popcll(mask);
+                        if (qn > FITCH_QUEUE - 64) flush();
+                    }
                 }
-                qn += (uint32_t)__popcll(mask);
-                if (qn > FITCH_QUEUE - 64) flush();
             }
         }
     };
-    // windows of 64 nodes (one vector of parent indices each), 64 / FITCH_BACK_UNROLL groups per window;
-    // the first group of the next window is requested at the end of the current one
+    // windows of 64 nodes (one vector of parent indices each), 64 / FITCH_BACK_UNROLL groups per window
     uint32_t tbA[FITCH_BACK_UNROLL], psA[FITCH_BACK_UNROLL], tbB[FITCH_BACK_UNROLL], psB[FITCH_BACK_UNROLL];
     for (uint32_t w0 = a; w0 < b; w0 += 64) {
         pv = (w0 + lane < b) ? t.parent[w0 + lane] : 0;
@@ -751,7 +762,6 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_down(FitchLeve
             use_group(w0 + g + FITCH_BACK_UNROLL, tbB, psB);
         }
     }
-    st.finish();
     if (qn) flush();
 }
 
