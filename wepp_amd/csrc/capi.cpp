@@ -190,15 +190,15 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     size_t sort_temp = 0;
     if (sort_reads) HIP_TRY(sort_reads_temp_bytes(n_reads, &sort_temp));
     sort_temp = (sort_temp + 255) & ~(size_t)255;
-    // fixed part of the workspace: tier | list | root_score | sort keys in/out | sort values | sort temp
-    const size_t fixed_bytes = tier_bytes + 2 * list_bytes + (sort_reads ? 3 * list_bytes + sort_temp : 0);
+    // fixed part of the workspace: tier | list | root_score | slot in block | sort keys in/out | sort values | sort temp
+    const size_t fixed_bytes = tier_bytes + 3 * list_bytes + (sort_reads ? 3 * list_bytes + sort_temp : 0);
     {
         // before routing only the fixed regions are needed; reserve a typical partial size too
         int rc = grow(fixed_bytes + (size_t)n_reads * 12 * 2);
         if (rc != WEPP_OK) return rc;
     }
     uint8_t* tier_of = nullptr;
-    uint32_t *list = nullptr, *key_in = nullptr, *key_out = nullptr, *val_in = nullptr;
+    uint32_t *list = nullptr, *slot_in_blk = nullptr, *key_in = nullptr, *key_out = nullptr, *val_in = nullptr;
     int32_t* root_score = nullptr;
     void* sort_tmp = nullptr;
     auto carve = [&]() {
@@ -206,6 +206,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         tier_of = (uint8_t*)p; p += tier_bytes;
         list = (uint32_t*)p; p += list_bytes;
         root_score = (int32_t*)p; p += list_bytes;
+        slot_in_blk = (uint32_t*)p; p += list_bytes;
         if (sort_reads) {
             key_in = (uint32_t*)p; p += list_bytes;
             key_out = (uint32_t*)p; p += list_bytes;
@@ -221,8 +222,8 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     auto route = [&]() -> int {
         HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
         HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score, blk_counts,
-                             tier_info, stream));
-        HIP_TRY(launch_scatter(tier_of, n_reads, blk_counts, tier_info, list, stream));
+                             tier_info, slot_in_blk, stream));
+        HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
         return WEPP_OK;
     };
     {

@@ -62,13 +62,14 @@ struct SweepPlans {
     SweepPlanDev p[MAX_STREAMS];
 };
 
-constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (grid-stride over the reads)
+constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (contiguous slices of the reads); 1024 blocks: route
+                                          // 30 -> 22 us but the per-block prefix over earlier blocks in k_scatter 29 -> 92 us
 constexpr uint32_t ROUTE_THREADS = 256;
 
 // route: tier of every read + per-(block, tier) counts and per-tier max entries
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, hipStream_t stream);
+                        uint32_t* tier_info, uint32_t* slot_in_blk, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
 constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less than the sort
@@ -78,8 +79,8 @@ hipError_t sort_reads_temp_bytes(uint32_t n, size_t* bytes);
 hipError_t launch_sort_reads(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                              uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream);
 // scatter: read indices grouped by tier into `list` (tier t occupies [tier_off[t], tier_off[t+1]))
-hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32_t* blk_counts, uint32_t* tier_info,
-                          uint32_t* list, hipStream_t stream);
+hipError_t launch_scatter(const uint8_t* tier_of, const uint32_t* slot_in_blk, uint32_t n_reads, const uint32_t* blk_counts,
+                          uint32_t* tier_info, uint32_t* list, hipStream_t stream);
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
                         const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list,
                         uint32_t n_list, uint32_t T,

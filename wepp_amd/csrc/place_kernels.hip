@@ -153,7 +153,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           int use_crowns, uint8_t* __restrict__ tier_of,
                                                           int32_t* __restrict__ root_score,
                                                           uint32_t* __restrict__ blk_counts,
-                                                          uint32_t* __restrict__ tier_info) {
+                                                          uint32_t* __restrict__ tier_info,
+                                                          uint32_t* __restrict__ slot_in_blk) {
     __shared__ uint32_t cnt[MAX_STREAMS], mx[MAX_STREAMS];
     if (threadIdx.x < MAX_STREAMS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
     __syncthreads();
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             for (uint32_t i = 0; i + 1 < m.n_streams; i++)
                 if (theta <= m.tau[i]) { t = i; break; }
         tier_of[r] = (uint8_t)t;
-        atomicAdd(&cnt[t], 1u);
+        slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the tier (k_scatter)
         atomicMax(&mx[t], k);
     }
     __syncthreads();
@@ -195,19 +196,31 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
 // k_scatter: list[] = read indices grouped by tier (same block decomposition as
 // k_route; a block's reads of one tier occupy a contiguous range).
 // -----------------------------------------------------------------------------
-__global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __restrict__ tier_of, uint32_t n_reads,
+__global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __restrict__ tier_of,
+                                                            const uint32_t* __restrict__ slot_in_blk, uint32_t n_reads,
                                                             const uint32_t* __restrict__ blk_counts,
                                                             uint32_t* __restrict__ tier_info,
                                                             uint32_t* __restrict__ list) {
-    __shared__ uint32_t base[MAX_STREAMS], cur[MAX_STREAMS];
+    __shared__ uint32_t base[MAX_STREAMS], before[MAX_STREAMS];
+    if (threadIdx.x < MAX_STREAMS) before[threadIdx.x] = 0;
+    __syncthreads();
+    // reads of every tier in the blocks before this one: the threads share the earlier blocks, each
+    // adds a block's 16 counts (one 64-byte row) -- a serial loop over all earlier blocks per tier
+    // used to be most of this kernel
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += blockDim.x) {
+        const uint32_t* row = blk_counts + b * MAX_STREAMS;
+#pragma unroll
+        for (uint32_t t = 0; t < MAX_STREAMS; t++) {
+            const uint32_t v = row[t];
+            if (v) atomicAdd(&before[t], v);
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < MAX_STREAMS) {
         const uint32_t t = threadIdx.x;
         uint32_t off = 0;                       // start of tier t in the list
         for (uint32_t i = 0; i < t; i++) off += tier_info[TI_COUNT + i];
-        uint32_t before = 0;                    // reads of tier t in earlier blocks
-        for (uint32_t b = 0; b < blockIdx.x; b++) before += blk_counts[b * MAX_STREAMS + t];
-        base[t] = off + before;
-        cur[t] = 0;
+        base[t] = off + before[t];
         if (blockIdx.x == 0) {
             tier_info[TI_OFF + t] = off;
             if (t == MAX_STREAMS - 1) tier_info[TI_OFF + MAX_STREAMS] = off + tier_info[TI_COUNT + t];
@@ -216,10 +229,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
-    for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
-        const uint32_t t = tier_of[r];
-        list[base[t] + atomicAdd(&cur[t], 1u)] = r;
-    }
+    for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) list[base[tier_of[r]] + slot_in_blk[r]] = r;   // no atomics here
 }
 
 // -----------------------------------------------------------------------------
@@ -1150,9 +1160,9 @@ __global__ void k_excess(DevMAT m, const uint32_t* __restrict__ read_off, const 
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, hipStream_t stream) {
+                        uint32_t* tier_info, uint32_t* slot_in_blk, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
-                       n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info);
+                       n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info, slot_in_blk);
     return hipGetLastError();
 }
 
@@ -1163,10 +1173,10 @@ hipError_t launch_first_pos(const uint32_t* list, uint32_t n, const uint32_t* d_
     return hipGetLastError();
 }
 
-hipError_t launch_scatter(const uint8_t* tier_of, uint32_t n_reads, const uint32_t* blk_counts, uint32_t* tier_info,
-                          uint32_t* list, hipStream_t stream) {
-    hipLaunchKernelGGL(k_scatter, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, tier_of, n_reads, blk_counts,
-                       tier_info, list);
+hipError_t launch_scatter(const uint8_t* tier_of, const uint32_t* slot_in_blk, uint32_t n_reads, const uint32_t* blk_counts,
+                          uint32_t* tier_info, uint32_t* list, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scatter, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, tier_of, slot_in_blk, n_reads,
+                       blk_counts, tier_info, list);
     return hipGetLastError();
 }
 
