@@ -64,7 +64,7 @@ struct SweepPlans {
 
 constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (contiguous slices of the reads); 1024 blocks: route
                                           // 30 -> 22 us but the per-block prefix over earlier blocks in k_scatter 29 -> 92 us
-constexpr uint32_t ROUTE_THREADS = 256;
+constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chains of dependent loads overlap
 
 // route: tier of every read + per-(block, tier) counts and per-tier max entries
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
@@ -109,6 +109,9 @@ constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep t
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                               const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
                               hipStream_t stream);
+// finalize: one thread per read up to this many chunks (lanes = consecutive reads: every partial load is
+// coalesced), one wave per read beyond (small batches cut into hundreds of chunks)
+constexpr uint32_t FINALIZE_THREAD_MAX_CHUNKS = 8;    // 64 measured no better (42 vs 46 us per 1 M reads)
 hipError_t launch_finalize_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                                  const uint32_t* d_read_word, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
                                  uint32_t* flags, hipStream_t stream);

@@ -885,7 +885,7 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
     while (p + 1 < pl.n && blockIdx.x >= pl.p[p].fin_end) p++;
     const SweepPlanDev& q = pl.p[p];
     const uint32_t blk = blockIdx.x - (p ? pl.p[p - 1].fin_end : 0);
-    if (q.nchunks > 8)
+    if (q.nchunks > FINALIZE_THREAD_MAX_CHUNKS)
         finalize_reads<true>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank,
                              q.part_cnt, best_bfs_j, score, num_best, flags);
     else
@@ -1225,7 +1225,7 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
-    if (nchunks > 8)
+    if (nchunks > FINALIZE_THREAD_MAX_CHUNKS)
         hipLaunchKernelGGL(k_finalize<true>, dim3((n_list + 3) / 4), dim3(256), 0, stream, m, d_read_off, d_read_word,
                            list, n_list, nchunks, part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags);
     else
