@@ -444,8 +444,10 @@ __device__ __forceinline__ void sweep_tile(
     // lane's node.
     // grp = the lanes whose read is word for word the read of lane r (they hold the same c, bs, br,
     // cnt at every point of the sweep): the evaluation is done once and its outcome taken by all
-    auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t m0,
-                          uint32_t m1, int64_t key, uint32_t st, int r, unsigned long long grp) {
+    // mm = this lane's two node offsets as loaded (byte 0: first event, byte 1: second): unpacked only
+    // here, so that the load issued with the first hit of the block is not waited for before it is needed
+    auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t mm,
+                          int64_t key, uint32_t st, int r, unsigned long long grp) {
         const uint32_t n0 = sum.node0;
         const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
         const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
@@ -501,8 +503,8 @@ __device__ __forceinline__ void sweep_tile(
                 }
             }
         };
-        apply(w0, m0);
-        apply(w1, m1);
+        apply(w0, mm);
+        apply(w1, mm >> 8);
         for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
             const bool valid = e + lane < e1;
             apply(valid ? m.ev_word[e + lane] : W_PAD_DEV, valid ? (uint32_t)m.ev_meta[e + lane] : 0u);
@@ -585,14 +587,12 @@ __device__ __forceinline__ void sweep_tile(
                 else { net += d; H += ad + 1; }
             }
         };
-        uint32_t m0 = 0, m1 = 0, st = 0;
+        uint32_t mm = 0, st = 0;
         int64_t key = 0;
         bool fetched = false;
         auto fetch_nodes = [&]() {
             if (e0 + 2 * lane < e1) {
-                const uint32_t mm = *reinterpret_cast<const uint16_t*>(m.ev_meta + e0 + 2 * lane);
-                m0 = mm & 0xFFu;
-                m1 = mm >> 8;
+                mm = *reinterpret_cast<const uint16_t*>(m.ev_meta + e0 + 2 * lane);
             }
             if (lane < sum.nn) { key = m.nkey[sum.node0 + lane]; st = m.nstat[sum.node0 + lane]; }
             fetched = true;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void sweep_tile(
                 }
                 hv &= ~grp;
                 if (!fetched) fetch_nodes();
-                heavy_eval(sum, e0, e1, w0, w1, m0, m1, key, st, r, grp);
+                heavy_eval(sum, e0, e1, w0, w1, mm, key, st, r, grp);
             }
             c += net;
         }
