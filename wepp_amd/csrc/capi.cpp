@@ -100,6 +100,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         ds.ncp = (uint32_t)st.cp_off.size() - 1;
         ds.eager = (i + 1 < f.streams.size()) ? 1u : 0u;
         ds.tier = (uint32_t)i;
+        ds.e_clamp = (uint32_t)(std::max<uint64_t>(st.E, 2) - 2);
         UP(ds.nkey, st.nkey) UP(ds.nstat, st.nstat) UP(ds.blk_node0, st.blk_node0) UP(ds.blk_eoff, st.blk_eoff)
         UP(ds.blk_sum, st.blk_sum) UP(ds.ev_word, st.ev_word) UP(ds.ev_meta, st.ev_meta) UP(ds.ev_lb, st.ev_lb) UP(ds.cp_off, st.cp_off)
         UP(ds.cp_word, st.cp_word)

@@ -21,6 +21,7 @@ struct DevStream {
     uint32_t n, NB, cp_stride, ncp;
     uint32_t eager;   // 1 on crown streams: fetch node data as soon as a block has a hit
     uint32_t tier;    // index of the stream in the handle (profiling counters)
+    uint32_t e_clamp; // max(E, 2) - 2: event index every lane may load from (lanes past a block's events read it and discard)
     const int64_t* nkey;
     const uint32_t* nstat;
     const uint32_t* blk_node0;

@@ -743,20 +743,23 @@ __device__ __forceinline__ void sweep_tile(
             BlkSum sm[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                // Every lane loads (lanes past the block's events from a clamped index, discarded below):
+                // with loads that may or may not be issued the compiler cannot count the outstanding ones
+                // and waits for all four blocks before the first.  Crown streams: a hit nearly always
+                // needs the per-event bounds; fetching them here keeps a dependent load off the hit path
+                // (the whole-tree stream ignores them).
                 const uint32_t idx = e[q] + 2 * lane;
-                ww[q] = make_uint2(W_PAD_DEV, W_PAD_DEV);
-                lbw[q] = 0;
-                if (idx < e[q + 1]) {
-                    ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idx);
-                    // crown streams: a hit nearly always needs the per-event bounds; fetching them
-                    // here keeps a dependent load (and its wait) off the hit path
-                    if (m.eager) lbw[q] = *reinterpret_cast<const uint16_t*>(m.ev_lb + idx);
-                }
+                const uint32_t idc = min(idx, m.e_clamp);
+                ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idc);
+                lbw[q] = *reinterpret_cast<const uint16_t*>(m.ev_lb + idc);
                 sm[q] = m.blk_sum[min(bb + j + q, m.NB - 1)];
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (j + q < ng) process_block(e[q], e[q + 1], ww[q].x, ww[q].y, lbw[q], sm[q]);
+            for (int q = 0; q < 4; q++) {
+                if (j + q >= ng) continue;
+                const bool ev = e[q] + 2 * lane < e[q + 1];            // lanes past the block's events: padding
+                process_block(e[q], e[q + 1], ev ? ww[q].x : W_PAD_DEV, ev ? ww[q].y : W_PAD_DEV, lbw[q], sm[q]);
+            }
         }
     }
 
