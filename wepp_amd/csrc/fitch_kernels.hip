@@ -574,36 +574,48 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels
         vnuc2[q] = vp[q] + 1 < vend[q] ? s.var_nuc[vp[q] + 1] : 0;
     }
     // observed allele sets of node d for this lane's rows (nodes are visited in increasing BFS index):
-    // bit q of the result = row q observes the node, allowed[q] = its set
-    auto observed = [&](uint32_t d, uint32_t (&allowed)[FR]) -> uint32_t {
+    // bit q of the result = row q observes the node, allowed[q] = its set.  vmin = the next observed
+    // node over the lane's four rows: most nodes are observed by no row of the wave, which one compare
+    // and a ballot establish (`any` = false, nothing else is touched).
+    uint32_t vmin = min(min(vnext[0], vnext[1]), min(vnext[2], vnext[3]));
+    auto observed = [&](uint32_t d, uint32_t (&allowed)[FR], bool& any) -> uint32_t {
+        any = __ballot(vmin == d) != 0;
+        if (!any) return 0;
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t is = 0;
 #pragma unroll
         for (uint32_t q = 0; q < FR; q++) {
             allowed[q] = vnuc[q] & 15u;
             is |= (vnext[q] == d ? 1u : 0u) << q;
         }
-        if (__ballot(is != 0)) {
 #pragma unroll
-            for (uint32_t q = 0; q < FR; q++) {
-                if ((is >> q) & 1u) {
-                    vp[q]++;
-                    vnext[q] = vnext2[q];
-                    vnuc[q] = vnuc2[q];
-                    vnext2[q] = vp[q] + 1 < vend[q] ? s.var_dfs[vp[q] + 1] : 0xFFFFFFFFu;
-                    vnuc2[q] = vp[q] + 1 < vend[q] ? s.var_nuc[vp[q] + 1] : 0;
-                }
+        for (uint32_t q = 0; q < FR; q++) {
+            if ((is >> q) & 1u) {
+                vp[q]++;
+                vnext[q] = vnext2[q];
+                vnuc[q] = vnuc2[q];
+                vnext2[q] = vp[q] + 1 < vend[q] ? s.var_dfs[vp[q] + 1] : 0xFFFFFFFFu;
+                vnuc2[q] = vp[q] + 1 < vend[q] ? s.var_nuc[vp[q] + 1] : 0;
             }
         }
+        vmin = min(min(vnext[0], vnext[1]), min(vnext[2], vnext[3]));
         return is;
     };
+    uint32_t leaf_w = 0;                                       // byte row of a leaf no row observes
+#pragma unroll
+    for (uint32_t q = 0; q < FR; q++) leaf_w |= leaf_no[q] << (8 * q);
     uint32_t next_node = a;                                    // nodes below it are done
     auto leaves_until = [&](uint32_t p) {                      // the nodes in [next_node, p) have no child
         for (uint32_t d = next_node; d < p; d++) {
             uint32_t allowed[FR];
-            const uint32_t is = observed(d, allowed);
-            uint32_t w = 0;
+            bool any;
+            const uint32_t is = observed(d, allowed, any);
+            uint32_t w = leaf_w;
+            if (any) {
+                w = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < FR; q++) w |= (((is >> q) & 1u) ? (~allowed[q] & 15u) : leaf_no[q]) << (8 * q);
+                for (uint32_t q = 0; q < FR; q++) w |= (((is >> q) & 1u) ? (~allowed[q] & 15u) : leaf_no[q]) << (8 * q);
+            }
             by[(size_t)d * 64] = w;
         }
     };
@@ -638,9 +650,15 @@ __global__ __launch_bounds__(64 * FITCH_LEVEL_WAVES) void k_fitch_up(FitchLevels
                 if (cur_par != 0xFFFFFFFFu) close_par();
                 leaves_until(p);
                 uint32_t allowed[FR];
-                const uint32_t is = observed(p, allowed);
+                bool any;
+                const uint32_t is = observed(p, allowed, any);
 #pragma unroll
-                for (uint32_t q = 0; q < FR; q++) x[q] = ((is >> q) & 1u) ? x_init(allowed[q]) : X2{0u, 0u};
+                for (uint32_t q = 0; q < FR; q++) x[q] = X2{0u, 0u};
+                if (any) {
+#pragma unroll
+                    for (uint32_t q = 0; q < FR; q++)
+                        if ((is >> q) & 1u) x[q] = x_init(allowed[q]);
+                }
                 cur_par = p;
                 next_node = p + 1;
             }
