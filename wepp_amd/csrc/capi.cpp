@@ -270,6 +270,13 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         const DevStream& st = mat->streams[t];
         static const uint32_t target_waves = getenv("WEPP_TARGET_WAVES") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES")) : 4096;   // 16 resident single-wave workgroups per CU x 256 CUs; 2048 / 8192 / 16384 measured slower (WEPP_TARGET_WAVES: tuning aid)
         uint32_t nchunks = std::max<uint32_t>(1, (target_waves + p.ntiles - 1) / p.ntiles);
+        // ... and chunks no longer than what stays in an XCD's L2 while the tiles sweep it: the waves of
+        // a launch are ordered chunk-major (all tiles of chunk 0, then of chunk 1, ...), so the ~4 K
+        // resident waves walk the same ~1.5 MB of the stream together instead of drifting apart over
+        // 118 MB (whole-tree sweep of 1 M reads: 432 ms with one chunk per tile, 235 ms with 80)
+        static const uint64_t chunk_bytes = getenv("WEPP_CHUNK_BYTES") ? (uint64_t)atoll(getenv("WEPP_CHUNK_BYTES")) : SWEEP_CHUNK_BYTES;
+        nchunks = std::max<uint32_t>(nchunks, (uint32_t)((mat->stream_bytes[t] + chunk_bytes - 1) / chunk_bytes));
+        nchunks = std::min<uint32_t>(nchunks, (uint32_t)std::max<uint64_t>(1, SWEEP_MAX_PARTIAL_BYTES / ((uint64_t)count * 12)));
         if (p.dense) nchunks = std::max<uint32_t>(nchunks, DENSE_WAVES_PER_WG);   // one chunk per wave of the workgroup
         nchunks = std::min(nchunks, st.ncp);
         const uint32_t cps_per_chunk = (st.ncp + nchunks - 1) / nchunks;

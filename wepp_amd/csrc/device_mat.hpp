@@ -94,6 +94,8 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
 #ifndef WEPP_SWEEP_WAVES
 #define WEPP_SWEEP_WAVES 1
 #endif
+constexpr uint64_t SWEEP_CHUNK_BYTES = 1ull << 20;   // 1 MB of stream per chunk (an XCD's L2 holds 4 MB; 0.75 / 1 / 1.5 / 2 / 3 MB: 236 / 235 / 238 / 240 / 250 ms)
+constexpr uint64_t SWEEP_MAX_PARTIAL_BYTES = 16ull << 30;   // per-(chunk, read) partial results of one stream: chunks get longer beyond
 constexpr uint32_t SWEEP_WAVES = WEPP_SWEEP_WAVES;            // independent sweeps (waves) per workgroup of k_sweep_multi
 constexpr uint32_t DENSE_WAVES_PER_WG = WEPP_DENSE_WAVES;     // waves sharing one tile's LDS index in the dense variant
 // LDS bytes of a k_sweep workgroup: bitmap + read words (+ dense: sorted keys + owners + accumulators)
