@@ -257,7 +257,10 @@ def main():
             a = whole["algorithmic_bytes_per_step"] / (whole["kernel_ms_per_step"] * 1e-3) / 1e9
             out["roofline_whole_tree"] = {
                 "what": "same batch with work skipping off: every 64-read tile streams the whole-tree event "
-                        "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`",
+                        "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`.  `achieved` "
+                        "counts the bytes every tile sweeps (algorithmic); the stream is cut into ~1 MB chunks swept "
+                        "chunk-major, so most of them are served by the L2s (`traffic` = bytes leaving the L2s) and "
+                        "the kernel is vector-issue bound (DESIGN.md 4.1)",
                 "bound": "hbm", "kernel": "k_sweep", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic("work_skipping_off"),
                 "reads_per_s": R / (whole["kernel_ms_per_step"] * 1e-3), **whole}
