@@ -21,6 +21,8 @@ void release(wepp_mat* h) {
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->io_in) (void)hipFree(h->io_in);
+    if (h->io_out) (void)hipFree(h->io_out);
     if (h->epp_ws) (void)hipFree(h->epp_ws);
     if (h->d_info) (void)hipFree(h->d_info);
     if (h->h_info) (void)hipHostFree(h->h_info);
@@ -434,10 +436,28 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
     int32_t* d_pns = nullptr;
     int rc = WEPP_OK;
-    hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n_reads * 16);
-    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
+    hipError_t e = hipSuccess;
+    {
+        // the device copies of the caller's buffers live on the handle and only grow: no hipMalloc /
+        // hipFree (and the device-wide synchronisation they imply) per call
+        const size_t off_bytes = (((size_t)(n_reads + 1) * 4) + 255) & ~(size_t)255;
+        const size_t in_need = off_bytes + std::max<size_t>(nw * 4, 16);
+        const size_t out_need = (size_t)n_reads * 16;
+        if (in_need > mat->io_in_bytes) {
+            if (mat->io_in) { (void)hipFree(mat->io_in); mat->io_in = nullptr; mat->io_in_bytes = 0; }
+            e = hipMalloc(&mat->io_in, in_need + in_need / 4);
+            if (e == hipSuccess) mat->io_in_bytes = in_need + in_need / 4;
+        }
+        if (e == hipSuccess && out_need > mat->io_out_bytes) {
+            if (mat->io_out) { (void)hipFree(mat->io_out); mat->io_out = nullptr; mat->io_out_bytes = 0; }
+            e = hipMalloc(&mat->io_out, out_need + out_need / 4);
+            if (e == hipSuccess) mat->io_out_bytes = out_need + out_need / 4;
+        }
+        if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
+        d_off = (uint32_t*)mat->io_in;
+        d_word = (uint32_t*)((char*)mat->io_in + off_bytes);
+        d_out = (uint32_t*)mat->io_out;
+    }
     e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && nw) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = hip_fail(e, "H2D copy of the reads"); goto done; }
@@ -459,9 +479,6 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     if (e == hipSuccess && flags) e = hipMemcpy(flags, d_out + 3 * (size_t)n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = hip_fail(e, "placement kernels / D2H copy of the results");
 done:
-    if (d_off) (void)hipFree(d_off);
-    if (d_word) (void)hipFree(d_word);
-    if (d_out) (void)hipFree(d_out);
     if (d_pns) (void)hipFree(d_pns);
     return rc;
 }

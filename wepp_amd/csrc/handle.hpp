@@ -31,6 +31,10 @@ struct wepp_mat {
     std::vector<void*> allocs;
     uint32_t tile_reads = 64;
     int use_crowns = 1;
+    // grow-only device copies of the caller's host buffers (wepp_place_batch): reads in, results out
+    void* io_in = nullptr;
+    void* io_out = nullptr;
+    size_t io_in_bytes = 0, io_out_bytes = 0;
     // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;
