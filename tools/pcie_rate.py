@@ -15,5 +15,5 @@ for _ in range(5):
     res = mat.place_batch(reads)
     best = min(best, time.perf_counter() - t0)
 print(json.dumps({"reads": reads.n_reads, "best_s": best, "reads_per_s_host_buffers": reads.n_reads / best,
-                  "note": "includes the C-ABI's validation loop over the read words and the pageable H2D / D2H copies"}))
+                  "note": "includes the C-ABI's validation of the read words and the staged H2D / D2H copies"}))
 mat.close()

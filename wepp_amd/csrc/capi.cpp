@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "handle.hpp"
@@ -23,6 +24,7 @@ void release(wepp_mat* h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->io_in) (void)hipFree(h->io_in);
     if (h->io_out) (void)hipFree(h->io_out);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->epp_ws) (void)hipFree(h->epp_ws);
     if (h->d_info) (void)hipFree(h->d_info);
     if (h->h_info) (void)hipHostFree(h->h_info);
@@ -422,15 +424,36 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     if (read_off[0] != 0) return set_error(WEPP_EINVAL, "read_off[0] must be 0");
     const uint64_t nw = read_off[n_reads];
     if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
-    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions
-    for (uint32_t r = 0; r < n_reads; r++) {
-        if (read_off[r + 1] < read_off[r]) return set_error(WEPP_EINVAL, "read_off not monotone");
-        for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
-            if ((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu))
-                return set_error(WEPP_EINVAL, "read " + std::to_string(r) + ": entries must be sorted by position with unique positions");
-        for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
-            if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0)
-                return set_error(WEPP_EINVAL, "read " + std::to_string(r) + ": zero nucleotide mask");
+    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.
+    // Checked by a few host threads on large batches; the first offending read (lowest index) is reported.
+    {
+        auto check = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
+            for (uint32_t r = lo; r < hi; r++) {
+                if (read_off[r + 1] < read_off[r]) { bad = r; what = 0; return; }
+                for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
+                    if ((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu)) { bad = r; what = 1; return; }
+                for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
+                    if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0) { bad = r; what = 2; return; }
+            }
+        };
+        const uint32_t nt = n_reads >= (1u << 16) ? std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::vector<uint32_t> bad(nt, 0xFFFFFFFFu);
+        std::vector<int> what(nt, 0);
+        if (nt == 1) check(0, n_reads, bad[0], what[0]);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t i = 0; i < nt; i++)
+                th.emplace_back(check, (uint32_t)((uint64_t)n_reads * i / nt), (uint32_t)((uint64_t)n_reads * (i + 1) / nt),
+                                std::ref(bad[i]), std::ref(what[i]));
+            for (auto& t : th) t.join();
+        }
+        for (uint32_t i = 0; i < nt; i++) {
+            if (bad[i] == 0xFFFFFFFFu) continue;
+            if (what[i] == 0) return set_error(WEPP_EINVAL, "read_off not monotone");
+            if (what[i] == 1)
+                return set_error(WEPP_EINVAL, "read " + std::to_string(bad[i]) + ": entries must be sorted by position with unique positions");
+            return set_error(WEPP_EINVAL, "read " + std::to_string(bad[i]) + ": zero nucleotide mask");
+        }
     }
     HIP_TRY(hipSetDevice(mat->device));
     uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
@@ -458,8 +481,22 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         d_word = (uint32_t*)((char*)mat->io_in + off_bytes);
         d_out = (uint32_t*)mat->io_out;
     }
-    e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nw) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
+    {
+        // pinned staging (grow-only): one memcpy + one DMA each way instead of the runtime's pageable path
+        const size_t need = std::max((size_t)(n_reads + 1) * 4 + nw * 4, (size_t)n_reads * 16);
+        if (need > mat->pin_bytes) {
+            if (mat->pin) { (void)hipHostFree(mat->pin); mat->pin = nullptr; mat->pin_bytes = 0; }
+            e = hipHostMalloc(&mat->pin, need + need / 4, hipHostMallocDefault);
+            if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); goto done; }
+            mat->pin_bytes = need + need / 4;
+        }
+    }
+    std::memcpy(mat->pin, read_off, (size_t)(n_reads + 1) * 4);
+    e = hipMemcpy(d_off, mat->pin, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nw) {
+        std::memcpy(mat->pin, read_word, nw * 4);
+        e = hipMemcpy(d_word, mat->pin, nw * 4, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { rc = hip_fail(e, "H2D copy of the reads"); goto done; }
     rc = wepp_place_batch_device(mat, d_off, d_word, n_reads, nw, d_out, (int32_t*)(d_out + n_reads),
                                  d_out + 2 * (size_t)n_reads, d_out + 3 * (size_t)n_reads, nullptr);
@@ -472,12 +509,15 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         if (e == hipSuccess) e = hipMemcpy(per_node_scores, d_pns, nb, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rc = hip_fail(e, "per-node score kernel"); goto done; }
     }
-    e = hipStreamSynchronize(nullptr);
-    if (e == hipSuccess && best_bfs_j) e = hipMemcpy(best_bfs_j, d_out, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && score) e = hipMemcpy(score, d_out + n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && num_best) e = hipMemcpy(num_best, d_out + 2 * (size_t)n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && flags) e = hipMemcpy(flags, d_out + 3 * (size_t)n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = hip_fail(e, "placement kernels / D2H copy of the results");
+    e = hipMemcpy(mat->pin, d_out, (size_t)n_reads * 16, hipMemcpyDeviceToHost);   // synchronises with the kernels
+    if (e != hipSuccess) { rc = hip_fail(e, "placement kernels / D2H copy of the results"); goto done; }
+    {
+        const uint32_t* po = (const uint32_t*)mat->pin;
+        if (best_bfs_j) std::memcpy(best_bfs_j, po, (size_t)n_reads * 4);
+        if (score) std::memcpy(score, po + n_reads, (size_t)n_reads * 4);
+        if (num_best) std::memcpy(num_best, po + 2 * (size_t)n_reads, (size_t)n_reads * 4);
+        if (flags) std::memcpy(flags, po + 3 * (size_t)n_reads, (size_t)n_reads * 4);
+    }
 done:
     if (d_pns) (void)hipFree(d_pns);
     return rc;

@@ -35,6 +35,8 @@ struct wepp_mat {
     void* io_in = nullptr;
     void* io_out = nullptr;
     size_t io_in_bytes = 0, io_out_bytes = 0;
+    void* pin = nullptr;              // pinned staging of the same (pageable caller buffers go through it)
+    size_t pin_bytes = 0;
     // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;
