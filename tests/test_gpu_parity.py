@@ -78,6 +78,22 @@ def test_duplicate_reads_and_sorted_batches(oracle, crowns):
         mat.close()
 
 
+def test_one_handle_many_batch_sizes(oracle):
+    """The handle keeps grow-only device / pinned buffers and workspaces between calls: batches of
+    growing, shrinking and zero size on ONE handle must all match the oracle."""
+    rng = np.random.default_rng(909)
+    tree, ref = ft.random_tree(rng, n_nodes=300, genome=120)
+    mat = w.Mat(tree)
+    ot = oracle.OracleTree(tree)
+    for n in (3, 700, 1, 0, 5000, 64, 65, 4097, 2):
+        reads = ft.reads_from_samples([ft.random_sample(rng, ref, genome=120) for _ in range(n)])
+        res = mat.place_batch(reads)
+        assert len(res.score) == n
+        if n:
+            assert_same(res, ot.place_batch(reads, 8), f"batch of {n}")
+    mat.close()
+
+
 def test_per_node_scores_mode_vs_oracle(oracle):
     """--write-parsimony-scores-per-node: all N values per read (usher_common.cpp:403-409)."""
     rng = np.random.default_rng(321)
