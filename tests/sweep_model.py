@@ -124,15 +124,15 @@ class FlatModel:
                     for i in range(o, nn):
                         cadd[i] -= d
                     net -= d
-                    H += abs(d)
+                    H += max(d, 0)          # nodes after the exit lose d: only d > 0 can lower a score
                 else:
                     if not (w & W_LEAF):
                         is_root = (n0 + o) == 0
                         for i in range(o if is_root else o + 1, nn):
                             cadd[i] += d
                         net += d
-                        H += abs(d)
-                    H += 1
+                        H += max(-d, 0)     # descendants gain d: only d < 0 can lower a score
+                    H += 1                  # the node's own adjustment is at least -1
                     touched[o] = True
                     a, dc = own_adjust(w, s)
                     adj[o] += a

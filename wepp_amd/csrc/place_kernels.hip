@@ -579,12 +579,14 @@ __device__ __forceinline__ void sweep_tile(
             STAT_ADD(3, __popcll(__ballot(s != NONE)));
             if (s != NONE) {
                 const int d = enter_delta(wl, s);
-                const int ad = d < 0 ? -d : d;
                 touched = true;
                 lbmin = min(lbmin, lbl);
-                if (wl & W_EXIT_DEV) { net -= d; H += ad; }
+                // H bounds how far the events can LOWER a score: an exit takes d away from the nodes
+                // behind it (matters if d > 0), an enter gives d to the descendants (matters if d < 0)
+                // and changes the node's own score by at least -1
+                if (wl & W_EXIT_DEV) { net -= d; H += max(d, 0); }
                 else if (wl & W_LEAF_DEV) { H += 1; }
-                else { net += d; H += ad + 1; }
+                else { net += d; H += max(-d, 0) + 1; }
             }
         };
         uint32_t mm = 0, st = 0;
@@ -640,11 +642,10 @@ __device__ __forceinline__ void sweep_tile(
                         if (act && i < n2 && (kv >> 13) == p) {
                             const uint32_t idx = kv & 8191u;
                             const int d = enter_delta(w, S_lds[idx]);
-                            const int ad = d < 0 ? -d : d;
                             int dn, dh;
-                            if (w & W_EXIT_DEV) { dn = -d; dh = ad; }
+                            if (w & W_EXIT_DEV) { dn = -d; dh = max(d, 0); }
                             else if (w & W_LEAF_DEV) { dn = 0; dh = 1; }
-                            else { dn = d; dh = ad + 1; }
+                            else { dn = d; dh = max(-d, 0) + 1; }
                             const uint32_t o = owner[idx];
                             if (dn) atomicAdd(&acc[o], dn);
                             if (dh) atomicAdd(&acc[64 + o], dh);
