@@ -11,13 +11,14 @@ import wepp_amd as w
 from wepp_amd._lib import lib
 
 NAMES = ["block_visits", "blocks_with_hit", "hit_events", "hit_read_matches", "heavy_evals", "heavy_reduced",
-         "blocks_with_summary_update", "waves"]
+         "blocks_with_summary_update", "waves", "cyc_setup", "cyc_nohit_blocks", "cyc_hit_blocks_light_only",
+         "cyc_hit_blocks_before_eval", "cyc_evals", "-", "-", "-"]
 
 
 def stats(reset=True):
-    buf = (ctypes.c_ulonglong * (16 * 8))()
+    buf = (ctypes.c_ulonglong * (16 * 16))()
     assert lib.wepp_debug_sweep_stats(buf, 1 if reset else 0) == 0
-    return np.array(buf[:]).reshape(16, 8)
+    return np.array(buf[:]).reshape(16, 16)
 
 
 def main():
@@ -47,7 +48,7 @@ def main():
         for t in range(st.n_streams):
             if s[t, 7]:
                 print(json.dumps({"crowns": crowns, "tau": int(st.stream_tau[t]), "stream_nodes": int(st.stream_nodes[t]),
-                                  **{n: int(v) for n, v in zip(NAMES, s[t])}}))
+                                  **{n: int(v) for n, v in zip(NAMES, s[t]) if n != "-"}}))
     mat.close()
 
 

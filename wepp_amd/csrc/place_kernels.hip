@@ -42,16 +42,26 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // -DWEPP_SWEEP_STATS: per-stream event counters of the sweep (a profiling build, never shipped):
 // [tier][0] block visits, [1] blocks with a bitmap hit, [2] hit events, [3] (hit event, read) matches,
 // [4] node-by-node evaluations, [5] of which reached the reduction, [6] blocks with a summary update, [7] waves
+// and wave cycles (s_memtime) by section: [tier][8] set-up, [9] blocks without a hit, [10] hit blocks without
+// a node-by-node evaluation, [11] hit blocks with one (light part), [12] the evaluations themselves
 #ifdef WEPP_SWEEP_STATS
-__device__ unsigned long long g_sweep_stats[MAX_STREAMS * 8];
-#define STAT_DECL uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 1}
+constexpr int NSTAT = 16;
+__device__ unsigned long long g_sweep_stats[MAX_STREAMS * NSTAT];
+#define STAT_DECL uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 1}; unsigned long long tt_[5] = {0, 0, 0, 0, 0}; \
+    unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define STAT_ADD(i, v) st_[i] += (uint32_t)(v)
+#define STAT_NOW() __builtin_amdgcn_s_memtime()
+#define STAT_T(i, from) tt_[i] += __builtin_amdgcn_s_memtime() - (from)
 #define STAT_FLUSH(tier)                                                                      \
-    if (lane == 0)                                                                            \
-        for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_sweep_stats[(tier) * 8 + i_], (unsigned long long)st_[i_])
+    if (lane == 0) {                                                                          \
+        for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_sweep_stats[(tier) * NSTAT + i_], (unsigned long long)st_[i_]); \
+        for (int i_ = 0; i_ < 5; i_++) atomicAdd(&g_sweep_stats[(tier) * NSTAT + 8 + i_], tt_[i_]);                 \
+    }
 #else
 #define STAT_DECL
 #define STAT_ADD(i, v)
+#define STAT_NOW() 0ull
+#define STAT_T(i, from)
 #define STAT_FLUSH(tier)
 #endif
 #ifndef WEPP_DENSE_MIN_HITS
@@ -267,6 +277,7 @@ __device__ __forceinline__ void sweep_tile(
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
     constexpr bool OWN = S_IN_LDS && !DENSE;
+    STAT_DECL;
     const DevStream& m = ms;
     // Plain variant: one wave = one tile of reads and one chunk of the stream; `wg` is the wave's
     // index among the sweeps of its plan and lds_word0 the start of its private LDS region (the
@@ -436,7 +447,7 @@ __device__ __forceinline__ void sweep_tile(
     int bs = have ? root_score[rd] + 1 : (int)0x80000000;
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
-    STAT_DECL;
+    STAT_T(0, t0_);
 
     // ---- node-by-node evaluation of one block for read r (lane = node) ----------
     // Everything it needs was fetched when the first hit of the block was seen:
@@ -542,6 +553,8 @@ __device__ __forceinline__ void sweep_tile(
     // w0/w1 = this lane's two words of the block's first 128 events (W_PAD beyond e1)
     // lbw = this lane's two per-event bounds (crown streams; fetched with the event words)
     auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t lbw, const BlkSum sum) {
+        const unsigned long long tb_ = STAT_NOW();
+        (void)tb_;
         const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
         STAT_ADD(0, 1);
         STAT_ADD(1, (hm0 | hm1) ? 1 : 0);
@@ -567,6 +580,7 @@ __device__ __forceinline__ void sweep_tile(
 #endif
         if (!any_hit) {
             summary_update(true);
+            STAT_T(1, tb_);
             return;
         }
         __builtin_amdgcn_sched_barrier(0);     // the hit path stays out of line of the fast path
@@ -611,7 +625,8 @@ __device__ __forceinline__ void sweep_tile(
             // crown streams hold only low-score nodes, so a hit nearly always ends in the
             // node-by-node path: start its loads before the lookups.  On the whole-tree
             // stream the bound prunes ~95 % of the hits and the loads are issued on demand.
-            if (m.eager && (hm0 | hm1)) fetch_nodes();
+            // (the node data is fetched when an evaluation is decided: fetched at the first hit, its loads sat
+            // between the prefetched event words of the next blocks and every hit block waited for them)
             unsigned long long hm;
             if (DENSE && __popcll(hm0) + __popcll(hm1) >= DENSE_MIN_HITS) {
                 // many hit events (long reads): lane = event.  Every lane looks its event up in
@@ -708,6 +723,9 @@ __device__ __forceinline__ void sweep_tile(
 #ifdef WEPP_EXP_NO_HEAVY   // timing experiment only (wrong results): no node-by-node evaluation
             hv = 0;
 #endif
+            const unsigned long long th_ = STAT_NOW();
+            (void)th_;
+            STAT_T(hv ? 3 : 2, tb_);
             while (hv) {
                 const int r = __builtin_ctzll(hv);
                 // reads of the tile identical to read r (sorted batches put them side by side)
@@ -726,6 +744,7 @@ __device__ __forceinline__ void sweep_tile(
                 if (!fetched) fetch_nodes();
                 heavy_eval(sum, e0, e1, w0, w1, mm, key, st, r, grp);
             }
+            STAT_T(4, th_);
             c += net;
         }
     };
@@ -1271,9 +1290,9 @@ hipError_t launch_excess(const DevMAT& m, const uint32_t* d_read_off, const uint
 
 #ifdef WEPP_SWEEP_STATS
 extern "C" int wepp_debug_sweep_stats(unsigned long long* out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_stats), sizeof(unsigned long long) * MAX_STREAMS * 8) != hipSuccess) return 1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_stats), sizeof(unsigned long long) * MAX_STREAMS * NSTAT) != hipSuccess) return 1;
     if (reset) {
-        static unsigned long long zero[MAX_STREAMS * 8];
+        static unsigned long long zero[MAX_STREAMS * NSTAT];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_stats), zero, sizeof(zero)) != hipSuccess) return 1;
     }
     return 0;
