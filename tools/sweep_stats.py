@@ -12,13 +12,14 @@ from wepp_amd._lib import lib
 
 NAMES = ["block_visits", "blocks_with_hit", "hit_events", "hit_read_matches", "heavy_evals", "heavy_reduced",
          "blocks_with_summary_update", "waves", "cyc_setup", "cyc_nohit_blocks", "cyc_hit_blocks_light_only",
-         "cyc_hit_blocks_before_eval", "cyc_evals", "-", "-", "-"]
+         "cyc_hit_blocks_before_eval", "cyc_evals", "cyc_setup_clear", "cyc_setup_stage", "cyc_setup_checkpoint",
+         "t_list", "t_read_off", "t_first_words", "t_prefix_clear", "-", "-", "-", "-"]
 
 
 def stats(reset=True):
-    buf = (ctypes.c_ulonglong * (16 * 16))()
+    buf = (ctypes.c_ulonglong * (16 * 24))()
     assert lib.wepp_debug_sweep_stats(buf, 1 if reset else 0) == 0
-    return np.array(buf[:]).reshape(16, 16)
+    return np.array(buf[:]).reshape(16, 24)
 
 
 def main():

@@ -19,7 +19,7 @@ constexpr uint32_t WEPP_FLAG_HAS_UNIQUE_DEV = WEPP_FLAG_HAS_UNIQUE;
 // one sweep stream (a crown or the whole tree), see flatmat.hpp
 struct DevStream {
     uint32_t n, NB, cp_stride, ncp;
-    uint32_t eager;   // 1 on crown streams: fetch node data as soon as a block has a hit
+    uint32_t eager;   // 1 on crown streams: the per-event bounds (ev_lb) prune there, the block minimum elsewhere
     uint32_t tier;    // index of the stream in the handle (profiling counters)
     uint32_t e_clamp; // max(E, 2) - 2: event index every lane may load from (lanes past a block's events read it and discard)
     const int64_t* nkey;

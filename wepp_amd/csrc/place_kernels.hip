@@ -43,25 +43,28 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // [tier][0] block visits, [1] blocks with a bitmap hit, [2] hit events, [3] (hit event, read) matches,
 // [4] node-by-node evaluations, [5] of which reached the reduction, [6] blocks with a summary update, [7] waves
 // and wave cycles (s_memtime) by section: [tier][8] set-up, [9] blocks without a hit, [10] hit blocks without
-// a node-by-node evaluation, [11] hit blocks with one (light part), [12] the evaluations themselves
+// a node-by-node evaluation, [11] hit blocks with one (light part), [12] the evaluations themselves,
+// [13..15] parts of the set-up: until the bitmap is cleared, until the reads are staged, the checkpoint
 #ifdef WEPP_SWEEP_STATS
-constexpr int NSTAT = 16;
+constexpr int NSTAT = 24;
 __device__ unsigned long long g_sweep_stats[MAX_STREAMS * NSTAT];
-#define STAT_DECL uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 1}; unsigned long long tt_[5] = {0, 0, 0, 0, 0}; \
+#define STAT_DECL uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 1}; unsigned long long tt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
     unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define STAT_ADD(i, v) st_[i] += (uint32_t)(v)
 #define STAT_NOW() __builtin_amdgcn_s_memtime()
 #define STAT_T(i, from) tt_[i] += __builtin_amdgcn_s_memtime() - (from)
+#define STAT_WAIT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAT_FLUSH(tier)                                                                      \
     if (lane == 0) {                                                                          \
         for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_sweep_stats[(tier) * NSTAT + i_], (unsigned long long)st_[i_]); \
-        for (int i_ = 0; i_ < 5; i_++) atomicAdd(&g_sweep_stats[(tier) * NSTAT + 8 + i_], tt_[i_]);                 \
+        for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_sweep_stats[(tier) * NSTAT + 8 + i_], tt_[i_]);                 \
     }
 #else
 #define STAT_DECL
 #define STAT_ADD(i, v)
 #define STAT_NOW() 0ull
 #define STAT_T(i, from)
+#define STAT_WAIT()
 #define STAT_FLUSH(tier)
 #endif
 #ifndef WEPP_DENSE_MIN_HITS
@@ -309,9 +312,27 @@ __device__ __forceinline__ void sweep_tile(
     const uint32_t nr = min(T, n_list - r0);
     const bool have = lane < nr;
     const uint32_t rd = have ? list[r0 + lane] : 0;   // this lane's read
+    STAT_WAIT(); STAT_T(8, t0_);
     const uint32_t so = have ? read_off[rd] : 0;
     const uint32_t my_k = have ? read_off[rd + 1] - so : 0;
+    STAT_WAIT(); STAT_T(9, t0_);
+    // everything the set-up needs from memory is requested here, in one go, so that the latencies
+    // overlap: the first words of the read, the root's score, the checkpoint of the chunk start
+    uint32_t pre[OWN_WORDS];
+#pragma unroll
+    for (uint32_t j = 0; j < OWN_WORDS; j++) pre[j] = (wv == 0 && my_k > j) ? read_word[so + j] : NONE;
+    const int root_sc = have ? root_score[rd] : 0;
+    const uint32_t b0 = chunk * blocks_per_chunk;
+    const uint32_t b1 = min(m.NB, b0 + blocks_per_chunk);
+    uint32_t cp_e0 = 0, cp_e1 = 0;
+    if (b0 < m.NB) {
+        const uint32_t cpi = b0 / m.cp_stride;
+        cp_e0 = m.cp_off[cpi];
+        cp_e1 = m.cp_off[cpi + 1];
+    }
+    const uint32_t cp_first = (cp_e0 + lane < cp_e1) ? m.cp_word[cp_e0 + lane] : 0;
 
+    STAT_WAIT(); STAT_T(10, t0_);
     // exclusive prefix sum of the entry counts: where this lane's read sits in LDS
     uint32_t incl = my_k;
 #pragma unroll
@@ -340,10 +361,13 @@ __device__ __forceinline__ void sweep_tile(
         for (uint32_t i = threadIdx.x; i < n2; i += 64 * NW) skey[i] = 0xFFFFFFFFu;
         for (uint32_t i = lane; i < 192; i += 64) acc[i] = 0;
     }
+    STAT_T(11, t0_);
     tile_sync();
+    STAT_T(5, t0_);
+    const unsigned long long ts1_ = STAT_NOW();
+    (void)ts1_;
     if (wv == 0) {
-        for (uint32_t j = 0; j < my_k; j++) {
-            const uint32_t w = read_word[so + j];
+        auto stage = [&](uint32_t j, uint32_t w) {
             const uint32_t p = w_pos(w);
             if (S_IN_LDS) S_lds[lds_off + j] = w;
             if (DENSE) {
@@ -351,7 +375,11 @@ __device__ __forceinline__ void sweep_tile(
                 owner[lds_off + j] = (uint8_t)lane;
             }
             if (p <= max_pos) atomicOr(&bitmap[(p >> 5) & bm_mask], 1u << (p & 31));
-        }
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < OWN_WORDS; j++)
+            if (my_k > j) stage(j, pre[j]);
+        for (uint32_t j = OWN_WORDS; j < my_k; j++) stage(j, read_word[so + j]);
     }
     tile_sync();
     // tile-wide position index: bitonic sort of the keys (once per tile, by the whole workgroup)
@@ -396,7 +424,7 @@ __device__ __forceinline__ void sweep_tile(
     if (OWN) {
 #pragma unroll
         for (uint32_t j = 0; j < OWN_WORDS; j++)
-            if (my_k > j) { ow[j] = S_lds[lds_off + j]; op[j] = w_pos(ow[j]); }
+            if (my_k > j) { ow[j] = pre[j]; op[j] = w_pos(ow[j]); }
         tile_long = __ballot(my_k > OWN_WORDS) != 0;
     }
     // this lane's read word at position P (wave-uniform), or NONE
@@ -419,16 +447,15 @@ __device__ __forceinline__ void sweep_tile(
         if (!rw_missing(s)) c += ((rw_mut(s) & rw_ref(s)) == 0) ? 1 : 0;
     }
 
-    const uint32_t b0 = chunk * blocks_per_chunk;
-    const uint32_t b1 = min(m.NB, b0 + blocks_per_chunk);
-
+    STAT_T(6, ts1_);
+    const unsigned long long ts2_ = STAT_NOW();
+    (void)ts2_;
     // ---- state at the chunk start: enter words of every node still open there -
-    if (b0 < m.NB) {
-        const uint32_t cpi = b0 / m.cp_stride;
-        const uint32_t e0 = m.cp_off[cpi], e1 = m.cp_off[cpi + 1];
+    {
+        const uint32_t e0 = cp_e0, e1 = cp_e1;
         for (uint32_t e = e0; e < e1; e += 64) {
             const bool valid = e + lane < e1;
-            const uint32_t w = valid ? m.cp_word[e + lane] : 0;
+            const uint32_t w = e == e0 ? cp_first : (valid ? m.cp_word[e + lane] : 0);
             unsigned long long hm = __ballot(valid && bit(w_pos(w)));
             while (hm) {
                 const int l = __builtin_ctzll(hm);
@@ -444,9 +471,10 @@ __device__ __forceinline__ void sweep_tile(
     // competes, so nothing worse can win or tie -- every chunk prunes against that bound from
     // its first block on (a chunk that finds nothing reports count 0 and loses in k_finalize).
     // Idle lanes of a partial tile hold INT_MIN: no block ever looks useful to them.
-    int bs = have ? root_score[rd] + 1 : (int)0x80000000;
+    int bs = have ? root_sc + 1 : (int)0x80000000;
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
+    STAT_T(7, ts2_);
     STAT_T(0, t0_);
 
     // ---- node-by-node evaluation of one block for read r (lane = node) ----------
