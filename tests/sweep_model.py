@@ -131,8 +131,11 @@ class FlatModel:
                         for i in range(o if is_root else o + 1, nn):
                             cadd[i] += d
                         net += d
-                        H += max(-d, 0)     # descendants gain d: only d < 0 can lower a score
-                    H += 1                  # the node's own adjustment is at least -1
+                        # descendants gain d (only d < 0 lowers a score), the node itself takes no d but an
+                        # adjustment of at least -1: no node is lowered by more than max(-d, 1)
+                        H += max(-d, 1)
+                    else:
+                        H += 1              # a leaf: its own adjustment is at least -1
                     touched[o] = True
                     a, dc = own_adjust(w, s)
                     adj[o] += a

@@ -478,13 +478,12 @@ __device__ __forceinline__ void sweep_tile(
     STAT_T(0, t0_);
 
     // ---- node-by-node evaluation of one block for read r (lane = node) ----------
-    // Everything it needs was fetched when the first hit of the block was seen:
+    // Everything it needs was fetched when the evaluation was decided (fetch_nodes):
     // w0/w1 + m0/m1 = this lane's two events and their node offsets, key/st = this
     // lane's node.
     // grp = the lanes whose read is word for word the read of lane r (they hold the same c, bs, br,
     // cnt at every point of the sweep): the evaluation is done once and its outcome taken by all
-    // mm = this lane's two node offsets as loaded (byte 0: first event, byte 1: second): unpacked only
-    // here, so that the load issued with the first hit of the block is not waited for before it is needed
+    // mm = this lane's two node offsets as loaded (byte 0: first event, byte 1: second)
     auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t mm,
                           int64_t key, uint32_t st, int r, unsigned long long grp) {
         const uint32_t n0 = sum.node0;
@@ -624,11 +623,11 @@ __device__ __forceinline__ void sweep_tile(
                 touched = true;
                 lbmin = min(lbmin, lbl);
                 // H bounds how far the events can LOWER a score: an exit takes d away from the nodes
-                // behind it (matters if d > 0), an enter gives d to the descendants (matters if d < 0)
-                // and changes the node's own score by at least -1
+                // behind it (matters if d > 0); an enter gives d to the descendants (matters if d < 0) and
+                // changes the node's own score, which takes no d, by at least -1: max(-d, 1) covers both
                 if (wl & W_EXIT_DEV) { net -= d; H += max(d, 0); }
                 else if (wl & W_LEAF_DEV) { H += 1; }
-                else { net += d; H += max(-d, 0) + 1; }
+                else { net += d; H += max(-d, 1); }
             }
         };
         uint32_t mm = 0, st = 0;
@@ -688,7 +687,7 @@ __device__ __forceinline__ void sweep_tile(
                             int dn, dh;
                             if (w & W_EXIT_DEV) { dn = -d; dh = max(d, 0); }
                             else if (w & W_LEAF_DEV) { dn = 0; dh = 1; }
-                            else { dn = d; dh = max(-d, 0) + 1; }
+                            else { dn = d; dh = max(-d, 1); }
                             const uint32_t o = owner[idx];
                             if (dn) atomicAdd(&acc[o], dn);
                             if (dh) atomicAdd(&acc[64 + o], dh);
