@@ -413,7 +413,23 @@ __device__ __forceinline__ void sweep_tile(
     // Slice of this lane's read inside S (LDS copy or the global array).
     const uint32_t* S = S_IN_LDS ? (const uint32_t*)S_lds : read_word;
     const uint32_t my_off = S_IN_LDS ? lds_off : so;
-    auto bit = [&](uint32_t pos) -> bool { return (bitmap[(pos >> 5) & bm_mask] >> (pos & 31)) & 1u; };
+    // position test.  `pos` is a position or a word whose low 20 bits are one: bm_words <= 2^15 (20-bit
+    // positions), so the byte-offset mask also drops the bits above the position -- shift, and, LDS read,
+    // bit-field extract (its offset operand uses the low five bits)
+    // With one sweep per workgroup the bitmap is the first thing in the workgroup's LDS (these kernels
+    // declare no static LDS; checked below): the byte offset then IS the LDS address, no base to add.
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    constexpr bool BM_AT_ZERO = SWEEP_WAVES == 1;
+#ifdef WEPP_SWEEP_STATS   // (the check costs the scalar summary loads of the product build: stats build only)
+    if (BM_AT_ZERO && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)bitmap != 0u) __builtin_trap();
+#endif
+    const uint32_t bm_mask4 = bm_mask << 2;
+    const char* bm_bytes = reinterpret_cast<const char*>(bitmap);
+    auto bit = [&](uint32_t pos) -> bool {
+        const uint32_t off = (pos >> 3) & bm_mask4;
+        const uint32_t word = BM_AT_ZERO ? *(lds_cu32*)(uintptr_t)off : *reinterpret_cast<const uint32_t*>(bm_bytes + off);
+        return __builtin_amdgcn_ubfe(word, pos, 1u) != 0;
+    };
 
     // OWN: the first OWN_WORDS words of this lane's read and their positions (an impossible
     // position where the read is shorter); tile_long = some read of the tile lists more
@@ -582,7 +598,7 @@ __device__ __forceinline__ void sweep_tile(
     auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t lbw, const BlkSum sum) {
         const unsigned long long tb_ = STAT_NOW();
         (void)tb_;
-        const unsigned long long hm0 = __ballot(bit(w_pos(w0))), hm1 = __ballot(bit(w_pos(w1)));
+        const unsigned long long hm0 = __ballot(bit(w0)), hm1 = __ballot(bit(w1));
         STAT_ADD(0, 1);
         STAT_ADD(1, (hm0 | hm1) ? 1 : 0);
         STAT_ADD(2, __popcll(hm0) + __popcll(hm1));
@@ -603,7 +619,9 @@ __device__ __forceinline__ void sweep_tile(
 #ifdef WEPP_EXP_NO_HITS     // timing experiment only (wrong results): every block takes the no-hit path
         const bool any_hit = false;
 #else
-        const bool any_hit = (hm0 | hm1) != 0 || e1 - e0 > 128;   // wave-uniform; false for most blocks
+        // wave-uniform; false for most blocks.  One 64-bit OR and one compare: hits of either half, or bit 0
+        // from the sign of 128 - (events of the block) (a block holds fewer than 2^31 events)
+        const bool any_hit = (hm0 | hm1 | (unsigned long long)((128u - (e1 - e0)) >> 31)) != 0;
 #endif
         if (!any_hit) {
             summary_update(true);
@@ -839,7 +857,7 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void k_sweep_multi(SweepPlans pl,
                                                                   const uint32_t* __restrict__ read_off,
                                                                   const uint32_t* __restrict__ read_word,
                                                                   const int32_t* __restrict__ root_score) {
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wv = SWEEP_WAVES == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t unit = blockIdx.x * SWEEP_WAVES + wv;
     if (unit >= pl.p[pl.n - 1].wg_end) return;
     uint32_t p = 0;
