@@ -104,10 +104,20 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         ds.ncp = (uint32_t)st.cp_off.size() - 1;
         ds.eager = (i + 1 < f.streams.size()) ? 1u : 0u;
         ds.tier = (uint32_t)i;
-        ds.e_clamp = (uint32_t)(std::max<uint64_t>(st.E, 2) - 2);
+        ds.e_pad = (uint32_t)st.E;
         UP(ds.nkey, st.nkey) UP(ds.nstat, st.nstat) UP(ds.blk_node0, st.blk_node0) UP(ds.blk_eoff, st.blk_eoff)
-        UP(ds.blk_sum, st.blk_sum) UP(ds.ev_word, st.ev_word) UP(ds.ev_meta, st.ev_meta) UP(ds.ev_lb, st.ev_lb) UP(ds.cp_off, st.cp_off)
-        UP(ds.cp_word, st.cp_word)
+        UP(ds.ev_meta, st.ev_meta) UP(ds.cp_off, st.cp_off) UP(ds.cp_word, st.cp_word)
+        {
+            // the sweep loads two events per lane from every block start and the summaries of the next
+            // three blocks without looking at the stream's end: padding behind the last event / block
+            std::vector<uint32_t> evw(st.ev_word);
+            evw.resize(evw.size() + EV_TAIL_PAD, W_PAD);
+            std::vector<uint8_t> evl(st.ev_lb);
+            evl.resize(evl.size() + EV_TAIL_PAD, 255);
+            std::vector<BlkSum> sums(st.blk_sum);
+            sums.resize(sums.size() + SUM_TAIL_PAD, sums.empty() ? BlkSum{} : sums.back());
+            UP(ds.ev_word, evw) UP(ds.ev_lb, evl) UP(ds.blk_sum, sums)
+        }
         h->streams.push_back(ds);
         h->stream_bytes.push_back(st.stream_bytes());
         d.tau[i] = st.tau;

@@ -16,12 +16,16 @@ constexpr uint32_t EV_OFF_MASK_DEV = EV_OFF_MASK;
 constexpr uint32_t W_EXIT_DEV = W_EXIT, W_LEAF_DEV = W_LEAF, W_PAD_DEV = W_PAD;
 constexpr uint32_t WEPP_FLAG_HAS_UNIQUE_DEV = WEPP_FLAG_HAS_UNIQUE;
 
+// padding behind the device copies of a stream's ev_word / ev_lb (events) and blk_sum (summaries): every lane
+// of a sweep loads its two events of a block, and the summaries of the next three blocks are prefetched,
+// without a look at the end of the stream
+constexpr uint32_t EV_TAIL_PAD = 128, SUM_TAIL_PAD = 4;
 // one sweep stream (a crown or the whole tree), see flatmat.hpp
 struct DevStream {
     uint32_t n, NB, cp_stride, ncp;
     uint32_t eager;   // 1 on crown streams: the per-event bounds (ev_lb) prune there, the block minimum elsewhere
     uint32_t tier;    // index of the stream in the handle (profiling counters)
-    uint32_t e_clamp; // max(E, 2) - 2: event index every lane may load from (lanes past a block's events read it and discard)
+    uint32_t e_pad;   // E: index of the first padding event behind the stream (lanes past a block's events load it)
     const int64_t* nkey;
     const uint32_t* nstat;
     const uint32_t* blk_node0;

@@ -487,7 +487,7 @@ __device__ __forceinline__ void sweep_tile(
     // competes, so nothing worse can win or tie -- every chunk prunes against that bound from
     // its first block on (a chunk that finds nothing reports count 0 and loses in k_finalize).
     // Idle lanes of a partial tile hold INT_MIN: no block ever looks useful to them.
-    int bs = have ? root_sc + 1 : (int)0x80000000;
+    int bs = have ? root_sc + 1 : -(1 << 30);
     uint32_t br = 0xFFFFFFFFu;  // its tie-break rank (smaller wins)
     uint32_t cnt = 0;           // eligible nodes attaining bs
     STAT_T(7, ts2_);
@@ -605,12 +605,12 @@ __device__ __forceinline__ void sweep_tile(
         // reads without an event in this block: one summary update (a block without statically
         // eligible nodes has base = SCORE_INF and never passes the test)
         auto summary_update = [&](bool untouched) {
-            const int s = sum.base + c;
-            const bool take = untouched && s <= bs;
+            const bool take = untouched && sum.base + c <= bs;
             STAT_ADD(6, __ballot(take) ? 1 : 0);
             if (__ballot(take)) {              // rare once a good node has been seen: skipped wave-wide
                 __builtin_amdgcn_sched_barrier(0);   // keeps the update behind a real branch (no if-conversion)
                 if (take) {
+                    const int s = sum.base + c;
                     if (s < bs) { bs = s; br = sum.rank; cnt = sum.cnt; }
                     else { cnt += sum.cnt; br = min(br, sum.rank); }
                 }
@@ -808,22 +808,24 @@ __device__ __forceinline__ void sweep_tile(
             BlkSum sm[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                // Every lane loads (lanes past the block's events from a clamped index, discarded below):
+                // Every lane loads:
                 // with loads that may or may not be issued the compiler cannot count the outstanding ones
                 // and waits for all four blocks before the first.  Crown streams: a hit nearly always
                 // needs the per-event bounds; fetching them here keeps a dependent load off the hit path
                 // (the whole-tree stream ignores them).
-                const uint32_t idx = e[q] + 2 * lane;
-                const uint32_t idc = min(idx, m.e_clamp);
-                ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idc);
-                lbw[q] = *reinterpret_cast<const uint16_t*>(m.ev_lb + idc);
-                sm[q] = m.blk_sum[min(bb + j + q, m.NB - 1)];
+                // (the device copies of ev_word / ev_lb / blk_sum carry EV_TAIL_PAD padding events and
+                // SUM_TAIL_PAD summaries behind the last one: no index needs a clamp)
+                // lanes past the block's events load padding words (the first two of the tail padding)
+                const uint32_t idr = e[q] + 2 * lane;
+                const uint32_t idx = idr < e[q + 1] ? idr : m.e_pad;
+                ww[q] = *reinterpret_cast<const uint2*>(m.ev_word + idx);
+                lbw[q] = *reinterpret_cast<const uint16_t*>(m.ev_lb + idx);
+                sm[q] = m.blk_sum[bb + j + q];
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (j + q >= ng) continue;
-                const bool ev = e[q] + 2 * lane < e[q + 1];            // lanes past the block's events: padding
-                process_block(e[q], e[q + 1], ev ? ww[q].x : W_PAD_DEV, ev ? ww[q].y : W_PAD_DEV, lbw[q], sm[q]);
+                process_block(e[q], e[q + 1], ww[q].x, ww[q].y, lbw[q], sm[q]);
             }
         }
     }
