@@ -381,7 +381,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             parts(p, d.part_score, d.part_rank, d.part_cnt);
             wg += p.ntiles * p.nchunks;
             d.wg_end = wg;
-            fin += (p.nchunks > FINALIZE_THREAD_MAX_CHUNKS) ? (p.count + 3) / 4 : (p.count + 255) / 256;   // wave / thread per read
+            fin += finalize_blocks(p.count, p.nchunks);
             d.fin_end = fin;
             lds_max = std::max(lds_max, p.lds_bytes);
         }

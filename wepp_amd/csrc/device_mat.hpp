@@ -116,9 +116,16 @@ constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep t
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                               const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
                               hipStream_t stream);
-// finalize: one thread per read up to this many chunks (lanes = consecutive reads: every partial load is
-// coalesced), one wave per read beyond (small batches cut into hundreds of chunks)
-constexpr uint32_t FINALIZE_THREAD_MAX_CHUNKS = 8;    // 64 measured no better (42 vs 46 us per 1 M reads)
+// finalize: 1, 4, 16 or 64 lanes per read by the number of chunk partials it has to combine (a wave holds
+// 64 / lanes consecutive reads: partial loads stay coalesced); 256-thread blocks.  One wave per read for
+// every plan beyond 8 chunks (the previous rule) made 60 % of the threads of a default step
+__host__ __device__ inline uint32_t finalize_lanes_per_read(uint32_t nchunks) {
+    return nchunks <= 8 ? 1u : nchunks <= 32 ? 4u : nchunks <= 128 ? 16u : 64u;
+}
+inline uint32_t finalize_blocks(uint32_t n_list, uint32_t nchunks) {
+    const uint32_t reads_per_block = 256 / finalize_lanes_per_read(nchunks);
+    return (n_list + reads_per_block - 1) / reads_per_block;
+}
 hipError_t launch_finalize_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                                  const uint32_t* d_read_word, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
                                  uint32_t* flags, hipStream_t stream);

@@ -235,16 +235,14 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
     __shared__ uint32_t base[MAX_STREAMS], before[MAX_STREAMS];
     if (threadIdx.x < MAX_STREAMS) before[threadIdx.x] = 0;
     __syncthreads();
-    // reads of every tier in the blocks before this one: the threads share the earlier blocks, each
-    // adds a block's 16 counts (one 64-byte row) -- a serial loop over all earlier blocks per tier
-    // used to be most of this kernel
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += blockDim.x) {
-        const uint32_t* row = blk_counts + b * MAX_STREAMS;
-#pragma unroll
-        for (uint32_t t = 0; t < MAX_STREAMS; t++) {
-            const uint32_t v = row[t];
-            if (v) atomicAdd(&before[t], v);
-        }
+    // reads of every tier in the blocks before this one: thread = (tier, one earlier block in 64), so that a
+    // wave's sixteen-lane groups read whole 64-byte rows and only four lanes of a wave add to the same LDS
+    // word (one thread per row with sixteen adds each serialised 64 lanes on every word)
+    {
+        const uint32_t t = threadIdx.x & (MAX_STREAMS - 1), c0 = threadIdx.x / MAX_STREAMS;
+        uint32_t acc = 0;
+        for (uint32_t b = c0; b < blockIdx.x; b += blockDim.x / MAX_STREAMS) acc += blk_counts[b * MAX_STREAMS + t];
+        if (acc) atomicAdd(&before[t], acc);
     }
     __syncthreads();
     if (threadIdx.x < MAX_STREAMS) {
@@ -909,40 +907,61 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void k_sweep_multi(SweepPlans pl,
 // reference's BFS index and recompute its has_unique flag
 // (usher_mapper.cpp:184,199,262,472,492).
 // -----------------------------------------------------------------------------
-template <bool WAVE_PER_READ>
+template <uint32_t LPR>
 __device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, const uint32_t* __restrict__ read_off,
                            const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
                            uint32_t n_list, uint32_t nchunks, const int32_t* __restrict__ part_score,
                            const uint32_t* __restrict__ part_rank, const uint32_t* __restrict__ part_cnt,
                            uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
                            uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
-    // few chunks: one thread per list entry; many chunks (small batches): one wave
-    // per entry, lanes stride over the chunks, then a wave reduction
-    const uint32_t lane = WAVE_PER_READ ? (threadIdx.x & 63) : 0;
-    const uint32_t gid = blk * blockDim.x + threadIdx.x;
-    const uint32_t i = WAVE_PER_READ ? (gid >> 6) : gid;
-    if (i >= n_list) return;
-    const uint32_t r = list[i];
+    // LPR lanes per read (finalize_lanes_per_read: 1, 4, 16 or 64 by the number of chunks): a wave holds
+    // 64 / LPR consecutive list entries, lane = sub * (64 / LPR) + entry, so that every load of a partial
+    // covers consecutive entries of LPR chunk rows; the LPR lanes of an entry stride over its chunks and
+    // are combined with xor shuffles
+    constexpr uint32_t RPW = 64 / LPR;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t sub = lane / RPW;
+    const uint32_t i = ((blk * blockDim.x + threadIdx.x) >> 6) * RPW + lane % RPW;
+    const bool valid = i < n_list;
+    if (LPR == 1 && !valid) return;                          // (no shuffles: a lane may leave)
     int bs = 0x7FFFFFFF;
     uint32_t br = 0xFFFFFFFFu, cnt = 0;
-    for (uint32_t ch = lane; ch < nchunks; ch += (WAVE_PER_READ ? 64 : 1)) {
-        const size_t o = (size_t)ch * n_list + i;
-        const int s = part_score[o];
-        if (part_cnt[o] == 0) continue;                      // this chunk found nothing within the bound
-        if (s < bs) { bs = s; br = part_rank[o]; cnt = part_cnt[o]; }
-        else if (s == bs) { cnt += part_cnt[o]; br = min(br, part_rank[o]); }
+    // the three values of a chunk are loaded together, and two chunks per round: a thread's chunks used to
+    // cost it up to three memory round trips each, one after the other
+    auto take = [&](int s, uint32_t pr, uint32_t pc) {
+        if (pc == 0) return;                                 // this chunk found nothing within the bound
+        if (s < bs) { bs = s; br = pr; cnt = pc; }
+        else if (s == bs) { cnt += pc; br = min(br, pr); }
+    };
+    if (valid) {
+        uint32_t ch = sub;
+        for (; ch + LPR < nchunks; ch += 2 * LPR) {
+            const size_t o0 = (size_t)ch * n_list + i, o1 = (size_t)(ch + LPR) * n_list + i;
+            const int s0 = part_score[o0], s1 = part_score[o1];
+            const uint32_t c0 = part_cnt[o0], c1 = part_cnt[o1];
+            const uint32_t r0 = part_rank[o0], r1 = part_rank[o1];
+            take(s0, r0, c0);
+            take(s1, r1, c1);
+        }
+        if (ch < nchunks) {
+            const size_t o = (size_t)ch * n_list + i;
+            const int s = part_score[o];
+            const uint32_t pc = part_cnt[o], pr = part_rank[o];
+            take(s, pr, pc);
+        }
     }
-    if (WAVE_PER_READ) {
-        const int smin = wave_min_i32(bs);
-        const bool at = (bs == smin) && cnt > 0;
-        br = wave_min_u32(at ? br : 0xFFFFFFFFu);
-        uint32_t csum = at ? cnt : 0;
 #pragma unroll
-        for (int msk = 32; msk >= 1; msk >>= 1) csum += (uint32_t)__shfl_xor((int)csum, msk, 64);
-        bs = smin;
-        cnt = csum;
+    for (uint32_t msk = RPW; msk < 64; msk <<= 1) {
+        const int os = __shfl_xor(bs, (int)msk, 64);
+        const uint32_t orr = (uint32_t)__shfl_xor((int)br, (int)msk, 64);
+        const uint32_t oc = (uint32_t)__shfl_xor((int)cnt, (int)msk, 64);
+        if (oc) {
+            if (os < bs) { bs = os; br = orr; cnt = oc; }
+            else if (os == bs) { cnt += oc; br = min(br, orr); }
+        }
     }
-    if (lane != 0) return;
+    if (sub != 0 || !valid) return;
+    const uint32_t r = list[i];
     // the root always competes, so some chunk reports it or better; the clamp only keeps a broken
     // invariant from becoming an out-of-bounds read
     const uint32_t d = m.rank2dfs[br < m.N ? br : 0u];
@@ -968,14 +987,14 @@ __device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, co
     if (flags) flags[r] = hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
 }
 
-template <bool WAVE_PER_READ>
+template <uint32_t LPR>
 __global__ void k_finalize(DevMAT m, const uint32_t* __restrict__ read_off,
                            const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
                            uint32_t n_list, uint32_t nchunks, const int32_t* __restrict__ part_score,
                            const uint32_t* __restrict__ part_rank, const uint32_t* __restrict__ part_cnt,
                            uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
                            uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
-    finalize_reads<WAVE_PER_READ>(m, blockIdx.x, read_off, read_word, list, n_list, nchunks, part_score, part_rank,
+    finalize_reads<LPR>(m, blockIdx.x, read_off, read_word, list, n_list, nchunks, part_score, part_rank,
                                   part_cnt, best_bfs_j, score, num_best, flags);
 }
 
@@ -988,12 +1007,15 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
     while (p + 1 < pl.n && blockIdx.x >= pl.p[p].fin_end) p++;
     const SweepPlanDev& q = pl.p[p];
     const uint32_t blk = blockIdx.x - (p ? pl.p[p - 1].fin_end : 0);
-    if (q.nchunks > FINALIZE_THREAD_MAX_CHUNKS)
-        finalize_reads<true>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank,
-                             q.part_cnt, best_bfs_j, score, num_best, flags);
-    else
-        finalize_reads<false>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank,
-                              q.part_cnt, best_bfs_j, score, num_best, flags);
+#define FIN(L) finalize_reads<L>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank, \
+                                 q.part_cnt, best_bfs_j, score, num_best, flags)
+    switch (finalize_lanes_per_read(q.nchunks)) {
+        case 1: FIN(1); break;
+        case 4: FIN(4); break;
+        case 16: FIN(16); break;
+        default: FIN(64); break;
+    }
+#undef FIN
 }
 
 // -----------------------------------------------------------------------------
@@ -1328,13 +1350,15 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
                            const uint32_t* list, uint32_t n_list, uint32_t nchunks, const int32_t* part_score,
                            const uint32_t* part_rank, const uint32_t* part_cnt, uint32_t* best_bfs_j,
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
-    if (nchunks > FINALIZE_THREAD_MAX_CHUNKS)
-        hipLaunchKernelGGL(k_finalize<true>, dim3((n_list + 3) / 4), dim3(256), 0, stream, m, d_read_off, d_read_word,
-                           list, n_list, nchunks, part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags);
-    else
-        hipLaunchKernelGGL(k_finalize<false>, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, d_read_off,
-                           d_read_word, list, n_list, nchunks, part_score, part_rank, part_cnt, best_bfs_j, score,
-                           num_best, flags);
+    const uint32_t lpr = finalize_lanes_per_read(nchunks);
+    const dim3 grid(finalize_blocks(n_list, nchunks)), block(256);
+#define FIN(L) hipLaunchKernelGGL(k_finalize<L>, grid, block, 0, stream, m, d_read_off, d_read_word, list, n_list, nchunks, \
+                                  part_score, part_rank, part_cnt, best_bfs_j, score, num_best, flags)
+    if (lpr == 1) FIN(1);
+    else if (lpr == 4) FIN(4);
+    else if (lpr == 16) FIN(16);
+    else FIN(64);
+#undef FIN
     return hipGetLastError();
 }
 
