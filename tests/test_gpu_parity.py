@@ -168,6 +168,25 @@ def test_config2_100k_nodes(oracle):
     mat.close()
 
 
+def test_small_batches_on_a_large_tree(oracle):
+    """Few reads on many nodes: every tile is swept in many chunks, whose partial results k_finalize
+    combines with 4, 16 or 64 lanes per read (finalize_lanes_per_read) instead of one thread."""
+    g = w.generate_tree(61, 200000)
+    reads = g.reads(62, 20000, p_iupac=0.01)
+    ot = oracle.OracleTree(g.tree)
+    want = ot.place_batch(reads.slice(0, 1200), os.cpu_count())
+    mat = w.Mat(g.tree)
+    for crowns in (True, False):
+        mat.set_use_crowns(crowns)
+        for n in (1, 9, 70, 1200, 5000, 20000):
+            res = mat.place_batch(reads.slice(0, n))
+            m = min(n, 1200)
+            for k, arr in (("score", res.score), ("best_j", res.best_bfs_j), ("num_best", res.num_best),
+                           ("has_unique", res.has_unique)):
+                assert (np.asarray(arr[:m]) == np.asarray(want[k][:m])).all(), (crowns, n, k)
+    mat.close()
+
+
 def test_crowns_on_and_off_agree(oracle):
     """Work skipping (crown streams) never changes a result."""
     g = w.generate_tree(51, 300000, p_ambiguous=0.002, root_mutations=1)
