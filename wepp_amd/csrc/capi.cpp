@@ -126,7 +126,8 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         h->stats.stream_bytes_of[i] = st.stream_bytes();
     }
 #undef UP
-    e = hipMalloc((void**)&h->d_info, (TI_WORDS + ROUTE_BLOCKS * MAX_STREAMS) * sizeof(uint32_t));
+    e = hipMalloc((void**)&h->d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_STREAMS) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(h->d_info, 0, 2 * TI_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_info, TI_WORDS * sizeof(uint32_t), hipHostMallocDefault);
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
         e = hipEventCreate(&h->ev0[i]);
@@ -230,14 +231,18 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         }
     };
     carve();
-    uint32_t* tier_info = mat->d_info;
-    uint32_t* blk_counts = mat->d_info + TI_WORDS;
+    uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
+    uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
 
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
-        HIP_TRY(hipMemsetAsync(tier_info, 0, TI_WORDS * sizeof(uint32_t), stream));
+        // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
+        // previous k_route), and this k_route clears the other one for the next call
+        tier_info = mat->d_info + mat->info_idx * TI_WORDS;
+        uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
         HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score, blk_counts,
-                             tier_info, slot_in_blk, stream));
+                             tier_info, slot_in_blk, tier_info_next, stream));
+        mat->info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
         return WEPP_OK;
     };
@@ -246,7 +251,15 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (rc != WEPP_OK) return rc;
     }
     HIP_TRY(hipMemcpyAsync(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    // the host sizes the launches from the counters, and the GPU idles until it has: poll for them (a
+    // blocking wait adds its wake-up, ~15 us per call, to that idle time); after ~0.1 s of polling -- a long
+    // queue in front of this call -- wait blocking
+    {
+        hipError_t q = hipErrorNotReady;
+        for (int spin = 0; spin < 200000 && (q = hipStreamQuery(stream)) == hipErrorNotReady; spin++) {}
+        (void)hipGetLastError();   // "not ready" is not an error: keep it out of the launchers' hipGetLastError()
+        if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
+    }
     const uint32_t* info = mat->h_info;
 
     // ---- plan the launches ---------------------------------------------------------

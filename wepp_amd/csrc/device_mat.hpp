@@ -71,10 +71,11 @@ constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (contig
                                           // 30 -> 22 us but the per-block prefix over earlier blocks in k_scatter 29 -> 92 us
 constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chains of dependent loads overlap
 
-// route: tier of every read + per-(block, tier) counts and per-tier max entries
+// route: tier of every read + per-(block, tier) counts and per-tier max entries; also clears tier_info_next,
+// the counters the next call will use (they must be zero before its k_route)
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, uint32_t* slot_in_blk, hipStream_t stream);
+                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
 constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less than the sort

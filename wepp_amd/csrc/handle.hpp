@@ -40,7 +40,8 @@ struct wepp_mat {
     // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    uint32_t* d_info = nullptr;       // tier_info (TI_WORDS) followed by blk_counts
+    uint32_t* d_info = nullptr;       // two sets of tier_info (TI_WORDS each, used alternately: k_route clears the other one) followed by blk_counts
+    uint32_t info_idx = 0;            // the set the next call uses (zero: cleared at creation or by the previous call's k_route)
     uint32_t* h_info = nullptr;       // pinned copy of tier_info
     // the sweeps of different streams are independent: they run concurrently on side streams
     hipStream_t side[MAX_STREAMS] = {};

@@ -167,8 +167,12 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           int32_t* __restrict__ root_score,
                                                           uint32_t* __restrict__ blk_counts,
                                                           uint32_t* __restrict__ tier_info,
-                                                          uint32_t* __restrict__ slot_in_blk) {
+                                                          uint32_t* __restrict__ slot_in_blk,
+                                                          uint32_t* __restrict__ tier_info_next) {
     __shared__ uint32_t cnt[MAX_STREAMS], mx[MAX_STREAMS];
+    // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
+    // (two fill kernels, ~10 us) in front of every call
+    if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
     if (threadIdx.x < MAX_STREAMS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
@@ -1285,9 +1289,9 @@ __global__ void k_excess(DevMAT m, const uint32_t* __restrict__ read_off, const 
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, uint32_t* slot_in_blk, hipStream_t stream) {
+                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
-                       n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info, slot_in_blk);
+                       n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
     return hipGetLastError();
 }
 
