@@ -18,6 +18,7 @@
 
 #include "epp.hpp"
 #include "handle.hpp"
+#include "staged_copy.hpp"
 
 namespace {
 
@@ -297,10 +298,11 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     }
     HIP_TRY(launch_epp_finish(N, d_dscore, 1.0 / a.fx_scale, d_score, d_dcnt, d_true, d_counts, d_div, d_scratch, stream));
     HIP_TRY(hipEventRecord(ev[4], stream));
-    HIP_TRY(hipMemcpyAsync(out->hap_score, d_score, (size_t)N * 8, hipMemcpyDeviceToHost, stream));
-    if (d_counts) HIP_TRY(hipMemcpyAsync(out->hap_read_counts, d_counts, (size_t)N * EPP_BINS * 4, hipMemcpyDeviceToHost, stream));
-    if (d_div) HIP_TRY(hipMemcpyAsync(out->hap_divergence, d_div, (size_t)N * 8, hipMemcpyDeviceToHost, stream));
-    if (epp_total) HIP_TRY(hipMemcpyAsync(out->epp_nodes, d_enodes, epp_total * 4, hipMemcpyDeviceToHost, stream));
+    // the per-haplotype outputs are gigabytes at 16 M nodes: staged copies (staged_copy.hpp)
+    HIP_TRY(d2h_staged(out->hap_score, d_score, (size_t)N * 8, stream));
+    if (d_counts) HIP_TRY(d2h_staged(out->hap_read_counts, d_counts, (size_t)N * EPP_BINS * 4, stream));
+    if (d_div) HIP_TRY(d2h_staged(out->hap_divergence, d_div, (size_t)N * 8, stream));
+    if (epp_total) HIP_TRY(d2h_staged(out->epp_nodes, d_enodes, epp_total * 4, stream));
     HIP_TRY(hipStreamSynchronize(stream));
 #undef GET
     g_last = EppTiming{};
