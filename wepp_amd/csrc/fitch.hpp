@@ -64,6 +64,9 @@ hipError_t launch_fitch_backward(const FitchTree& t, const FitchSites& s, uint32
 // order of the emitted mutations: by row, then by BFS index of the node (the order mapper_body emits them,
 // :115); k_fitch_sort_keys builds (row << 28 | node) from the queue entries, sort_reads.hip sorts
 hipError_t launch_fitch_sort_keys(const uint2* out, uint64_t n, unsigned long long* keys, uint32_t* vals, hipStream_t stream);
+hipError_t launch_fitch_decode(const unsigned long long* keys, const uint32_t* vals, const uint32_t* bfs2id, uint64_t n,
+                               uint32_t* out_site, uint32_t* out_node, uint8_t* out_par, uint8_t* out_mut,
+                               hipStream_t stream);
 hipError_t sort_u64_u32_temp_bytes(uint64_t n, uint32_t end_bit, size_t* bytes);
 hipError_t launch_sort_u64_u32(const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
                                uint32_t* vals_out, uint64_t n, uint32_t end_bit, void* temp, size_t temp_bytes,

@@ -15,6 +15,7 @@
 #include "../../include/wepp_place.h"
 #include "errors.hpp"
 #include "fitch.hpp"
+#include "staged_copy.hpp"
 #include "flatmat.hpp"
 
 using namespace wepp;
@@ -256,17 +257,22 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         if (e == hipSuccess)
             e = launch_sort_u64_u32(d_k0.as<unsigned long long>(), d_k1.as<unsigned long long>(), d_v0.as<uint32_t>(),
                                     d_v1.as<uint32_t>(), cnt, 28 + site_bits, d_tmp.p, tmp_bytes, nullptr);
-        std::vector<unsigned long long> keys(cnt);
-        std::vector<uint32_t> vals(cnt);
-        if (e == hipSuccess) e = hipMemcpy(keys.data(), d_k1.p, cnt * 8, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(vals.data(), d_v1.p, cnt * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return hipf(e, "sort / D2H copy of the mutations");
-        for (uint64_t i = 0; i < cnt; i++) {
-            out_site[i] = (uint32_t)(keys[i] >> 28);
-            out_node[i] = f.bfs2id[vals[i] & 0x0FFFFFFFu];
-            out_par[i] = (uint8_t)(1u << ((vals[i] >> 28) & 3u));
-            out_mut[i] = (uint8_t)(1u << ((vals[i] >> 30) & 3u));
-        }
+        // decoded on the device into the caller's four arrays (the raw queue entries are dead after the key
+        // kernel: its memory takes the decoded rows and node ids), then copied out (staged_copy.hpp)
+        DevBuf d_b2i, d_pm;
+        uint32_t* d_site = d_out.as<uint32_t>();
+        uint32_t* d_node = d_site + cnt;
+        if (e == hipSuccess && ((e = d_b2i.alloc((size_t)N * 4)) != hipSuccess || (e = d_pm.alloc(cnt * 2)) != hipSuccess))
+            return set_error(WEPP_ENOMEM, std::string("hipMalloc (decoding the mutations): ") + hipGetErrorString(e));
+        if (e == hipSuccess) e = hipMemcpy(d_b2i.p, f.bfs2id.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = launch_fitch_decode(d_k1.as<unsigned long long>(), d_v1.as<uint32_t>(), d_b2i.as<uint32_t>(), cnt, d_site,
+                                    d_node, d_pm.as<uint8_t>(), d_pm.as<uint8_t>() + cnt, nullptr);
+        if (e == hipSuccess) e = d2h_staged(out_site, d_site, cnt * 4, nullptr);
+        if (e == hipSuccess) e = d2h_staged(out_node, d_node, cnt * 4, nullptr);
+        if (e == hipSuccess) e = d2h_staged(out_par, d_pm.as<uint8_t>(), cnt, nullptr);
+        if (e == hipSuccess) e = d2h_staged(out_mut, d_pm.as<uint8_t>() + cnt, cnt, nullptr);
+        if (e != hipSuccess) return hipf(e, "sort / decode / D2H copy of the mutations");
         return WEPP_OK;
     }
     std::vector<uint2> raw(cnt);

@@ -798,6 +798,29 @@ hipError_t launch_fitch_sort_keys(const uint2* out, uint64_t n, unsigned long lo
     return hipGetLastError();
 }
 
+// the sorted mutations in the caller's layout: row, node id, parent and new allele as one-hot masks
+__global__ void k_fitch_decode(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                               const uint32_t* __restrict__ bfs2id, uint64_t n, uint32_t* __restrict__ out_site,
+                               uint32_t* __restrict__ out_node, uint8_t* __restrict__ out_par,
+                               uint8_t* __restrict__ out_mut) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = vals[i];
+    out_site[i] = (uint32_t)(keys[i] >> 28);
+    out_node[i] = bfs2id[v & 0x0FFFFFFFu];
+    out_par[i] = (uint8_t)(1u << ((v >> 28) & 3u));
+    out_mut[i] = (uint8_t)(1u << ((v >> 30) & 3u));
+}
+
+hipError_t launch_fitch_decode(const unsigned long long* keys, const uint32_t* vals, const uint32_t* bfs2id, uint64_t n,
+                               uint32_t* out_site, uint32_t* out_node, uint8_t* out_par, uint8_t* out_mut,
+                               hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fitch_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, vals, bfs2id, n,
+                       out_site, out_node, out_par, out_mut);
+    return hipGetLastError();
+}
+
 hipError_t launch_fitch_levels(const FitchLevels& t, const uint32_t* h_level_off, const FitchSites& s, uint32_t batch0,
                                uint32_t nbatches, uint8_t* bytes, unsigned long long* out_count, uint64_t capacity,
                                uint2* out, hipStream_t stream) {
