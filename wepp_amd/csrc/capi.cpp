@@ -447,17 +447,59 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     if (read_off[0] != 0) return set_error(WEPP_EINVAL, "read_off[0] must be 0");
     const uint64_t nw = read_off[n_reads];
     if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
-    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.
-    // Checked by a few host threads on large batches; the first offending read (lowest index) is reported.
+    HIP_TRY(hipSetDevice(mat->device));
+    uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
+    int32_t* d_pns = nullptr;
+    int rc = WEPP_OK;
+    hipError_t e = hipSuccess;
+    const size_t off_bytes = (((size_t)(n_reads + 1) * 4) + 255) & ~(size_t)255;
     {
+        // the device copies of the caller's buffers live on the handle and only grow: no hipMalloc /
+        // hipFree (and the device-wide synchronisation they imply) per call
+        const size_t in_need = off_bytes + std::max<size_t>(nw * 4, 16);
+        const size_t out_need = (size_t)n_reads * 16;
+        if (in_need > mat->io_in_bytes) {
+            if (mat->io_in) { (void)hipFree(mat->io_in); mat->io_in = nullptr; mat->io_in_bytes = 0; }
+            e = hipMalloc(&mat->io_in, in_need + in_need / 4);
+            if (e == hipSuccess) mat->io_in_bytes = in_need + in_need / 4;
+        }
+        if (e == hipSuccess && out_need > mat->io_out_bytes) {
+            if (mat->io_out) { (void)hipFree(mat->io_out); mat->io_out = nullptr; mat->io_out_bytes = 0; }
+            e = hipMalloc(&mat->io_out, out_need + out_need / 4);
+            if (e == hipSuccess) mat->io_out_bytes = out_need + out_need / 4;
+        }
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        d_off = (uint32_t*)mat->io_in;
+        d_word = (uint32_t*)((char*)mat->io_in + off_bytes);
+        d_out = (uint32_t*)mat->io_out;
+        // pinned staging (grow-only), laid out like the device buffer: offsets, then (256-byte aligned) words
+        const size_t need = std::max(in_need, out_need);
+        if (need > mat->pin_bytes) {
+            if (mat->pin) { (void)hipHostFree(mat->pin); mat->pin = nullptr; mat->pin_bytes = 0; }
+            e = hipHostMalloc(&mat->pin, need + need / 4, hipHostMallocDefault);
+            if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+            mat->pin_bytes = need + need / 4;
+        }
+    }
+    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.
+    // Checked by a few host threads on large batches, each of which also moves its reads into the pinned
+    // staging buffer (one pass over the input instead of a check and two memcpys); the first offending
+    // read (lowest index) is reported.
+    {
+        uint32_t* pin_off = (uint32_t*)mat->pin;
+        uint32_t* pin_word = (uint32_t*)((char*)mat->pin + off_bytes);
         auto check = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
             for (uint32_t r = lo; r < hi; r++) {
-                if (read_off[r + 1] < read_off[r]) { bad = r; what = 0; return; }
+                if (read_off[r + 1] < read_off[r] || read_off[r + 1] > nw) { bad = r; what = 0; return; }
                 for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
                     if ((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu)) { bad = r; what = 1; return; }
                 for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
                     if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0) { bad = r; what = 2; return; }
             }
+            // this range is well-formed (offsets monotone, within the word array): stage it
+            std::memcpy(pin_off + lo, read_off + lo, (size_t)(hi - lo + (hi == n_reads ? 1 : 0)) * 4);
+            if (read_off[hi] > read_off[lo])
+                std::memcpy(pin_word + read_off[lo], read_word + read_off[lo], (size_t)(read_off[hi] - read_off[lo]) * 4);
         };
         const uint32_t nt = n_reads >= (1u << 16) ? std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
         std::vector<uint32_t> bad(nt, 0xFFFFFFFFu);
@@ -478,48 +520,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
             return set_error(WEPP_EINVAL, "read " + std::to_string(bad[i]) + ": zero nucleotide mask");
         }
     }
-    HIP_TRY(hipSetDevice(mat->device));
-    uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
-    int32_t* d_pns = nullptr;
-    int rc = WEPP_OK;
-    hipError_t e = hipSuccess;
-    {
-        // the device copies of the caller's buffers live on the handle and only grow: no hipMalloc /
-        // hipFree (and the device-wide synchronisation they imply) per call
-        const size_t off_bytes = (((size_t)(n_reads + 1) * 4) + 255) & ~(size_t)255;
-        const size_t in_need = off_bytes + std::max<size_t>(nw * 4, 16);
-        const size_t out_need = (size_t)n_reads * 16;
-        if (in_need > mat->io_in_bytes) {
-            if (mat->io_in) { (void)hipFree(mat->io_in); mat->io_in = nullptr; mat->io_in_bytes = 0; }
-            e = hipMalloc(&mat->io_in, in_need + in_need / 4);
-            if (e == hipSuccess) mat->io_in_bytes = in_need + in_need / 4;
-        }
-        if (e == hipSuccess && out_need > mat->io_out_bytes) {
-            if (mat->io_out) { (void)hipFree(mat->io_out); mat->io_out = nullptr; mat->io_out_bytes = 0; }
-            e = hipMalloc(&mat->io_out, out_need + out_need / 4);
-            if (e == hipSuccess) mat->io_out_bytes = out_need + out_need / 4;
-        }
-        if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
-        d_off = (uint32_t*)mat->io_in;
-        d_word = (uint32_t*)((char*)mat->io_in + off_bytes);
-        d_out = (uint32_t*)mat->io_out;
-    }
-    {
-        // pinned staging (grow-only): one memcpy + one DMA each way instead of the runtime's pageable path
-        const size_t need = std::max((size_t)(n_reads + 1) * 4 + nw * 4, (size_t)n_reads * 16);
-        if (need > mat->pin_bytes) {
-            if (mat->pin) { (void)hipHostFree(mat->pin); mat->pin = nullptr; mat->pin_bytes = 0; }
-            e = hipHostMalloc(&mat->pin, need + need / 4, hipHostMallocDefault);
-            if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); goto done; }
-            mat->pin_bytes = need + need / 4;
-        }
-    }
-    std::memcpy(mat->pin, read_off, (size_t)(n_reads + 1) * 4);
-    e = hipMemcpy(d_off, mat->pin, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nw) {
-        std::memcpy(mat->pin, read_word, nw * 4);
-        e = hipMemcpy(d_word, mat->pin, nw * 4, hipMemcpyHostToDevice);
-    }
+    e = hipMemcpy(d_off, mat->pin, off_bytes + nw * 4, hipMemcpyHostToDevice);     // offsets and words in one DMA
     if (e != hipSuccess) { rc = hip_fail(e, "H2D copy of the reads"); goto done; }
     rc = wepp_place_batch_device(mat, d_off, d_word, n_reads, nw, d_out, (int32_t*)(d_out + n_reads),
                                  d_out + 2 * (size_t)n_reads, d_out + 3 * (size_t)n_reads, nullptr);
@@ -536,10 +537,15 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     if (e != hipSuccess) { rc = hip_fail(e, "placement kernels / D2H copy of the results"); goto done; }
     {
         const uint32_t* po = (const uint32_t*)mat->pin;
-        if (best_bfs_j) std::memcpy(best_bfs_j, po, (size_t)n_reads * 4);
-        if (score) std::memcpy(score, po + n_reads, (size_t)n_reads * 4);
-        if (num_best) std::memcpy(num_best, po + 2 * (size_t)n_reads, (size_t)n_reads * 4);
-        if (flags) std::memcpy(flags, po + 3 * (size_t)n_reads, (size_t)n_reads * 4);
+        void* dst[4] = {best_bfs_j, score, num_best, flags};
+        auto move = [&](int i) { if (dst[i]) std::memcpy(dst[i], po + (size_t)i * n_reads, (size_t)n_reads * 4); };
+        if (n_reads >= (1u << 16) && std::thread::hardware_concurrency() >= 4) {   // one host thread per output array
+            std::thread t1(move, 1), t2(move, 2), t3(move, 3);
+            move(0);
+            t1.join(); t2.join(); t3.join();
+        } else {
+            for (int i = 0; i < 4; i++) move(i);
+        }
     }
 done:
     if (d_pns) (void)hipFree(d_pns);
