@@ -103,13 +103,37 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     hipStream_t stream = nullptr;
 
     // ---- reads in window order, tiles, groups ------------------------------------------
+    // order by (start, end, index).  Window bounds are genome positions: two stable counting passes (end,
+    // then start) instead of a comparison sort through two indirections (≈0.1 s per 1 M reads)
     std::vector<uint32_t> order(R);
-    std::iota(order.begin(), order.end(), 0u);
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        if (rd->start[a] != rd->start[b]) return rd->start[a] < rd->start[b];
-        if (rd->end[a] != rd->end[b]) return rd->end[a] < rd->end[b];
-        return a < b;
-    });
+    {
+        int32_t lo = 0, hi = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            lo = std::min({lo, rd->start[r], rd->end[r]});
+            hi = std::max({hi, rd->start[r], rd->end[r]});
+        }
+        if (lo < 0 || (uint64_t)hi > (1ull << 24)) {          // not positions: the general way
+            std::iota(order.begin(), order.end(), 0u);
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                if (rd->start[a] != rd->start[b]) return rd->start[a] < rd->start[b];
+                if (rd->end[a] != rd->end[b]) return rd->end[a] < rd->end[b];
+                return a < b;
+            });
+        } else {
+            std::vector<uint32_t> tmp(R), cnt((size_t)hi + 2);
+            auto pass = [&](const int32_t* key, const uint32_t* in, uint32_t* out) {
+                std::fill(cnt.begin(), cnt.end(), 0u);
+                for (uint32_t s = 0; s < R; s++) cnt[(size_t)key[in ? in[s] : s] + 1]++;
+                for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+                for (uint32_t s = 0; s < R; s++) {
+                    const uint32_t r = in ? in[s] : s;
+                    out[cnt[(size_t)key[r]]++] = r;
+                }
+            };
+            pass(rd->end, nullptr, tmp.data());
+            pass(rd->start, tmp.data(), order.data());
+        }
+    }
     // reads per lane.  4 shares the serial per-event work (broadcasts, flips, atomics) among 256 reads
     // per wave, but a tile that large lists almost every position of its window, so every event takes
     // the allele-lookup path: measured 1.4x slower than 1 -- kept selectable for
