@@ -23,15 +23,25 @@ inline hipError_t d2h_staged(void* dst, const void* src, size_t bytes, hipStream
         hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
         return e != hipSuccess ? e : hipStreamSynchronize(stream);
     }
-    static std::mutex mu;                     // one staged copy at a time per process: the buffers are shared
-    static char* pin[2] = {nullptr, nullptr};
-    static hipEvent_t ev[2];
-    std::lock_guard<std::mutex> lock(mu);
-    hipError_t e;
+    // staging state per device (events belong to a device): one staged copy at a time per device and process
+    struct Stage { std::mutex mu; char* pin[2] = {nullptr, nullptr}; hipEvent_t ev[2]; };
+    constexpr int MAX_DEV = 64;
+    static Stage stages[MAX_DEV];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEV) {
+        e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(stream);
+    }
+    Stage& st = stages[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    char** pin = st.pin;
+    hipEvent_t* ev = st.ev;
     if (!pin[0]) {
         char *a = nullptr, *b = nullptr;
-        if ((e = hipHostMalloc((void**)&a, STAGE_CHUNK, hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void**)&b, STAGE_CHUNK, hipHostMallocDefault)) != hipSuccess) { (void)hipHostFree(a); return e; }
+        if ((e = hipHostMalloc((void**)&a, STAGE_CHUNK, hipHostMallocPortable)) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void**)&b, STAGE_CHUNK, hipHostMallocPortable)) != hipSuccess) { (void)hipHostFree(a); return e; }
         if ((e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming)) != hipSuccess) {
             (void)hipHostFree(a); (void)hipHostFree(b);
