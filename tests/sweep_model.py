@@ -135,7 +135,12 @@ class FlatModel:
                         # adjustment of at least -1: no node is lowered by more than max(-d, 1)
                         H += max(-d, 1)
                     else:
-                        H += 1              # a leaf: its own adjustment is at least -1
+                        # a leaf: only its own adjustment can lower it, by one, and only if the read shares
+                        # the new allele and not the parent's
+                        _, ref_, par_, mut_ = _tw(w)
+                        _, sref_, a_, missing_ = s
+                        lowers = (not missing_) and (a_ & mut_) != 0 and (a_ & (par_ if par_ else sref_)) == 0
+                        H += 1 if lowers else 0     # (= actual_sub of own_adjust)
                     touched[o] = True
                     a, dc = own_adjust(w, s)
                     adj[o] += a

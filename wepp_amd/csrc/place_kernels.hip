@@ -679,7 +679,14 @@ __device__ __forceinline__ void sweep_tile(
                 // behind it (matters if d > 0); an enter gives d to the descendants (matters if d < 0) and
                 // changes the node's own score, which takes no d, by at least -1: max(-d, 1) covers both
                 if (wl & W_EXIT_DEV) { net -= d; H += max(d, 0); }
-                else if (wl & W_LEAF_DEV) { H += 1; }
+                else if (wl & W_LEAF_DEV) {
+                    // a leaf has no descendants: only its own adjustment can lower its score, and it does
+                    // (by one) only if the read shares the new allele and not the parent's (own_adjust:
+                    // actual_sub); an N or another allele leaves the leaf's score where it was
+                    const uint32_t a = rw_mut(s), par = tw_par(wl);
+                    const bool lowers = !rw_missing(s) && (a & tw_mut(wl)) != 0 && (a & (par ? par : rw_ref(s))) == 0;
+                    H += lowers ? 1 : 0;
+                }
                 else { net += d; H += max(-d, 1); }
             }
         };
@@ -739,7 +746,11 @@ __device__ __forceinline__ void sweep_tile(
                             const int d = enter_delta(w, S_lds[idx]);
                             int dn, dh;
                             if (w & W_EXIT_DEV) { dn = -d; dh = max(d, 0); }
-                            else if (w & W_LEAF_DEV) { dn = 0; dh = 1; }
+                            else if (w & W_LEAF_DEV) {
+                                const uint32_t sl = S_lds[idx], a = rw_mut(sl), par = tw_par(w);
+                                dn = 0;
+                                dh = (!rw_missing(sl) && (a & tw_mut(w)) != 0 && (a & (par ? par : rw_ref(sl))) == 0) ? 1 : 0;
+                            }
                             else { dn = d; dh = max(-d, 1); }
                             const uint32_t o = owner[idx];
                             if (dn) atomicAdd(&acc[o], dn);
