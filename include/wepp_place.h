@@ -21,8 +21,12 @@
  *    src/mutation_annotated_tree.cpp:474,514,533);
  *  - nucleotides are the reference's 4-bit one-hot/IUPAC masks A=1 C=2 G=4 T=8,
  *    N=15 (src/mutation_annotated_tree.cpp:19-74);
- *  - a handle is bound to one device and is not re-entrant; different handles
- *    may be used concurrently from different host threads (one per GPU).
+ *  - a handle is bound to one device and is not re-entrant: its workspace, routing
+ *    counters and staging buffers belong to one call at a time, so the calls on one
+ *    handle must be serial AND, for wepp_place_batch_device, ordered on ONE stream
+ *    (or separated by a synchronisation).  Different handles -- on different GPUs or
+ *    on the same one -- may be used concurrently from different host threads
+ *    (tests/test_gpu_parity.py::test_two_handles_two_host_threads).
  */
 #ifndef WEPP_PLACE_H
 #define WEPP_PLACE_H
@@ -163,8 +167,14 @@ int wepp_excess_mutations(wepp_mat_t *mat, const uint32_t *read_off, const uint3
 
 /* Same computation with every buffer already resident on the handle's device
  * (device pointers); work is enqueued on `hip_stream` (a hipStream_t, NULL =
- * the default stream) and NOT synchronised on return.  n_read_words =
- * read_off[n_reads].  Used when the caller keeps reads in HBM. */
+ * the default stream).  n_read_words = read_off[n_reads].  Used when the caller
+ * keeps reads in HBM.
+ * Synchronisation: the call BLOCKS the host until the two routing kernels (~20 us per
+ * 1 M reads, plus whatever precedes them on the stream) have finished -- the sweep
+ * grids are sized from their counters --, then enqueues the sweeps and returns
+ * WITHOUT waiting for them: the results are valid once `hip_stream` has reached the
+ * point of return.  Work the caller wants overlapped with the routing (the next
+ * batch's H2D) goes on another stream. */
 int wepp_place_batch_device(wepp_mat_t *mat, const uint32_t *d_read_off, const uint32_t *d_read_word,
                             uint32_t n_reads, uint64_t n_read_words, uint32_t *d_best_bfs_j,
                             int32_t *d_score, uint32_t *d_num_best, uint32_t *d_flags,
@@ -189,6 +199,11 @@ int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
 int wepp_mat_timing_reset(wepp_mat_t *mat);
 int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_calls, uint64_t *passes,
                          uint64_t *algorithmic_bytes);
+
+/* Diagnostic: tiers[r] = index of the sweep stream (wepp_mat_stats::stream_tau) read r of
+ * the handle's most recent placement call was routed to; n_reads must be that call's.
+ * Synchronises the device.  Lets a test reach every stream with the oracle. */
+int wepp_mat_last_tiers(wepp_mat_t *mat, uint8_t *tiers, uint32_t n_reads);
 
 const char *wepp_last_error(void);
 

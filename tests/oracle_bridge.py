@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "oracle", f) for f in ("mapper2_oracle.c", "epp_oracle.c")]
+SRCS = [os.path.join(ROOT, "oracle", f) for f in ("mapper2_oracle.c", "epp_oracle.c", "incremental_oracle.c")]
 DEPS = SRCS + [os.path.join(ROOT, "oracle", "oracle_tree.h")]
 OUT_DIR = os.path.join(ROOT, "oracle", "_build")
 OUT = os.path.join(OUT_DIR, "liboracle.so")
@@ -55,6 +55,12 @@ def lib():
             ctypes.c_uint64] + [ctypes.c_void_p] * 3
         L.oracle_epp_distance.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [
             ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.inc_tree_build.restype = ctypes.c_void_p
+        L.inc_tree_build.argtypes = [ctypes.c_void_p]
+        L.inc_tree_free.argtypes = [ctypes.c_void_p]
+        L.inc_place_sample.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + [
+            ctypes.POINTER(OracleResult), ctypes.c_void_p]
+        L.inc_place_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         for f in ("oracle_tree_bfs_ids", "oracle_tree_dfs_ids", "oracle_tree_num_leaves"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
@@ -208,9 +214,75 @@ class OracleTree:
                                   int(start), int(end), _p(out))
         return out
 
+    def incremental(self):
+        """The one-walk-per-read checker (oracle/incremental_oracle.c) over the same pointer tree."""
+        return IncrementalTree(self)
+
     def close(self):
         if self._h:
             lib().oracle_tree_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+RESULT_DTYPE = np.dtype([("score", "<i4"), ("num_best", "<u4"), ("best_j", "<u4"), ("best_node_id", "<i4"),
+                         ("has_unique", "<u4")])
+
+
+class IncrementalTree:
+    """oracle/incremental_oracle.c: one pre-order walk per read (SURVEY.md Appendix A closed form).
+    Trusted only through tests/test_incremental.py (equality with the faithful restatement)."""
+
+    def __init__(self, oracle_tree):
+        self._ot = oracle_tree          # keeps the pointer tree (and its arrays) alive
+        self.n = oracle_tree.n
+        self._h = lib().inc_tree_build(oracle_tree._h)
+        if not self._h:
+            raise MemoryError("inc_tree_build failed")
+
+    def place_sample(self, pos, ref, mut, missing, per_node_scores=False, want_best_vec=False):
+        pos = np.ascontiguousarray(pos, np.int32); ref = np.ascontiguousarray(ref, np.uint8)
+        mut = np.ascontiguousarray(mut, np.uint8); missing = np.ascontiguousarray(missing, np.uint8)
+        n = len(pos)
+        z32 = np.zeros(1, np.int32); z8 = np.zeros(1, np.uint8)
+        res = OracleResult()
+        nsd = np.zeros(self.n, np.int32) if per_node_scores else None
+        bv = np.zeros(self.n, np.uint32) if want_best_vec else None
+        rc = lib().inc_place_sample(self._h, n, _p(pos if n else z32), _p(ref if n else z8), _p(mut if n else z8),
+                                    _p(missing if n else z8), _p(nsd) if per_node_scores else None, ctypes.byref(res),
+                                    _p(bv) if want_best_vec else None)
+        if rc:
+            raise ValueError("inc_place_sample failed: %d" % rc)
+        out = dict(score=res.score, num_best=res.num_best, best_j=res.best_j, best_node_id=res.best_node_id,
+                   has_unique=res.has_unique)
+        if per_node_scores:
+            out["node_scores"] = nsd
+        if want_best_vec:
+            out["best_j_vec"] = np.sort(bv[: res.num_best])
+        return out
+
+    def place_batch(self, reads, nthreads=1):
+        from wepp_amd import unpack_read_word
+        R = reads.n_reads
+        pos, ref, mut, miss = unpack_read_word(reads.read_word)
+        if pos.size == 0:
+            pos = np.zeros(1, np.int32); ref = np.zeros(1, np.uint8); mut = np.zeros(1, np.uint8); miss = np.zeros(1, np.uint8)
+        res = (OracleResult * max(R, 1))()
+        rc = lib().inc_place_batch(self._h, R, _p(reads.read_off), _p(np.ascontiguousarray(pos)),
+                                   _p(np.ascontiguousarray(ref)), _p(np.ascontiguousarray(mut)),
+                                   _p(np.ascontiguousarray(miss)), ctypes.cast(res, ctypes.c_void_p), int(nthreads))
+        if rc:
+            raise ValueError("inc_place_batch failed: %d" % rc)
+        return np.frombuffer(res, dtype=RESULT_DTYPE, count=R).copy()
+
+    def close(self):
+        if self._h:
+            lib().inc_tree_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -405,6 +405,12 @@ class Mat:
         check(lib.wepp_place_batch_device(self._h, d_read_off, d_read_word, int(n_reads), int(n_read_words),
                                           d_best, d_score, d_num_best, d_flags, stream or None))
 
+    def last_tiers(self, n_reads):
+        """Sweep stream every read of the last placement call was routed to (diagnostic)."""
+        out = np.zeros(int(n_reads), np.uint8)
+        check(lib.wepp_mat_last_tiers(self._h, _ptr(out), int(n_reads)))
+        return out
+
     def timing_reset(self):
         check(lib.wepp_mat_timing_reset(self._h))
 

@@ -407,6 +407,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     mat->n_timed++;
     mat->last_passes = passes;
     mat->last_bytes = bytes;
+    mat->last_n_reads = n_reads;
     return WEPP_OK;
 }
 
@@ -552,10 +553,49 @@ done:
     return rc;
 }
 
+namespace {
+
+// shared argument check of the calls that take a read CSR from the host: offsets start at 0, are monotone and
+// stay inside the word array (whose size is read_off[n_reads])
+int check_read_csr(const uint32_t* read_off, const uint32_t* read_word, uint32_t n_reads) {
+    if (!read_off) return set_error(WEPP_EINVAL, "null read_off");
+    if (read_off[0] != 0) return set_error(WEPP_EINVAL, "read_off[0] must be 0");
+    for (uint32_t r = 0; r < n_reads; r++)
+        if (read_off[r + 1] < read_off[r]) return set_error(WEPP_EINVAL, "read_off not monotone");
+    if (read_off[n_reads] && !read_word) return set_error(WEPP_EINVAL, "null read_word");
+    return WEPP_OK;
+}
+
+// Grow-only buffers of the handle for the pass-2 calls: `dev_bytes` of device memory in io_in and `pin_bytes`
+// of pinned staging (the same buffers wepp_place_batch uses; the calls on a handle are serial).
+int reserve_io(wepp_mat* mat, size_t dev_bytes, size_t pin_need) {
+    if (dev_bytes > mat->io_in_bytes) {
+        if (mat->io_in) { (void)hipFree(mat->io_in); mat->io_in = nullptr; mat->io_in_bytes = 0; }
+        hipError_t e = hipMalloc(&mat->io_in, dev_bytes + dev_bytes / 4);
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        mat->io_in_bytes = dev_bytes + dev_bytes / 4;
+    }
+    if (pin_need > mat->pin_bytes) {
+        if (mat->pin) { (void)hipHostFree(mat->pin); mat->pin = nullptr; mat->pin_bytes = 0; }
+        hipError_t e = hipHostMalloc(&mat->pin, pin_need + pin_need / 4, hipHostMallocDefault);
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        mat->pin_bytes = pin_need + pin_need / 4;
+    }
+    return WEPP_OK;
+}
+
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
 extern "C" int wepp_imputed_mutations(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word,
                                       uint32_t n_reads, const uint32_t* best_bfs_j, uint32_t* imp_off,
                                       int32_t* imp_pos, uint8_t* imp_nuc, uint64_t capacity) {
     if (!mat || !read_off || !best_bfs_j || !imp_off) return set_error(WEPP_EINVAL, "null argument");
+    {
+        int rc = check_read_csr(read_off, read_word, n_reads);
+        if (rc != WEPP_OK) return rc;
+    }
     std::vector<uint32_t> pairs;
     imp_off[0] = 0;
     for (uint32_t r = 0; r < n_reads; r++) {
@@ -569,33 +609,33 @@ extern "C" int wepp_imputed_mutations(wepp_mat_t* mat, const uint32_t* read_off,
     const uint32_t np = (uint32_t)(pairs.size() / 2);
     if (np > capacity) return set_error(WEPP_ELIMIT, "imputed-mutation buffers too small: need " + std::to_string(np));
     if (np == 0) return WEPP_OK;
-    if (!imp_pos || !imp_nuc || !read_word) return set_error(WEPP_EINVAL, "null argument");
+    if (!imp_pos || !imp_nuc) return set_error(WEPP_EINVAL, "null argument");
     for (uint32_t i = 0; i < np; i++) imp_pos[i] = (int32_t)(read_word[pairs[2 * i + 1]] & 0xFFFFFu);
     HIP_TRY(hipSetDevice(mat->device));
+    // one staged upload (offsets | words | placements | pairs) and one download (nucleotides) through the
+    // handle's pinned buffer; device memory from its grow-only input buffer
     const uint64_t nw = read_off[n_reads];
-    uint32_t *d_off = nullptr, *d_word = nullptr, *d_best = nullptr, *d_pairs = nullptr;
-    uint8_t* d_nuc = nullptr;
-    int rc = WEPP_OK;
-    hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_best, (size_t)n_reads * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_pairs, (size_t)np * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_nuc, np);
-    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
-    e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_best, best_bfs_j, (size_t)n_reads * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_pairs, pairs.data(), (size_t)np * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_imputed(mat->dev, d_off, d_word, d_best, d_pairs, np, d_nuc, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(imp_nuc, d_nuc, np, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = hip_fail(e, "imputed-mutation kernel");
-done:
-    if (d_off) (void)hipFree(d_off);
-    if (d_word) (void)hipFree(d_word);
-    if (d_best) (void)hipFree(d_best);
-    if (d_pairs) (void)hipFree(d_pairs);
-    if (d_nuc) (void)hipFree(d_nuc);
-    return rc;
+    const size_t b_off = pad256((size_t)(n_reads + 1) * 4), b_word = pad256(std::max<size_t>(nw * 4, 16));
+    const size_t b_best = pad256((size_t)n_reads * 4), b_pairs = pad256((size_t)np * 8), b_nuc = pad256(np);
+    const size_t up = b_off + b_word + b_best + b_pairs;
+    {
+        int rc = reserve_io(mat, up + b_nuc, up);
+        if (rc != WEPP_OK) return rc;
+    }
+    char* hp = (char*)mat->pin;
+    std::memcpy(hp, read_off, (size_t)(n_reads + 1) * 4);
+    if (nw) std::memcpy(hp + b_off, read_word, nw * 4);
+    std::memcpy(hp + b_off + b_word, best_bfs_j, (size_t)n_reads * 4);
+    std::memcpy(hp + b_off + b_word + b_best, pairs.data(), (size_t)np * 8);
+    char* dp = (char*)mat->io_in;
+    HIP_TRY(hipMemcpy(dp, hp, up, hipMemcpyHostToDevice));
+    uint8_t* d_nuc = (uint8_t*)(dp + up);
+    HIP_TRY(launch_imputed(mat->dev, (const uint32_t*)dp, (const uint32_t*)(dp + b_off), (const uint32_t*)(dp + b_off + b_word),
+                           (const uint32_t*)(dp + b_off + b_word + b_best), np, d_nuc, nullptr));
+    hipError_t e = hipMemcpy(hp, d_nuc, np, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "imputed-mutation kernel");
+    std::memcpy(imp_nuc, hp, np);
+    return WEPP_OK;
 }
 
 extern "C" int wepp_excess_mutations(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word,
@@ -606,57 +646,93 @@ extern "C" int wepp_excess_mutations(wepp_mat_t* mat, const uint32_t* read_off, 
     exc_off[0] = 0;
     if (n_pairs == 0) return WEPP_OK;
     if (!pair_read || !pair_bfs_j) return set_error(WEPP_EINVAL, "null argument");
+    {
+        int rc = check_read_csr(read_off, read_word, n_reads);
+        if (rc != WEPP_OK) return rc;
+    }
     for (uint32_t i = 0; i < n_pairs; i++) {
         if (pair_read[i] >= n_reads) return set_error(WEPP_EINVAL, "pair_read out of range");
         if (pair_bfs_j[i] >= mat->dev.N) return set_error(WEPP_EINVAL, "pair_bfs_j out of range");
     }
     const uint64_t nw = read_off[n_reads];
-    if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
     HIP_TRY(hipSetDevice(mat->device));
-    uint32_t *d_off = nullptr, *d_word = nullptr, *d_pr = nullptr, *d_pj = nullptr, *d_cnt = nullptr, *d_out = nullptr;
-    unsigned long long* d_ooff = nullptr;
-    std::vector<uint32_t> counts(n_pairs), packed;
-    std::vector<unsigned long long> ooff(n_pairs);
+    // upload (offsets | words | pair reads | pair nodes), count, size the output, emit: all through the
+    // handle's grow-only device buffer and pinned staging buffer
+    const size_t b_off = pad256((size_t)(n_reads + 1) * 4), b_word = pad256(std::max<size_t>(nw * 4, 16));
+    const size_t b_pair = pad256((size_t)n_pairs * 4), b_ooff = pad256((size_t)n_pairs * 8);
+    const size_t up = b_off + b_word + 2 * b_pair;
+    const size_t fixed = up + b_pair /* counts */ + b_ooff;
+    {
+        int rc = reserve_io(mat, fixed, std::max(up, b_ooff));
+        if (rc != WEPP_OK) return rc;
+    }
+    char* hp = (char*)mat->pin;
+    std::memcpy(hp, read_off, (size_t)(n_reads + 1) * 4);
+    if (nw) std::memcpy(hp + b_off, read_word, nw * 4);
+    std::memcpy(hp + b_off + b_word, pair_read, (size_t)n_pairs * 4);
+    std::memcpy(hp + b_off + b_word + b_pair, pair_bfs_j, (size_t)n_pairs * 4);
+    char* dp = (char*)mat->io_in;
+    HIP_TRY(hipMemcpy(dp, hp, up, hipMemcpyHostToDevice));
+    const uint32_t *d_off = (const uint32_t*)dp, *d_word = (const uint32_t*)(dp + b_off);
+    const uint32_t *d_pr = (const uint32_t*)(dp + b_off + b_word), *d_pj = (const uint32_t*)(dp + b_off + b_word + b_pair);
+    uint32_t* d_cnt = (uint32_t*)(dp + up);
+    unsigned long long* d_ooff = (unsigned long long*)(dp + up + b_pair);
+    HIP_TRY(launch_excess(mat->dev, d_off, d_word, d_pr, d_pj, n_pairs, nullptr, d_cnt, nullptr, nullptr));
+    hipError_t e = hipMemcpy(hp, d_cnt, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "excess-mutation count");
     uint64_t total = 0;
-    int rc = WEPP_OK;
-    hipError_t e = hipMalloc((void**)&d_off, (size_t)(n_reads + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_word, std::max<size_t>(nw * 4, 16));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_pr, (size_t)n_pairs * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_pj, (size_t)n_pairs * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, (size_t)n_pairs * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_ooff, (size_t)n_pairs * 8);
-    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
-    e = hipMemcpy(d_off, read_off, (size_t)(n_reads + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nw) e = hipMemcpy(d_word, read_word, nw * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_pr, pair_read, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_pj, pair_bfs_j, (size_t)n_pairs * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_excess(mat->dev, d_off, d_word, d_pr, d_pj, n_pairs, nullptr, d_cnt, nullptr, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(counts.data(), d_cnt, (size_t)n_pairs * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { rc = hip_fail(e, "excess-mutation count"); goto done; }
-    for (uint32_t i = 0; i < n_pairs; i++) { ooff[i] = total; total += counts[i]; exc_off[i + 1] = total; }
-    if (total > capacity) { rc = set_error(WEPP_ELIMIT, "excess-mutation buffers too small: need " + std::to_string(total)); goto done; }
-    if (total == 0) goto done;
-    if (!exc_pos || !exc_ref || !exc_par || !exc_mut) { rc = set_error(WEPP_EINVAL, "null output array"); goto done; }
-    e = hipMalloc((void**)&d_out, total * 4);
-    if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); goto done; }
-    e = hipMemcpy(d_ooff, ooff.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_excess(mat->dev, d_off, d_word, d_pr, d_pj, n_pairs, d_ooff, d_cnt, d_out, nullptr);
-    packed.resize(total);
-    if (e == hipSuccess) e = hipMemcpy(packed.data(), d_out, total * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { rc = hip_fail(e, "excess-mutation kernel"); goto done; }
+    {
+        const uint32_t* counts = (const uint32_t*)hp;
+        for (uint32_t i = 0; i < n_pairs; i++) { total += counts[i]; exc_off[i + 1] = total; }
+    }
+    if (total > capacity) return set_error(WEPP_ELIMIT, "excess-mutation buffers too small: need " + std::to_string(total));
+    if (total == 0) return WEPP_OK;
+    if (!exc_pos || !exc_ref || !exc_par || !exc_mut) return set_error(WEPP_EINVAL, "null output array");
+    {
+        // the device buffer may move when it grows: the inputs are uploaded again behind the new base
+        const bool grows = fixed + pad256(total * 4) > mat->io_in_bytes;
+        int rc = reserve_io(mat, fixed + pad256(total * 4), std::max({up, b_ooff, (size_t)total * 4}));
+        if (rc != WEPP_OK) return rc;
+        hp = (char*)mat->pin;
+        if (grows) {
+            std::memcpy(hp, read_off, (size_t)(n_reads + 1) * 4);
+            if (nw) std::memcpy(hp + b_off, read_word, nw * 4);
+            std::memcpy(hp + b_off + b_word, pair_read, (size_t)n_pairs * 4);
+            std::memcpy(hp + b_off + b_word + b_pair, pair_bfs_j, (size_t)n_pairs * 4);
+            dp = (char*)mat->io_in;
+            HIP_TRY(hipMemcpy(dp, hp, up, hipMemcpyHostToDevice));
+            d_off = (const uint32_t*)dp; d_word = (const uint32_t*)(dp + b_off);
+            d_pr = (const uint32_t*)(dp + b_off + b_word); d_pj = (const uint32_t*)(dp + b_off + b_word + b_pair);
+            d_cnt = (uint32_t*)(dp + up);
+            d_ooff = (unsigned long long*)(dp + up + b_pair);
+        }
+    }
+    {
+        unsigned long long* ho = (unsigned long long*)hp;
+        for (uint32_t i = 0; i < n_pairs; i++) ho[i] = exc_off[i];
+        HIP_TRY(hipMemcpy(d_ooff, ho, (size_t)n_pairs * 8, hipMemcpyHostToDevice));
+    }
+    uint32_t* d_out = (uint32_t*)(dp + fixed);
+    HIP_TRY(launch_excess(mat->dev, d_off, d_word, d_pr, d_pj, n_pairs, d_ooff, d_cnt, d_out, nullptr));
+    e = hipMemcpy(hp, d_out, total * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "excess-mutation kernel");
+    const uint32_t* packed = (const uint32_t*)hp;
     for (uint64_t q = 0; q < total; q++) {
         exc_pos[q] = (int32_t)(packed[q] & 0xFFFFFu);
         exc_ref[q] = (uint8_t)((packed[q] >> 20) & 15u);
         exc_par[q] = (uint8_t)((packed[q] >> 24) & 15u);
         exc_mut[q] = (uint8_t)((packed[q] >> 28) & 15u);
     }
-done:
-    if (d_off) (void)hipFree(d_off);
-    if (d_word) (void)hipFree(d_word);
-    if (d_pr) (void)hipFree(d_pr);
-    if (d_pj) (void)hipFree(d_pj);
-    if (d_cnt) (void)hipFree(d_cnt);
-    if (d_ooff) (void)hipFree(d_ooff);
-    if (d_out) (void)hipFree(d_out);
-    return rc;
+    return WEPP_OK;
+}
+
+// diagnostic: the sweep stream every read of the handle's most recent placement call was routed to
+extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_reads) {
+    if (!mat || !tiers) return set_error(WEPP_EINVAL, "null argument");
+    if (n_reads != mat->last_n_reads || !mat->ws)
+        return set_error(WEPP_EINVAL, "n_reads differs from the handle's last placement call");
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(tiers, mat->ws, n_reads, hipMemcpyDeviceToHost));
+    return WEPP_OK;
 }

@@ -96,6 +96,10 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     }
     // rows: reference base index, tree samples sorted by node index (BFS for the level-synchronous
     // form, DFS for the two stack forms)
+    // the CSR over the rows is checked before anything is sized from it or written through it
+    if (var_off[0] != 0) return set_error(WEPP_EINVAL, "var_off[0] must be 0");
+    for (uint32_t s = 0; s < n_sites; s++)
+        if (var_off[s + 1] < var_off[s]) return set_error(WEPP_EINVAL, "var_off not monotone");
     const uint64_t nv = var_off[n_sites];
     if (nv && (!var_node || !var_nuc)) return set_error(WEPP_EINVAL, "null variant arrays");
     for (uint64_t k = 0; k < nv; k++)

@@ -50,6 +50,7 @@ struct wepp_mat {
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_timed = 0;             // placement calls since the last timing reset
     uint64_t last_passes = 0, last_bytes = 0;
+    uint32_t last_n_reads = 0;        // reads of the most recent placement call (wepp_mat_last_tiers)
 };
 
 namespace wepp {

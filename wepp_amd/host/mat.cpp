@@ -28,7 +28,10 @@ int8_t get_nuc_id(char nuc) {
 
 int8_t get_nuc_id(const std::vector<int8_t>& nuc_vec) {
     int8_t ret = 0;
-    for (int8_t n : nuc_vec) ret = (int8_t)(ret + (int8_t)(1 << n));
+    for (int8_t n : nuc_vec) {
+        if (n < 0 || n > 3) throw mat_error("ERROR: nucleotide index outside 0..3");
+        ret = (int8_t)(ret + (int8_t)(1 << n));
+    }
     return ret;
 }
 
@@ -157,26 +160,23 @@ std::vector<Node*> Tree::depth_first_expansion(Node* node) const {
 
 // ---- strings --------------------------------------------------------------------
 void Tree::uncondense_leaves() {
-    for (auto& cn : condensed_nodes) {
-        Node* n = get_node(cn.first);
-        if (!n) continue;
-        Node* par = n->parent ? n->parent : n;
-        const size_t num_samples = cn.second.size();
-        if (num_samples > 1 && !n->mutations.empty()) {
-            all_nodes.erase(n->identifier);
-            n->identifier = new_internal_node_id();
-            all_nodes[n->identifier] = n;
-            for (size_t s = 0; s < num_samples; s++) create_node(cn.second[s], n, -1.0f);
-        } else if (num_samples > 1) {
-            all_nodes.erase(n->identifier);
-            n->identifier = cn.second[0];
-            all_nodes[n->identifier] = n;
-            for (size_t s = 1; s < num_samples; s++) create_node(cn.second[s], par, n->branch_length);
-        } else if (num_samples == 1) {
-            all_nodes.erase(n->identifier);
-            n->identifier = cn.second[0];
-            all_nodes[n->identifier] = n;
-        }
+    auto rename = [&](Node* n, std::string id) {
+        all_nodes.erase(n->identifier);
+        n->identifier = std::move(id);
+        all_nodes[n->identifier] = n;
+    };
+    for (auto& entry : condensed_nodes) {
+        const std::vector<std::string>& samples = entry.second;
+        Node* n = get_node(entry.first);
+        if (!n || samples.empty()) continue;
+        // A condensed leaf that carries mutations of its own stays as an internal node above all of its
+        // samples; one without mutations turns into its first sample and the others become its siblings
+        // (children of the root itself when the condensed node is the root).
+        const bool stays_internal = samples.size() > 1 && !n->mutations.empty();
+        Node* attach_to = stays_internal ? n : (n->parent ? n->parent : n);
+        const float branch = stays_internal ? -1.0f : n->branch_length;
+        rename(n, stays_internal ? new_internal_node_id() : samples.front());
+        for (size_t k = stays_internal ? 0 : 1; k < samples.size(); k++) create_node(samples[k], attach_to, branch);
     }
     condensed_nodes.clear();
     condensed_leaves.clear();
@@ -334,6 +334,9 @@ Tree load_mutation_annotated_tree(std::string const& filename) {
             m.chrom = pm.chrom;
             m.position = pm.position;
             if (!m.is_masked()) {
+                if (pm.ref_nuc < 0 || pm.ref_nuc > 3 || pm.par_nuc < 0 || pm.par_nuc > 3)
+                    throw mat_error("ERROR: corrupt mutation-annotated tree: nucleotide index outside 0..3 at position " +
+                                    std::to_string(pm.position));
                 m.ref_nuc = (int8_t)(1 << pm.ref_nuc);
                 m.par_nuc = (int8_t)(1 << pm.par_nuc);
                 m.mut_nuc = get_nuc_id(pm.mut_nuc);

@@ -38,3 +38,13 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
                         std::vector<usher_place_result>* results = nullptr, int device = 0,
                         bool sort_before_placement_1 = false, bool sort_before_placement_2 = false,
                         bool sort_before_placement_3 = false, bool reverse_sort = false);
+// The same over several GPUs of one node: one host thread and one handle per entry of `devices`
+// (HIP device indices; an index may repeat), device g placing the contiguous range of samples
+// [R*g/G, R*(g+1)/G) -- the per-sample work of usher_common.cpp:386-446 is independent between
+// samples, so the ranges never exchange anything and the rows are written in the usual order.
+int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t max_parsimony,
+                        bool print_parsimony_scores, std::vector<Missing_Sample>& missing_samples,
+                        std::vector<std::string>& low_confidence_samples, MAT::Tree* T,
+                        const std::vector<int>& devices, std::vector<usher_place_result>* results = nullptr,
+                        bool sort_before_placement_1 = false, bool sort_before_placement_2 = false,
+                        bool sort_before_placement_3 = false, bool reverse_sort = false);

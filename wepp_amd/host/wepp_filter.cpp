@@ -5,7 +5,7 @@
 #include <cctype>
 #include <cstdio>
 #include <fstream>
-#include <queue>
+#include <iterator>
 #include <sstream>
 
 #include "../../include/wepp_place.h"
@@ -127,41 +127,58 @@ void mask_reads(std::vector<raw_read>& reads, std::vector<int> const& masked_sit
 }
 
 std::unordered_set<int> site_read_map(std::vector<raw_read> const& reads, std::vector<int> const& masked_sites) {
-    std::unordered_set<int> ret, mask(masked_sites.begin(), masked_sites.end());
-    for (auto const& rp : reads) {
-        std::unordered_set<int> ambiguous;
-        for (auto const& mut : rp.mutations)
-            if (mut.mut_nuc == 0b1111) ambiguous.insert(mut.position);
-        for (int j = rp.start; j <= rp.end; j++)
-            if (!ambiguous.count(j) && !mask.count(j)) ret.insert(j);
+    // A site is covered when some read spans it with a base other than N, and it is not masked:
+    // (reads spanning j) - (reads with an N at j) > 0.  Both counts come from one pass over the reads
+    // (a difference array over the genome for the spans), not from a walk over every base of every read.
+    int last = 0;
+    for (auto const& rd : reads) last = std::max(last, rd.end);
+    std::vector<int32_t> span((size_t)last + 2, 0), n_at((size_t)last + 2, 0);
+    for (auto const& rd : reads) {
+        if (rd.end < rd.start) continue;
+        const int lo = std::max(rd.start, 0);
+        span[(size_t)lo] += 1;
+        span[(size_t)rd.end + 1] -= 1;
+        for (auto const& mut : rd.mutations)
+            if (mut.mut_nuc == 0b1111 && mut.position >= lo && mut.position <= rd.end) n_at[(size_t)mut.position] += 1;
     }
-    return ret;
+    std::vector<char> masked((size_t)last + 2, 0);
+    for (int site : masked_sites)
+        if (site >= 0 && site <= last) masked[(size_t)site] = 1;
+    std::unordered_set<int> covered;
+    int32_t open_reads = 0;
+    for (int j = 0; j <= last; j++) {
+        open_reads += span[(size_t)j];
+        if (open_reads - n_at[(size_t)j] > 0 && !masked[(size_t)j]) covered.insert(j);
+    }
+    return covered;
 }
 
 MAT::Tree create_condensed_tree(MAT::Node* ref_root, const std::unordered_set<int>& site_read_map,
                                 std::unordered_map<MAT::Node*, std::vector<MAT::Node*>>& node_mappings) {
-    std::queue<std::pair<MAT::Node*, MAT::Node*>> remaining_nodes;
+    // Breadth-first order of the original tree; rep[k] = the condensed node that stands for original
+    // node k: a new node when k keeps a mutation at a covered site (the root always), else the
+    // representative of its parent.  Parents precede children in this order, and the children of a
+    // condensed node are created in the order their originals appear in it -- which is what fixes the
+    // pre-order (arena) index of every haplotype.
     MAT::Tree T;
-    auto new_root = T.create_node(ref_root->identifier, -1.0f);
-    for (const auto& mut : ref_root->mutations)
-        if (site_read_map.count(mut.position)) new_root->mutations.emplace_back(mut);
-    node_mappings[new_root] = {ref_root};
-    for (auto child : ref_root->children) remaining_nodes.push({child, new_root});
-    while (!remaining_nodes.empty()) {
-        auto r_curr_node = remaining_nodes.front().first;
-        auto n_parent_node = remaining_nodes.front().second;
-        remaining_nodes.pop();
-        std::vector<MAT::Mutation> covered;
-        for (const auto& mut : r_curr_node->mutations)
-            if (site_read_map.count(mut.position)) covered.emplace_back(mut);
-        if (!covered.empty()) {                            // :110-121
-            auto new_node = T.create_node(r_curr_node->identifier, n_parent_node, -1.0f);
-            new_node->mutations = std::move(covered);
-            node_mappings[new_node] = {r_curr_node};
-            for (auto child : r_curr_node->children) remaining_nodes.push({child, new_node});
-        } else {                                           // :123-129
-            node_mappings[n_parent_node].emplace_back(r_curr_node);
-            for (auto child : r_curr_node->children) remaining_nodes.push({child, n_parent_node});
+    std::vector<MAT::Node*> order{ref_root};
+    std::vector<size_t> parent_slot{0};
+    for (size_t head = 0; head < order.size(); head++)
+        for (MAT::Node* c : order[head]->children) { order.push_back(c); parent_slot.push_back(head); }
+    std::vector<MAT::Node*> rep(order.size(), nullptr);
+    for (size_t k = 0; k < order.size(); k++) {
+        MAT::Node* orig = order[k];
+        std::vector<MAT::Mutation> kept;
+        std::copy_if(orig->mutations.begin(), orig->mutations.end(), std::back_inserter(kept),
+                     [&](const MAT::Mutation& m) { return site_read_map.count(m.position) != 0; });
+        if (k == 0 || !kept.empty()) {
+            rep[k] = k == 0 ? T.create_node(orig->identifier, -1.0f)
+                            : T.create_node(orig->identifier, rep[parent_slot[k]], -1.0f);
+            rep[k]->mutations = std::move(kept);
+            node_mappings[rep[k]] = {orig};
+        } else {
+            rep[k] = rep[parent_slot[k]];
+            node_mappings[rep[k]].push_back(orig);
         }
     }
     return T;
@@ -213,13 +230,22 @@ int cartesian_map(MAT::Tree& condensed, const std::vector<raw_read>& reads, size
     }
     wepp_epp_reads in{(uint32_t)R, off.data(), words.data(), start.data(), end.data(), degree.data()};
     std::vector<int32_t> pars(R), counts(N * NUM_RANGE_BINS);
-    std::vector<uint32_t> mult(R), epp(std::max<size_t>(R, 1) * MAX_CACHED_EPP_SIZE), order(N);
+    std::vector<uint32_t> mult(R), epp, order(N);
     std::vector<uint64_t> epp_off(R + 1);
     out.score.assign(N, 0.0);
     out.dist_divergence.assign(N, 0.0);
-    wepp_epp_out o{pars.data(), mult.data(), epp_off.data(), epp.data(), epp.size(), out.score.data(), counts.data(),
-                   out.dist_divergence.data()};
-    int rc = wepp_epp_map(mat, &in, (uint32_t)genome_size, MAX_CACHED_EPP_SIZE, &o);
+    // The EPP lists hold what the reads' multiplicities add up to, at most MAX_CACHED_EPP_SIZE each: sized
+    // from a typical guess first, then -- wepp_epp_map reports the needed total with WEPP_ELIMIT -- exactly
+    // (the worst case, R * 2048 entries, is 8 GiB per million reads).
+    epp.resize(std::max<size_t>(R, 1) * 16);
+    int rc = WEPP_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        wepp_epp_out o{pars.data(), mult.data(), epp_off.data(), epp.data(), epp.size(), out.score.data(), counts.data(),
+                       out.dist_divergence.data()};
+        rc = wepp_epp_map(mat, &in, (uint32_t)genome_size, MAX_CACHED_EPP_SIZE, &o);
+        if (rc != WEPP_ELIMIT || attempt == 1 || epp_off[R] <= epp.size()) break;
+        epp.assign((size_t)epp_off[R], 0);
+    }
     if (rc == WEPP_OK) rc = wepp_mat_dfs_order(mat, order.data());
     if (rc != WEPP_OK) {
         fprintf(stderr, "ERROR: %s\n", wepp_last_error());

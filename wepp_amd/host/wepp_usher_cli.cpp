@@ -12,12 +12,15 @@
 
 static void usage() {
     fprintf(stderr, "usage: wepp-usher -i <mat.pb[.gz]> -v <samples.vcf[.gz]> [-d <outdir>] [-p] [-e max_uncertainty] "
-                    "[-E max_parsimony] [-s|-S|-A] [-r] [--device N] [--dump]\n");
+                    "[-E max_parsimony] [-s|-S|-A] [-r] [--device N | --devices 0,1,...] [--dump]\n"
+                    "       -n/--no-add is required: samples are placed on the tree as given, never added to it\n");
 }
 
 int main(int argc, char** argv) {
     std::string pb, vcf, outdir = ".";
     bool print_scores = false, dump = false, sort1 = false, sort2 = false, sort3 = false, reverse_sort = false;
+    bool no_add = false;
+    std::vector<int> devices;
     uint32_t max_uncertainty = 1000000, max_parsimony = 1000000;   // usher.cpp:77-80 defaults
     int device = 0;
     for (int i = 1; i < argc; i++) {
@@ -29,12 +32,17 @@ int main(int argc, char** argv) {
         else if (a == "-p" || a == "--write-parsimony-scores-per-node") print_scores = true;
         else if (a == "-e" || a == "--max-uncertainty-per-sample") max_uncertainty = (uint32_t)atoi(next());
         else if (a == "-E" || a == "--max-parsimony-per-sample") max_parsimony = (uint32_t)atoi(next());
-        else if (a == "-n" || a == "--no-add") {}
+        else if (a == "-n" || a == "--no-add") no_add = true;
         else if (a == "-s" || a == "--sort-before-placement-1") sort1 = true;
         else if (a == "-S" || a == "--sort-before-placement-2") sort2 = true;
         else if (a == "-A" || a == "--sort-before-placement-3") sort3 = true;
         else if (a == "-r" || a == "--reverse-sort") reverse_sort = true;
         else if (a == "--device") device = atoi(next());
+        else if (a == "--devices") {                              // one host thread + one handle per listed GPU
+            std::vector<std::string> ids;
+            MAT::string_split(next(), ',', ids);
+            for (auto& d : ids) devices.push_back(atoi(d.c_str()));
+        }
         else if (a == "--dump") dump = true;
         else { usage(); return 1; }
     }
@@ -59,12 +67,19 @@ int main(int argc, char** argv) {
             return 0;
         }
         std::vector<std::string> low_conf;
+        if (!no_add) {
+            // reference usher without -n adds every placed sample to the tree (usher_common.cpp:649-762), so later
+            // placements depend on earlier ones; that sequential mode is not implemented here
+            fprintf(stderr, "ERROR: wepp-usher places samples on a fixed tree only; pass -n/--no-add (adding samples to the tree, usher's default, is not implemented).\n");
+            return 1;
+        }
         if (sort1 && sort2) {
             fprintf(stderr, "ERROR: Can't use sort-before-placement-1 and sort-before-placement-2 simultaneously. Please specify only one.\n");
             return 1;                                               // usher_common.cpp:14-71 style validation
         }
+        if (devices.empty()) devices.push_back(device);
         return usher_place_samples(outdir, max_uncertainty, max_parsimony, print_scores, missing_samples, low_conf, &T,
-                                   nullptr, device, sort1, sort2, sort3, reverse_sort);
+                                   devices, nullptr, sort1, sort2, sort3, reverse_sort);
     } catch (const std::exception& e) {
         fprintf(stderr, "%s\n", e.what());
         return 1;
