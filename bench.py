@@ -27,6 +27,21 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 (per XCD 4 MiB) ~34.5 TB/s aggregate
+N_CUS = 256            # MI355X_MICROARCH.md chip-level parameters
+MAX_CLOCK_GHZ = 2.4    # max clock; a CU issues at most one vector instruction per cycle (4 SIMDs, one per 4 cycles)
+VALU_ISSUE_PEAK = N_CUS * MAX_CLOCK_GHZ   # G wave-instructions / s
+KERNEL_SOURCES = ("place_kernels.hip", "device_mat.hpp", "flatmat.hpp", "flatmat.cpp", "capi.cpp", "sort_reads.hip")
+
+
+def kernel_hash():
+    """Identifies the build of the placement kernels a profile belongs to: bench.py refuses to quote
+    counters (roofline.traffic, instruction counts) measured on other code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "wepp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -46,6 +61,13 @@ def parse():
                     help="extra untimed-for-value steps with work skipping off (whole-tree streaming roofline)")
     ap.add_argument("--no-crowns", action="store_true",
                     help="disable work skipping: every read sweeps the whole-tree stream (roofline run)")
+    ap.add_argument("--pcie-steps", type=int, default=5,
+                    help="timed steps of the host-buffer leg (wepp_place_batch: H2D of the reads and D2H of the "
+                         "results inside); 0 disables it")
+    ap.add_argument("--no-sensitivity", action="store_true",
+                    help="skip the sensitivity ladder (reads/s against the N rate and the entries per read)")
+    ap.add_argument("--p-n", type=float, default=None, help="per-base N rate of the synthetic reads (default 0.005 "
+                    "for 150 bp reads, SURVEY 8(d) config 2/3; 0.02 for long reads, config 5)")
     return ap.parse_args()
 
 
@@ -100,16 +122,83 @@ def cpu_baseline(tree, reads, gpu_res, target_s):
     }
 
 
-def pmc_traffic(mode):
-    """HBM-side bytes per step of k_sweep from the committed rocprofv3 PMC profile of
-    this same command (profiles/pmc_traffic.json, written by tools/summarize_profile.py);
-    None when no profile is committed."""
+def pmc_profile(mode):
+    """Counters per step of k_sweep from the committed rocprofv3 --pmc profile of THIS workload
+    (`mode`: short_reads / whole_tree / long_reads) and THIS build of the kernels
+    (profiles/pmc_counters.json, written by tools/summarize_profile.py from tools/profile.sh runs):
+    HBM-side bytes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE,
+    x 1024) and vector / scalar instruction counts.  None unless the profile's kernel hash is the hash
+    of the sources this process was built from."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as fh:
             t = json.load(fh)[mode]
-        return t["traffic_bytes_per_step"]
     except (OSError, KeyError, ValueError):
         return None
+    if t.get("kernel_hash") != kernel_hash():
+        return None
+    return t
+
+
+def sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch):
+    """The two roofline objects of one measurement: the binding one (vector instruction issue: the
+    streams are shared by all tiles and served by the L2s) and the HBM one."""
+    prof = pmc_profile(mode)
+    secs = sweep_ms * 1e-3
+    alg = alg_bytes / secs / 1e9
+    issue = {"bound": "valu_issue", "kernel": "k_sweep", "peak": VALU_ISSUE_PEAK, "unit": "G wave-instructions/s",
+             "peak_note": "256 CUs x one vector instruction per cycle (4 SIMDs, one wave-instruction per 4 cycles each) "
+                          "x 2.4 GHz max clock; the clock the chip really holds under load is lower, so frac is a lower bound",
+             "kernel_ms_per_step": sweep_ms, "steps_timed": n_launch}
+    hbm = {"bound": "hbm", "kernel": "k_sweep", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg / HBM_PEAK_GBS,
+           "achieved_note": "ALGORITHMIC bytes (every tile of 64 reads sweeps its stream once; DESIGN.md 4.1) over the "
+                            "live kernel time.  The streams are shared between tiles and served by the L2s: this is "
+                            "not the HBM traffic (see traffic / traffic_gbs) and frac is not an HBM efficiency",
+           "algorithmic_bytes_per_step": alg_bytes, "stream_sweeps_per_step": passes, "kernel_ms_per_step": sweep_ms}
+    if prof is None:
+        issue.update({"achieved": None, "frac": None, "traffic": None,
+                      "provenance": "no rocprofv3 --pmc profile of this workload for this build of the kernels is committed "
+                                    "(profiles/pmc_counters.json, tools/profile.sh)"})
+        hbm.update({"traffic": None, "traffic_gbs": None, "traffic_frac": None})
+        return issue, hbm
+    a = prof["valu_insts_per_step"] / secs / 1e9
+    issue.update({"achieved": a, "frac": a / VALU_ISSUE_PEAK, "traffic": prof["traffic_bytes_per_step"],
+                  "valu_insts_per_step": prof["valu_insts_per_step"], "salu_insts_per_step": prof.get("salu_insts_per_step"),
+                  "salu_frac": (prof["salu_insts_per_step"] / secs / 1e9 / VALU_ISSUE_PEAK) if prof.get("salu_insts_per_step") else None,
+                  "provenance": f"SQ_INSTS_VALU / SQ_INSTS_SALU per step from {prof['profile']} (rocprofv3 --pmc run of this "
+                                f"workload, kernel hash {prof['kernel_hash']}); duration measured live with HIP events; "
+                                f"profiled kernel time {prof.get('kernel_ms_per_step_trace')} ms per step"})
+    hbm.update({"traffic": prof["traffic_bytes_per_step"], "traffic_gbs": prof["traffic_bytes_per_step"] / secs / 1e9,
+                "traffic_frac": prof["traffic_bytes_per_step"] / secs / 1e9 / HBM_PEAK_GBS,
+                "traffic_note": "bytes per step leaving the L2s, (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes; "
+                                "Infinity-Cache hits are counted, so true HBM traffic is lower still"})
+    return issue, hbm
+
+
+class DeviceBatch:
+    """A batch of reads resident in HBM plus its result buffers."""
+
+    def __init__(self, torch, reads, dev):
+        self.reads = reads
+        self.R = reads.n_reads
+        self.nw = int(reads.read_off[-1])
+        self.d_off = torch.from_numpy(reads.read_off.astype(np.int32)).to(dev)
+        self.d_word = torch.from_numpy((reads.read_word if self.nw else np.zeros(1, np.uint32)).astype(np.int32)).to(dev)
+        self.out = [torch.zeros(self.R, dtype=torch.int32, device=dev) for _ in range(4)]   # best, score, num_best, flags
+
+    def place(self, mat, stream):
+        mat.place_batch_device(self.d_off.data_ptr(), self.d_word.data_ptr(), self.R, self.nw, self.out[0].data_ptr(),
+                               self.out[1].data_ptr(), self.out[2].data_ptr(), self.out[3].data_ptr(), stream)
+
+
+def truncate_reads(w, reads, k):
+    """The reads of `reads` that list at least k positions, cut to their first k entries."""
+    cnt = np.diff(reads.read_off.astype(np.int64))
+    sel = np.nonzero(cnt >= k)[0]
+    if k == 0:
+        return w.Reads(np.zeros(reads.n_reads + 1, np.uint32), np.zeros(0, np.uint32))
+    idx = (reads.read_off[sel].astype(np.int64)[:, None] + np.arange(k)[None, :]).ravel()
+    return w.Reads((np.arange(len(sel) + 1) * k).astype(np.uint32), reads.read_word[idx])
 
 
 def main():
@@ -134,12 +223,18 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- synthetic workload (identical tree on every rank, per-rank reads) ----
+    long_reads = args.read_len > 400
     t0 = time.perf_counter()
     g = w.generate_tree(21, args.nodes)
-    amp_len, amp_step = (400, 300) if args.read_len <= 400 else (args.read_len, int(args.read_len * 0.85))
-    reads = g.reads(22 + rank, args.reads, read_len=args.read_len, amplicon_len=amp_len, amplicon_step=amp_step,
-                    p_substitution=0.001 if args.read_len <= 400 else 0.03,
-                    p_n=0.005 if args.read_len <= 400 else 0.02)
+    amp_len, amp_step = (args.read_len, int(args.read_len * 0.85)) if long_reads else (400, 300)
+    p_sub = 0.03 if long_reads else 0.001
+    p_n = args.p_n if args.p_n is not None else (0.02 if long_reads else 0.005)
+
+    def gen_reads(seed, n, pn=p_n):
+        return g.reads(seed, n, read_len=args.read_len, amplicon_len=amp_len, amplicon_step=amp_step,
+                       p_substitution=p_sub, p_n=pn)
+
+    reads = gen_reads((24 if long_reads else 22) + rank, args.reads)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     mat = w.Mat(g.tree, device=local_rank)
@@ -147,20 +242,9 @@ def main():
     mat.set_use_crowns(not args.no_crowns)
     t_flat = time.perf_counter() - t0
     st = mat.stats
-
-    R = reads.n_reads
-    nw = int(reads.read_off[-1])
-    d_off = torch.from_numpy(reads.read_off.astype(np.int32)).to(dev)
-    d_word = torch.from_numpy((reads.read_word if nw else np.zeros(1, np.uint32)).astype(np.int32)).to(dev)
-    d_best = torch.zeros(R, dtype=torch.int32, device=dev)
-    d_score = torch.zeros(R, dtype=torch.int32, device=dev)
-    d_nbest = torch.zeros(R, dtype=torch.int32, device=dev)
-    d_flags = torch.zeros(R, dtype=torch.int32, device=dev)
+    batch = DeviceBatch(torch, reads, dev)
+    R, nw = batch.R, batch.nw
     stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        mat.place_batch_device(d_off.data_ptr(), d_word.data_ptr(), R, nw, d_best.data_ptr(), d_score.data_ptr(),
-                               d_nbest.data_ptr(), d_flags.data_ptr(), stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -168,46 +252,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # ---- the timed region: K steps, inputs resident in HBM ----------------------------------
     for _ in range(args.warmup):
-        step()
+        batch.place(mat, stream)
     fence()
     mat.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        batch.place(mat, stream)
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     sweep_ms, n_launch, passes, alg_bytes = mat.last_timing()
+    tiers = mat.last_tiers(R)
+    ref_out = [t.clone() for t in batch.out]
+
+    # ---- SURVEY 8(d)'s metric as defined: wall clock of wepp_place_batch with HOST buffers (validation of the
+    # read words, H2D of the reads, kernels, D2H of the results inside) -----------------------
+    pcie = None
+    if args.pcie_steps > 0:
+        hres = mat.place_batch(reads)                 # grows the handle's staging buffers once
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.pcie_steps):
+            hres = mat.place_batch(reads, out=hres)
+        fence()
+        el = max_over_ranks(time.perf_counter() - t0)
+        same = bool((hres.score == ref_out[1].cpu().numpy()).all() and
+                    (hres.best_bfs_j == ref_out[0].cpu().numpy().view(np.uint32)).all())
+        pcie = {"value": R * world * args.pcie_steps / el, "ms_per_step": el / args.pcie_steps * 1e3,
+                "steps": args.pcie_steps, "bytes_in_per_step": 4 * (R + 1) + 4 * nw, "bytes_out_per_step": 16 * R,
+                "results_identical_to_timed_run": same}
 
     # ---- the "HBM-roofline run" of configs[2]: same batch, work skipping off, so that
     # every tile streams the whole-tree event stream once (not part of `value`) ----
     whole = None
     if not args.no_crowns and args.roofline_steps > 0:
-        ref_out = [t.clone() for t in (d_best, d_score, d_nbest, d_flags)]
         mat.set_use_crowns(False)
-        step()
+        batch.place(mat, stream)
         fence()
         mat.timing_reset()
         for _ in range(args.roofline_steps):
-            step()
+            batch.place(mat, stream)
         fence()
         w_ms, w_n, w_passes, w_bytes = mat.last_timing()
-        same = all(bool((a == b).all()) for a, b in zip(ref_out, (d_best, d_score, d_nbest, d_flags)))
+        same = all(bool((a == b).all()) for a, b in zip(ref_out, batch.out))
         mat.set_use_crowns(True)
         whole = {"kernel_ms_per_step": w_ms, "steps_timed": w_n, "stream_sweeps_per_step": w_passes,
                  "algorithmic_bytes_per_step": w_bytes, "results_identical_to_timed_run": same}
 
+    # ---- sensitivity: how much of `value` is the generator's choice of |S| (rank 0 only) --------
+    sens = None
+    if rank == 0 and world == 1 and not args.no_sensitivity and not args.no_crowns:
+        sens = []
+
+        def leg(label, rd, steps=3):
+            if rd.n_reads == 0:
+                return
+            b = DeviceBatch(torch, rd, dev)
+            b.place(mat, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b.place(mat, stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            tr = mat.last_tiers(rd.n_reads)
+            sens.append({"reads": label, "n_reads": rd.n_reads, "mean_entries": b.nw / rd.n_reads,
+                         "reads_per_s": rd.n_reads / dt, "ms_per_step": dt * 1e3,
+                         "share_on_whole_tree_stream": float((tr == st.n_streams - 1).mean()),
+                         "median_stream_nodes": int(st.stream_nodes[int(np.median(tr))])})
+
+        n_s = min(R, 1_000_000)
+        for pn in ((0.005, 0.02, 0.05) if not long_reads else (0.02, 0.05)):
+            leg(f"p_n = {pn}", gen_reads(122, n_s, pn))
+        if not long_reads:
+            pool = gen_reads(123, n_s, 0.06)     # mean ~9 entries: a pool with enough long lists to cut from
+            for k in (0, 1, 2, 4, 8):
+                leg(f"exactly {k} entries", truncate_reads(w, pool, k))
+
     if rank == 0:
-        gpu_res = {"score": d_score.cpu().numpy(), "best": d_best.cpu().numpy().view(np.uint32),
-                   "num_best": d_nbest.cpu().numpy().view(np.uint32), "flags": d_flags.cpu().numpy().view(np.uint32)}
+        gpu_res = {"score": ref_out[1].cpu().numpy(), "best": ref_out[0].cpu().numpy().view(np.uint32),
+                   "num_best": ref_out[2].cpu().numpy().view(np.uint32), "flags": ref_out[3].cpu().numpy().view(np.uint32)}
         total_reads = R * world * args.steps
         value = total_reads / elapsed
-        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+        mode = "long_reads" if long_reads else ("whole_tree" if args.no_crowns else "short_reads")
+        issue, hbm = sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch)
+        shape = (f"{R} synthetic midnight-amplicon-like {args.read_len} bp reads per GPU per step (3 % substitutions, "
+                 f"N rate {p_n}; seed 24+rank); BASELINE.json configs[4] shape on one GPU" if long_reads else
+                 f"{R} synthetic ARTIC-like {args.read_len} bp reads per GPU per step (0.1 % substitutions, N rate {p_n}; "
+                 f"seed 22+rank); BASELINE.json configs[2]")
+        counts = np.bincount(tiers, minlength=st.n_streams)
         out = {
             "metric": "reads placed/sec on SARS-CoV-2 MAT (~16M nodes)",
             "value": value,
@@ -221,10 +362,14 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
+            "value_note": "inputs and outputs resident in HBM (wepp_place_batch_device); value_pcie_inclusive is SURVEY 8(d)'s "
+                          "wall clock of wepp_place_batch with host buffers.  Both are a best case of the synthetic "
+                          "generator (reads of reference-like genotypes with ~1 entry): see `sensitivity`",
+            "value_pcie_inclusive": pcie["value"] if pcie else None,
+            "pcie_inclusive": pcie,
             "config": {
                 "workload": f"synthetic SARS-CoV-2-like MAT N={st.n_nodes} nodes M={st.n_mutations} mutations "
-                            f"(seed 21, L=29903), {R} synthetic ARTIC-like {args.read_len} bp reads per GPU per step "
-                            f"(seed 22+rank); BASELINE.json configs[2]",
+                            f"(seed 21, L=29903), {shape}",
                 "reads_per_gpu": R,
                 "read_words_per_gpu": nw,
                 "tile_reads_T": args.tile,
@@ -234,40 +379,25 @@ def main():
                         "blocks": int(st.n_blocks), "leaves": int(st.n_leaves), "max_depth": int(st.max_depth),
                         "device_bytes": int(st.device_bytes)},
                 "setup_s": {"generate": round(t_gen, 1), "flatten_upload": round(t_flat, 1)},
+                "kernel_hash": kernel_hash(),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_sweep",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("work_skipping_off" if args.no_crowns else "work_skipping_on"),
-                "traffic_note": "bytes per step leaving the L2s, (2*FETCH_SIZE+WRITE_SIZE)*1024 from a separate "
-                                "rocprofv3 --pmc run of this command (profiles/); Infinity-Cache hits included",
-                "algorithmic_bytes_per_step": alg_bytes,
-                "stream_sweeps_per_step": passes,
-                "kernel_ms_per_step": sweep_ms,
-                "steps_timed": n_launch,
-                "whole_tree_stream_bytes": int(st.stream_bytes),
-                "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]),
-                             "bytes": int(st.stream_bytes_of[i])} for i in range(st.n_streams)],
-            },
+            "roofline": issue,
+            "roofline_hbm": hbm,
+            "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]), "bytes": int(st.stream_bytes_of[i]),
+                         "reads_routed": int(counts[i])} for i in range(st.n_streams)],
         }
         if whole is not None:
-            a = whole["algorithmic_bytes_per_step"] / (whole["kernel_ms_per_step"] * 1e-3) / 1e9
+            wi, wh = sweep_roofline("whole_tree", whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],
+                                    whole["stream_sweeps_per_step"], whole["steps_timed"])
             out["roofline_whole_tree"] = {
                 "what": "same batch with work skipping off: every 64-read tile streams the whole-tree event "
-                        "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`.  `achieved` "
-                        "counts the bytes every tile sweeps (algorithmic); the stream is cut into ~1 MB chunks swept "
-                        "chunk-major, so most of them are served by the L2s (`traffic` = bytes leaving the L2s) and "
-                        "the kernel is vector-issue bound (DESIGN.md 4.1)",
-                "bound": "hbm", "kernel": "k_sweep", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic("work_skipping_off"),
-                # the same rate against what actually serves the bytes (MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate);
-                # frac can exceed 1 because the HBM peak is not the binding resource once the chunks are L2-resident
-                "served_from": "L2 (chunk-major 1 MB chunks)", "l2_peak": L2_PEAK_GBS, "frac_of_l2_peak": a / L2_PEAK_GBS,
-                "reads_per_s": R / (whole["kernel_ms_per_step"] * 1e-3), **whole}
+                        "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`",
+                "reads_per_s": R / (whole["kernel_ms_per_step"] * 1e-3),
+                "results_identical_to_timed_run": whole["results_identical_to_timed_run"],
+                "issue": wi, "hbm": wh,
+                "served_from": "L2 (chunk-major 1 MB chunks)", "l2_peak": L2_PEAK_GBS,
+                "algorithmic_frac_of_l2_peak": wh["achieved"] / L2_PEAK_GBS}
+        out["sensitivity"] = sens
         if world == 1 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(g.tree, reads, gpu_res, args.cpu_baseline_seconds)
         else:

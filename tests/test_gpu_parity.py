@@ -324,15 +324,64 @@ def test_device_pointer_entry_point(oracle):
     mat.close()
 
 
-def test_full_size_properties(oracle):
-    """BASELINE.json configs[2] size (16M nodes): properties that need no
-    oracle run over the whole batch, plus the oracle on a handful of reads.
-      - tile-size invariance (T=64 vs T=16), work skipping on/off, batch-permutation invariance,
-      - every score lies in [0, root placement score] and num_best >= 1."""
+def test_full_size_parity_and_properties(oracle):
+    """BASELINE.json configs[2] at full size -- 16 M nodes, the whole 1 M-read batch, work skipping on --
+    and configs[4]'s read shape on the same MAT.
+      1. the incremental CPU checker (oracle/incremental_oracle.c, proven equal to the faithful
+         restatement by tests/test_incremental.py) on >= 10 000 of the 150-bp reads, drawn so that EVERY
+         non-empty sweep stream (crown tier) is covered, and on >= 500 1.2-kb reads;
+      2. the faithful restatement of mapper2_body itself (node range split over the host threads, as the
+         reference's parallel_for does) on 2 reads of every non-empty tier and 4 of the long reads;
+      3. size-independent properties over the whole batch: tile-size invariance, work skipping on/off,
+         batch-permutation invariance, score bounds."""
+    nthr = os.cpu_count() or 1
     g = w.generate_tree(21, 16_000_000)
-    reads = g.reads(22, 200_000)
+    reads = g.reads(22, 1_000_000)
     mat = w.Mat(g.tree)
     res = mat.place_batch(reads)
+    tiers = mat.last_tiers(reads.n_reads)
+    ot = oracle.OracleTree(g.tree)
+    inc = ot.incremental()
+
+    def gather(idx):
+        lists_off = np.zeros(len(idx) + 1, np.uint32)
+        words = []
+        for i, q in enumerate(idx):
+            a, b = int(reads.read_off[q]), int(reads.read_off[q + 1])
+            words.append(reads.read_word[a:b])
+            lists_off[i + 1] = lists_off[i] + (b - a)
+        return Reads(lists_off, np.concatenate(words) if words else np.zeros(0, np.uint32))
+
+    def same(got, idx, want):
+        assert (got.score[idx] == want["score"]).all()
+        assert (got.best_bfs_j[idx] == want["best_j"]).all()
+        assert (got.num_best[idx] == want["num_best"]).all()
+        assert (got.has_unique[idx] == want["has_unique"]).all()
+
+    # 1. up to 900 reads of every non-empty tier, then the head of the batch up to 10 240 reads
+    present = [int(t) for t in np.unique(tiers)]
+    assert len(present) >= 6, present                      # the batch reaches many crown streams
+    pick = []
+    for t in present:
+        pick.extend(np.nonzero(tiers == t)[0][:900].tolist())
+    rest = np.setdiff1d(np.arange(20000), np.array(pick))
+    pick = np.array(sorted(set(pick) | set(rest[: max(0, 10240 - len(pick))].tolist())))
+    assert len(pick) >= 10000
+    same(res, pick, inc.place_batch(gather(pick), nthreads=nthr))
+    # 2. the faithful oracle: 2 reads per tier
+    few = np.array([q for t in present for q in np.nonzero(tiers == t)[0][:2].tolist()])
+    same(res, few, ot.place_batch(gather(few), nthr, node_parallel=True))
+
+    # configs[4] shape: 1.2 kb reads, ~58 entries each (dense sweep variant), same MAT
+    long_reads = g.reads(24, 600, read_len=1200, amplicon_len=1200, amplicon_step=1100, p_substitution=0.03, p_n=0.02)
+    rl = mat.place_batch(long_reads)
+    all_long = np.arange(long_reads.n_reads)
+    same(rl, all_long, inc.place_batch(long_reads, nthreads=nthr))
+    same(rl, np.arange(4), ot.place_batch(long_reads.slice(0, 4), nthr, node_parallel=True))
+    inc.close()
+    ot.close()
+
+    # 3. properties
     mat.set_tile_reads(16)
     sub = reads.slice(0, 20000)
     r16 = mat.place_batch(sub)
@@ -341,29 +390,53 @@ def test_full_size_properties(oracle):
     mat.set_tile_reads(64)
     mat.set_use_crowns(False)
     roff = mat.place_batch(sub)
+    assert (mat.last_tiers(sub.n_reads) == mat.stats.n_streams - 1).all()
     mat.set_use_crowns(True)
     assert (roff.score == res.score[:20000]).all() and (roff.best_bfs_j == res.best_bfs_j[:20000]).all()
     assert (roff.num_best == res.num_best[:20000]).all() and (roff.flags == res.flags[:20000]).all()
-    # permutation invariance
     rng = np.random.default_rng(0)
     perm = rng.permutation(20000)
-    lists = []
-    for q in perm:
-        p, rf, a, ms = sub.entries(int(q))
-        lists.append([(int(p[i]), int(rf[i]), int(a[i]), int(ms[i])) for i in range(len(p))])
-    rp = mat.place_batch(Reads.from_lists(lists))
+    rp = mat.place_batch(gather(perm))
     assert (rp.score == res.score[perm]).all() and (rp.best_bfs_j == res.best_bfs_j[perm]).all()
     assert (rp.num_best == res.num_best[perm]).all()
     # scores are bounded by the root placement: len(non-missing S) (root has no mutations here)
     cs = np.concatenate([[0], np.cumsum(((reads.read_word >> 28) & 1) == 0)])
     k_nm = cs[reads.read_off[1:].astype(np.int64)] - cs[reads.read_off[:-1].astype(np.int64)]
     assert (res.score <= k_nm).all() and (res.score >= 0).all() and (res.num_best >= 1).all()
-    # oracle on a few reads (node range split over all host threads)
-    few = reads.slice(0, 6)
-    want = oracle.OracleTree(g.tree).place_batch(few, os.cpu_count(), node_parallel=True)
-    assert (res.score[:6] == want["score"]).all() and (res.best_bfs_j[:6] == want["best_j"]).all()
-    assert (res.num_best[:6] == want["num_best"]).all() and (res.has_unique[:6] == want["has_unique"]).all()
     mat.close()
+
+
+def test_two_handles_two_host_threads(oracle):
+    """include/wepp_place.h: different handles may be used concurrently from different host threads.
+    Two handles on device 0, each placing its own contiguous shard of the batch from its own thread
+    (what the C++ multi-GPU driver does per device), several rounds; results against the oracle."""
+    import threading
+    g = w.generate_tree(31, 60_000, genome_len=5000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
+    reads = g.reads(32, 6000, p_substitution=0.004, p_n=0.01, p_iupac=0.1)
+    want = oracle.OracleTree(g.tree).incremental().place_batch(reads, nthreads=os.cpu_count() or 1)
+    mats = [w.Mat(g.tree), w.Mat(g.tree)]
+    shards = [reads.slice(0, 2500), reads.slice(2500, 6000)]
+    los = [0, 2500]
+    errs = []
+
+    def worker(k):
+        try:
+            for _ in range(6):
+                r = mats[k].place_batch(shards[k])
+                sl = slice(los[k], los[k] + shards[k].n_reads)
+                assert (r.score == want["score"][sl]).all() and (r.best_bfs_j == want["best_j"][sl]).all()
+                assert (r.num_best == want["num_best"][sl]).all() and (r.has_unique == want["has_unique"][sl]).all()
+        except BaseException as e:   # noqa: BLE001 (reported by the main thread)
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for m in mats:
+        m.close()
+    assert not errs, errs
 
 
 @pytest.mark.gpu

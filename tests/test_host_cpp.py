@@ -192,3 +192,48 @@ def test_wepp_usher_end_to_end(tmp_path, oracle):
                 assert b[5] == ",".join(f"{pbf.NUC.get(pa, 'N')}{p}{pbf.NUC.get(mu, 'N')}" for (p, _, pa, mu) in want), (q, k)
                 n_lists += 1
     assert n_lists > 40
+
+
+@pytest.mark.gpu
+def test_wepp_usher_devices_and_chunked_scores(tmp_path):
+    """The C++ multi-GPU driver (usher_place_samples with a device list: one host thread and one handle
+    per entry, contiguous sample ranges -- the per-sample loop of usher_common.cpp:386-446 sharded) with
+    `--devices 0,0` (two handles, two host threads, one GPU), and the -p mode cut into chunks of three
+    samples: every file byte-identical to the single-handle, single-chunk run.  Without -n the tool
+    refuses (it never adds samples to the tree)."""
+    rng = np.random.default_rng(101)
+    tree, ref = ft.random_tree(rng, n_nodes=400, genome=150, p_root_masked=0.0)
+    parent, muts = _tree_lists(tree)
+    names = _names(parent)
+    samples = [ft.random_sample(rng, ref, genome=150) for _ in range(53)]
+    snames = [f"s{i}" for i in range(53)]
+    pb, vcf = str(tmp_path / "t.pb"), str(tmp_path / "s.vcf")
+    pbf.write_pb(pb, parent, names, muts, compress=False)
+    pbf.write_vcf(vcf, snames, samples)
+
+    def run(name, *extra, env=None):
+        out = tmp_path / name
+        out.mkdir()
+        e = dict(os.environ)
+        e.update(env or {})
+        r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-d", str(out)] + list(extra), capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        return out, r.stderr
+
+    one, err1 = run("one")
+    two, err2 = run("two", "--devices", "0,0")
+    three, _ = run("three", "--devices", "0,0,0", "-S", "-r")
+    one_s, _ = run("one_s", "-S", "-r")
+    assert open(one / "placement_stats.tsv").read() == open(two / "placement_stats.tsv").read()
+    assert open(one_s / "placement_stats.tsv").read() == open(three / "placement_stats.tsv").read()
+    assert err1 == err2
+    p1, _ = run("p1", "-p")
+    p2, _ = run("p2", "-p", "--devices", "0,0", env={"WEPP_USHER_CHUNK_ROWS": "3"})
+    p3, _ = run("p3", "-p", "-s", env={"WEPP_USHER_CHUNK_ROWS": "7"})
+    p4, _ = run("p4", "-p", "-s", "--devices", "0,0,0")
+    a = open(p1 / "parsimony-scores.tsv").read()
+    assert len(a.splitlines()) == 1 + 53 * 400
+    assert a == open(p2 / "parsimony-scores.tsv").read()
+    assert open(p3 / "parsimony-scores.tsv").read() == open(p4 / "parsimony-scores.tsv").read()
+    r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-d", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "--no-add" in r.stderr

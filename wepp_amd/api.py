@@ -317,13 +317,17 @@ class Mat:
         """Work skipping on (default) / off; speed only, never results."""
         check(lib.wepp_mat_set_use_crowns(self._h, 1 if enable else 0))
 
-    def place_batch(self, reads, per_node_scores=False):
-        """Host buffers in/out: wepp_place_batch."""
+    def place_batch(self, reads, per_node_scores=False, out=None):
+        """Host buffers in/out: wepp_place_batch.  out = a PlacementResult of a previous call with the
+        same number of reads, to reuse its arrays."""
         n = reads.n_reads
-        bj = np.zeros(n, np.uint32)
-        sc = np.zeros(n, np.int32)
-        nb = np.zeros(n, np.uint32)
-        fl = np.zeros(n, np.uint32)
+        if out is not None and out.score.shape[0] == n:
+            bj, sc, nb, fl = out.best_bfs_j, out.score, out.num_best, out.flags
+        else:
+            bj = np.zeros(n, np.uint32)
+            sc = np.zeros(n, np.int32)
+            nb = np.zeros(n, np.uint32)
+            fl = np.zeros(n, np.uint32)
         pns = np.zeros((n, self.n_nodes), np.int32) if per_node_scores else None
         rw = reads.read_word if reads.read_word.size else np.zeros(1, np.uint32)
         check(lib.wepp_place_batch(self._h, _ptr(reads.read_off), _ptr(rw), n, _ptr(bj), _ptr(sc), _ptr(nb),
