@@ -61,6 +61,8 @@ def parse():
                     help="extra untimed-for-value steps with work skipping off (whole-tree streaming roofline)")
     ap.add_argument("--no-crowns", action="store_true",
                     help="disable work skipping: every read sweeps the whole-tree stream (roofline run)")
+    ap.add_argument("--no-walk", action="store_true",
+                    help="place every read by a sweep of its stream (no per-read walks of the position index)")
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="timed steps of the host-buffer leg (wepp_place_batch: H2D of the reads and D2H of the "
                          "results inside); 0 disables it")
@@ -240,6 +242,7 @@ def main():
     mat = w.Mat(g.tree, device=local_rank)
     mat.set_tile_reads(args.tile)
     mat.set_use_crowns(not args.no_crowns)
+    mat.set_use_walk(not args.no_walk)
     t_flat = time.perf_counter() - t0
     st = mat.stats
     batch = DeviceBatch(torch, reads, dev)
@@ -295,6 +298,7 @@ def main():
     whole = None
     if not args.no_crowns and args.roofline_steps > 0:
         mat.set_use_crowns(False)
+        mat.set_use_walk(False)
         batch.place(mat, stream)
         fence()
         mat.timing_reset()
@@ -304,6 +308,7 @@ def main():
         w_ms, w_n, w_passes, w_bytes = mat.last_timing()
         same = all(bool((a == b).all()) for a, b in zip(ref_out, batch.out))
         mat.set_use_crowns(True)
+        mat.set_use_walk(not args.no_walk)
         whole = {"kernel_ms_per_step": w_ms, "steps_timed": w_n, "stream_sweeps_per_step": w_passes,
                  "algorithmic_bytes_per_step": w_bytes, "results_identical_to_timed_run": same}
 

@@ -186,6 +186,11 @@ int wepp_mat_set_tile_reads(wepp_mat_t *mat, uint32_t reads_per_tile);
 /* Work skipping on (default) / off: when off every read sweeps the whole-tree
  * stream.  Affects speed only, never results. */
 int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
+/* Per-read walks on (default) / off: when on, a read that lists at most 16 positions visits only the
+ * events of those positions (position index + range queries over the stream) instead of sweeping the
+ * whole stream with 63 other reads; when off every read is placed by a sweep.  Affects speed only,
+ * never results. */
+int wepp_mat_set_use_walk(wepp_mat_t *mat, int enable);
 
 /* Timing of the dominant kernel (k_sweep), measured with HIP events recorded on
  * the launch stream around the sweep (+ the 10-80 us finalize) launches of every
@@ -193,9 +198,10 @@ int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
  * and joined into the launch stream -- since the
  * handle was created or wepp_mat_timing_reset() was called (the most recent 64
  * calls are kept).  Blocks until those launches have finished.
- * mean_sweep_ms = mean duration of the sweep launches of one call; passes =
- * event-stream sweeps of the last call (one per tile); algorithmic_bytes =
- * bytes those sweeps read (sum over tiles of their stream's size). */
+ * mean_sweep_ms = mean duration of the sweep / walk launches of one call; passes =
+ * event-stream sweeps of the last call (one per tile) plus the 64-read waves of its walks;
+ * algorithmic_bytes = bytes the sweeps read (sum over tiles of their stream's size) plus 26 bytes
+ * per loop iteration of the walks (index entry, node key and flags, two sparse-table bytes). */
 int wepp_mat_timing_reset(wepp_mat_t *mat);
 int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_calls, uint64_t *passes,
                          uint64_t *algorithmic_bytes);
@@ -204,6 +210,11 @@ int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_call
  * the handle's most recent placement call was routed to; n_reads must be that call's.
  * Synchronises the device.  Lets a test reach every stream with the oracle. */
 int wepp_mat_last_tiers(wepp_mat_t *mat, uint8_t *tiers, uint32_t n_reads);
+
+/* Diagnostic: reads of the handle's most recent placement call that walked their own events (k_walk;
+ * the others were placed by sweeps of their stream), and the loop iterations (one per event, interval end or
+ * range query) all walks of the handle ran since wepp_mat_timing_reset().  Synchronises the device. */
+int wepp_mat_last_walk(wepp_mat_t *mat, uint64_t *reads_walked, uint64_t *walk_iterations);
 
 const char *wepp_last_error(void);
 

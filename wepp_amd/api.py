@@ -203,7 +203,7 @@ class GenTree:
 class FlatView:
     """Host-only view of the flattened MAT (wepp_flat_*), for the CPU tests."""
 
-    _DT = {"nkey": np.int64, "ev_meta": np.uint8, "ev_lb": np.uint8}
+    _DT = {"nkey": np.int64, "ev_meta": np.uint8, "ev_lb": np.uint8, "sp": np.uint8, "maxnest": np.uint8}
 
     def __init__(self, tree):
         self._tree = tree
@@ -231,6 +231,9 @@ class FlatView:
         check(lib.wepp_flat_get(self._h, name.encode(), ctypes.byref(data), ctypes.byref(cnt), ctypes.byref(eb)))
         if cnt.value == 0:
             return np.zeros(0, np.uint32)
+        if base in ("rq_pre", "rq_suf", "rq_dst"):
+            raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 3,)).copy()
+            return raw.reshape(-1, 3)   # base, rank, cnt
         if base == "blk_sum":
             raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 8,)).copy()
             return raw.reshape(-1, 8)   # base, rank, cnt, min_all, node0, nn, pad, pad
@@ -316,6 +319,10 @@ class Mat:
     def set_use_crowns(self, enable):
         """Work skipping on (default) / off; speed only, never results."""
         check(lib.wepp_mat_set_use_crowns(self._h, 1 if enable else 0))
+
+    def set_use_walk(self, enable):
+        """Per-read walks on (default) / off (every read placed by a sweep); speed only, never results."""
+        check(lib.wepp_mat_set_use_walk(self._h, 1 if enable else 0))
 
     def place_batch(self, reads, per_node_scores=False, out=None):
         """Host buffers in/out: wepp_place_batch.  out = a PlacementResult of a previous call with the
@@ -414,6 +421,12 @@ class Mat:
         out = np.zeros(int(n_reads), np.uint8)
         check(lib.wepp_mat_last_tiers(self._h, _ptr(out), int(n_reads)))
         return out
+
+    def last_walk(self):
+        """(reads of the last call placed by the per-read walk, walk loop iterations since timing_reset)."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.wepp_mat_last_walk(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def timing_reset(self):
         check(lib.wepp_mat_timing_reset(self._h))

@@ -27,6 +27,8 @@ void release(wepp_mat* h) {
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->epp_ws) (void)hipFree(h->epp_ws);
     if (h->d_info) (void)hipFree(h->d_info);
+    if (h->d_work) (void)hipFree(h->d_work);
+    if (h->ws2) (void)hipFree(h->ws2);
     if (h->h_info) (void)hipHostFree(h->h_info);
     for (uint32_t i = 0; i < wepp_mat::kRing; i++) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
@@ -93,6 +95,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         UP(d.bfs2dfs, bfs2dfs)
     }
     UP(d.parent_dfs, f.parent_dfs)
+    UP(d.maxnest, f.maxnest)
     UP(h->epp_word, f.epp_word) UP(h->epp_node, f.epp_node)
     h->epp_events = f.epp_word.size();
     for (size_t i = 0; i < f.streams.size(); i++) {
@@ -120,13 +123,33 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
         }
         h->streams.push_back(ds);
         h->stream_bytes.push_back(st.stream_bytes());
+        {
+            DevWalk dw{};
+            dw.n = st.n;
+            dw.rq_blocks = st.rq_blocks;
+            dw.last_ent = (uint32_t)st.ix_node.size() - 1;
+            dw.nkey = ds.nkey;
+            dw.nstat = ds.nstat;
+            UP(dw.ix_off, st.ix_off) UP(dw.ix_node, st.ix_node) UP(dw.ix_end, st.ix_end) UP(dw.ix_word, st.ix_word)
+            UP(dw.ix_up, st.ix_up)
+            UP(dw.rq_pre, st.rq_pre) UP(dw.rq_suf, st.rq_suf) UP(dw.rq_dst, st.rq_dst) UP(dw.sp, st.sp)
+            h->walks.push_back(dw);
+        }
         d.tau[i] = st.tau;
         h->stats.stream_tau[i] = st.tau;
         h->stats.stream_nodes[i] = st.n;
         h->stats.stream_bytes_of[i] = st.stream_bytes();
     }
+    UP(d.walks, h->walks)
 #undef UP
-    e = hipMalloc((void**)&h->d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_STREAMS) * sizeof(uint32_t));
+    {
+        static const bool walk_on = !(getenv("WEPP_WALK") && getenv("WEPP_WALK")[0] == '0');
+        h->use_walk = walk_on ? 1 : 0;
+    }
+    e = hipMalloc((void**)&h->d_work, WALK_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_work, 0, WALK_COUNTERS * sizeof(unsigned long long));
+    if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
+    e = hipMalloc((void**)&h->d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_PLANS) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(h->d_info, 0, 2 * TI_WORDS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_info, TI_WORDS * sizeof(uint32_t), hipHostMallocDefault);
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
@@ -174,6 +197,12 @@ extern "C" int wepp_mat_set_use_crowns(wepp_mat_t* mat, int enable) {
     return WEPP_OK;
 }
 
+extern "C" int wepp_mat_set_use_walk(wepp_mat_t* mat, int enable) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    mat->use_walk = enable ? 1 : 0;
+    return WEPP_OK;
+}
+
 extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word,
                                        uint32_t n_reads, uint64_t n_read_words, uint32_t* d_best_bfs_j,
                                        int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags,
@@ -207,7 +236,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     if (sort_reads) HIP_TRY(sort_reads_temp_bytes(n_reads, &sort_temp));
     sort_temp = (sort_temp + 255) & ~(size_t)255;
     // fixed part of the workspace: tier | list | root_score | slot in block | sort keys in/out | sort values | sort temp
-    const size_t fixed_bytes = tier_bytes + 3 * list_bytes + (sort_reads ? 3 * list_bytes + sort_temp : 0);
+    const size_t fixed_bytes = tier_bytes + 4 * list_bytes + (sort_reads ? 3 * list_bytes + sort_temp : 0);
     {
         // before routing only the fixed regions are needed; reserve a typical partial size too
         int rc = grow(fixed_bytes + (size_t)n_reads * 12 * 2);
@@ -215,6 +244,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     }
     uint8_t* tier_of = nullptr;
     uint32_t *list = nullptr, *slot_in_blk = nullptr, *key_in = nullptr, *key_out = nullptr, *val_in = nullptr;
+    uint32_t* job_n = nullptr;       // jobs of every read whose walk is cut into chunks (k_route)
     int32_t* root_score = nullptr;
     void* sort_tmp = nullptr;
     auto carve = [&]() {
@@ -223,6 +253,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         list = (uint32_t*)p; p += list_bytes;
         root_score = (int32_t*)p; p += list_bytes;
         slot_in_blk = (uint32_t*)p; p += list_bytes;
+        job_n = (uint32_t*)p; p += list_bytes;
         if (sort_reads) {
             key_in = (uint32_t*)p; p += list_bytes;
             key_out = (uint32_t*)p; p += list_bytes;
@@ -234,13 +265,14 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
     uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
 
+    static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
         tier_info = mat->d_info + mat->info_idx * TI_WORDS;
         uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
-        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, tier_of, root_score, blk_counts,
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, stream));
         mat->info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
@@ -264,21 +296,56 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
 
     // ---- plan the launches ---------------------------------------------------------
     struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; const uint32_t* lst; };
-    Plan plans[MAX_STREAMS];
+    Plan plans[MAX_PLANS];
     uint32_t np = 0;
     size_t part_total = 0;
     const uint32_t bm_bytes = mat->dev.bm_words * 4;
     if (bm_bytes > 128 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
-    for (uint32_t t = 0; t < ns; t++) {
-        const uint32_t count = info[TI_COUNT + t];
+    // walk plans (device_mat.hpp): the reads of one (class, stream) that walk their own events
+    WalkPlans walk[2]{}, walkc{};
+    uint64_t walk_reads = 0, n_jobs = 0;
+    uint32_t walkc_reads = 0;
+    // a walk is one wave per 64 reads, each running its reads' events one after the other: a handful of reads
+    // on a large stream (thousands of events per read) is placed faster by a sweep cut into many chunks
+    static const uint32_t walk_min_reads = getenv("WEPP_WALK_MIN_READS") ? (uint32_t)atoi(getenv("WEPP_WALK_MIN_READS")) : 2048;
+    for (uint32_t id = 0; id < MAX_PLANS; id++) {
+        const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
+        const uint32_t t = id & 15u, cls = id >> 4;
+        if (t >= ns) return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+        if (cls == PLAN_WALKC) {
+            // the reads with many events: their walks are cut into jobs (below); the plans of the class are
+            // the streams, the jobs of stream t numbered behind those of the streams before it
+            WalkPlanDev& d = walkc.p[walkc.n];
+            d.tier = t;
+            d.n_list = info[TI_JOBS + t];
+            d.job0 = (uint32_t)n_jobs;
+            d.list = list + info[TI_OFF + (PLAN_WALKC << 4)];
+            d.wave_end = (walkc.n ? walkc.p[walkc.n - 1].wave_end : 0u) + (d.n_list + 63) / 64;
+            walkc.n++;
+            n_jobs += d.n_list;
+            walkc_reads += count;
+            walk_reads += count;
+            continue;
+        }
+        if (cls != PLAN_SWEEP && (count >= walk_min_reads || mat->streams[t].n <= (1u << 16))) {
+            WalkPlans& wp = walk[cls];
+            WalkPlanDev& d = wp.p[wp.n];
+            d.tier = t;
+            d.n_list = count;
+            d.list = list + info[TI_OFF + id];
+            d.wave_end = (wp.n ? wp.p[wp.n - 1].wave_end : 0u) + (count + 63) / 64;
+            wp.n++;
+            walk_reads += count;
+            continue;
+        }
         Plan& p = plans[np++];
         p.t = t;
         p.count = count;
-        p.off = info[TI_OFF + t];
+        p.off = info[TI_OFF + id];
         // reads per tile: at most MAX_TILE_ENTRIES read words per tile (long reads share a
         // sweep between fewer reads), a power of two, never more than the knob
-        const uint32_t maxk = std::max<uint32_t>(1, info[TI_MAXK + t]);
+        const uint32_t maxk = std::max<uint32_t>(1, info[TI_MAXK + id]);
         uint32_t Tp = T;
         while (Tp > 1 && (uint64_t)Tp * maxk > MAX_TILE_ENTRIES) Tp >>= 1;
         p.T = Tp;
@@ -304,6 +371,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         static const uint64_t chunk_bytes = getenv("WEPP_CHUNK_BYTES") ? (uint64_t)atoll(getenv("WEPP_CHUNK_BYTES")) : SWEEP_CHUNK_BYTES;
         nchunks = std::max<uint32_t>(nchunks, (uint32_t)((mat->stream_bytes[t] + chunk_bytes - 1) / chunk_bytes));
         nchunks = std::min<uint32_t>(nchunks, (uint32_t)std::max<uint64_t>(1, SWEEP_MAX_PARTIAL_BYTES / ((uint64_t)count * 12)));
+        // ... but a chunk's wave pays a set-up (bitmap, read words, checkpoint) worth several blocks: no chunk
+        // shorter than 8 blocks, however few tiles the plan has (a plan of a few hundred reads used to be cut into
+        // 4096 waves of one or two blocks each)
+        nchunks = std::min<uint32_t>(nchunks, std::max<uint32_t>(1, st.NB / 8));
         if (p.dense) nchunks = std::max<uint32_t>(nchunks, DENSE_WAVES_PER_WG);   // one chunk per wave of the workgroup
         nchunks = std::min(nchunks, st.ncp);
         const uint32_t cps_per_chunk = (st.ncp + nchunks - 1) / nchunks;
@@ -348,22 +419,80 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         pr = (uint32_t*)(ps + (size_t)p.nchunks * p.count);
         pc = pr + (size_t)p.nchunks * p.count;
     };
-    uint32_t order[MAX_STREAMS], n_plain = 0, n_other = 0, others[MAX_STREAMS];
+    uint32_t order[MAX_PLANS], n_plain = 0, n_other = 0, others[MAX_PLANS];
     // WEPP_SWEEP_UNFUSED=1 (profiling aid): one launch per plan, back to back on `stream`, so that a
     // kernel trace shows the time of every stream's sweep; results are identical
     static const bool unfused = getenv("WEPP_SWEEP_UNFUSED") && getenv("WEPP_SWEEP_UNFUSED")[0] == '1';
     for (uint32_t i = 0; i < np; i++) {
-        if (plans[i].s_in_lds && !plans[i].dense && !unfused) order[n_plain++] = i;
+        if (plans[i].s_in_lds && !plans[i].dense && !unfused && n_plain < MAX_STREAMS) order[n_plain++] = i;
         else others[n_other++] = i;
         passes += plans[i].ntiles;                                   // every tile sweeps its stream once
         bytes += (uint64_t)plans[i].ntiles * mat->stream_bytes[plans[i].t];
     }
     std::sort(order, order + n_plain, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
-    const bool fork = !unfused && n_other > 0 && (n_plain > 0 || n_other > 1);
+    const bool walks = walk[0].n || walk[1].n || walkc.n;
+    if (n_jobs >= (1ull << 31)) return set_error(WEPP_ELIMIT, "too many walk jobs in one call; split the batch");
+    for (uint32_t cls = 0; cls < 2; cls++)
+        if (walk[cls].n) passes += walk[cls].p[walk[cls].n - 1].wave_end;   // a walk "pass" = one wave of 64 reads
+    if (walkc.n) passes += walkc.p[walkc.n - 1].wave_end;
+    const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + (walkc.n ? 1u : 0u);
+    const bool fork = !unfused && (n_other + n_walk_chains > 0) && (n_plain > 0 || n_other + n_walk_chains > 1);
     if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
+    if (walks) {
+        // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
+        // sweeps run side by side (the walks wait on memory most of the time)
+        hipStream_t q = fork ? mat->side[MAX_STREAMS - 1] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        for (uint32_t cls = 0; cls < 2; cls++)
+            HIP_TRY(launch_walk(mat->dev, walk[cls], cls, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
+                                d_num_best, d_flags, mat->d_work, q));
+        if (fork) {
+            HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
+            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[MAX_STREAMS - 1], 0));
+            q = mat->side[MAX_STREAMS - 2];
+            if (walkc.n) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        }
+        if (walkc.n) {
+            // chunked walks: jobs per read in list order -> exclusive scan -> job -> read table -> the walk
+            // (a partial per job) -> one combination per read.  Buffers: a second grow-only workspace.
+            const uint32_t R3 = walkc_reads, J = (uint32_t)n_jobs;
+            size_t scan_temp = 0;
+            HIP_TRY(scan_u32_temp_bytes(R3, &scan_temp));
+            auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            const size_t b_cnt = pad((size_t)R3 * 4), b_off = pad((size_t)R3 * 4), b_tmp = pad(scan_temp), b_job = pad((size_t)J * 4);
+            const size_t need = b_cnt + b_off + b_tmp + 3 * b_job;
+            if (need > mat->ws2_bytes) {
+                if (mat->ws2) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->ws2); mat->ws2 = nullptr; mat->ws2_bytes = 0; }
+                hipError_t e2 = hipMalloc(&mat->ws2, need + need / 4);
+                if (e2 != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc walk workspace: ") + hipGetErrorString(e2));
+                mat->ws2_bytes = need + need / 4;
+            }
+            char* w2 = (char*)mat->ws2;
+            uint32_t* jcnt = (uint32_t*)w2; w2 += b_cnt;
+            uint32_t* joff = (uint32_t*)w2; w2 += b_off;
+            void* jtmp = w2; w2 += b_tmp;
+            WalkJobs jb{};
+            jb.n_list = R3;
+            jb.job_off = joff;
+            jb.job_n = job_n;
+            jb.part_score = (int32_t*)w2; w2 += b_job;
+            jb.part_rank = (uint32_t*)w2; w2 += b_job;
+            jb.part_cnt = (uint32_t*)w2;
+            const uint32_t* list3 = walkc.p[0].list;
+            HIP_TRY(launch_gather_jobs(list3, R3, job_n, jcnt, q));
+            HIP_TRY(launch_exclusive_scan_u32(jcnt, joff, R3, jtmp, scan_temp, q));
+            HIP_TRY(launch_walk_jobs(mat->dev, walkc, jb, d_read_off, d_read_word, root_score, mat->d_work, q));
+            HIP_TRY(launch_finalize_jobs(mat->dev, list3, R3, jb, d_read_off, d_read_word, d_best_bfs_j, d_score,
+                                         d_num_best, d_flags, q));
+            if (fork) {
+                HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 2], q));
+                HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[MAX_STREAMS - 2], 0));
+            }
+        }
+    }
     for (uint32_t k = 0; k < n_other; k++) {
         const Plan& p = plans[others[k]];
-        hipStream_t q = fork ? mat->side[k] : stream;
+        hipStream_t q = fork ? mat->side[k % (MAX_STREAMS - 2)] : stream;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
@@ -372,9 +501,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                              p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, p.lst, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
-        if (fork) {
-            HIP_TRY(hipEventRecord(mat->join_ev[k], q));
-            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[k], 0));
+        if (fork && (k + (MAX_STREAMS - 2) >= n_other)) {
+            // the last launch on every side stream joins the caller's stream
+            HIP_TRY(hipEventRecord(mat->join_ev[k % (MAX_STREAMS - 2)], q));
+            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[k % (MAX_STREAMS - 2)], 0));
         }
     }
     if (n_plain) {
@@ -408,12 +538,16 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     mat->last_passes = passes;
     mat->last_bytes = bytes;
     mat->last_n_reads = n_reads;
+    mat->last_walk_reads = walk_reads;
     return WEPP_OK;
 }
 
 extern "C" int wepp_mat_timing_reset(wepp_mat_t* mat) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
     mat->n_timed = 0;
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(mat->d_work, 0, WALK_COUNTERS * sizeof(unsigned long long)));
     return WEPP_OK;
 }
 
@@ -431,10 +565,18 @@ extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint3
         HIP_TRY(hipEventElapsedTime(&ms, mat->ev0[slot], mat->ev1[slot]));
         sum += ms;
     }
+    // what the walks read: per loop iteration one index entry (12 B), one node key + flags (12 B) and two
+    // sparse-table bytes; averaged over the calls since the reset
+    unsigned long long it = 0;
+    {
+        std::vector<unsigned long long> slots(WALK_COUNTERS);
+        HIP_TRY(hipMemcpy(slots.data(), mat->d_work, WALK_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (unsigned long long v : slots) it += v;
+    }
     if (mean_sweep_ms) *mean_sweep_ms = (float)(sum / n);
     if (n_calls) *n_calls = n;
     if (passes) *passes = mat->last_passes;
-    if (algorithmic_bytes) *algorithmic_bytes = mat->last_bytes;
+    if (algorithmic_bytes) *algorithmic_bytes = mat->last_bytes + (uint64_t)(it / std::max<uint64_t>(1, mat->n_timed)) * 26u;
     return WEPP_OK;
 }
 
@@ -734,5 +876,22 @@ extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_r
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tiers, mat->ws, n_reads, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_reads; r++) tiers[r] &= 15u;     // the workspace holds plan ids: (class << 4) | stream
+    return WEPP_OK;
+}
+
+// diagnostic: how the most recent placement call placed its reads
+extern "C" int wepp_mat_last_walk(wepp_mat_t* mat, uint64_t* reads_walked, uint64_t* walk_iterations) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long it = 0;
+    {
+        std::vector<unsigned long long> slots(WALK_COUNTERS);
+        HIP_TRY(hipMemcpy(slots.data(), mat->d_work, WALK_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (unsigned long long v : slots) it += v;
+    }
+    if (reads_walked) *reads_walked = mat->last_walk_reads;
+    if (walk_iterations) *walk_iterations = it;
     return WEPP_OK;
 }

@@ -38,6 +38,22 @@ struct DevStream {
     const uint32_t* cp_word;
 };
 
+// the position index and range-query structures of one stream (flatmat.hpp), for k_walk
+struct DevWalk {
+    uint32_t n, rq_blocks, last_ent, pad;   // nodes, blocks of the exact range query, index of the last (sentinel) entry
+    const uint32_t* ix_off;
+    const uint32_t* ix_node;
+    const uint32_t* ix_end;
+    const uint32_t* ix_word;
+    const uint32_t* ix_up;
+    const SegNode* rq_pre;
+    const SegNode* rq_suf;
+    const SegNode* rq_dst;
+    const uint8_t* sp;
+    const int64_t* nkey;
+    const uint32_t* nstat;
+};
+
 // tree-wide arrays (global DFS indices)
 struct DevMAT {
     uint32_t N, bm_words, max_pos, n_streams;
@@ -50,7 +66,56 @@ struct DevMAT {
     const uint32_t* dfs2bfs;
     const uint32_t* bfs2dfs;      // inverse of dfs2bfs
     const uint32_t* parent_dfs;   // DFS index of the parent (root: 0)
+    const uint8_t* maxnest;       // [max_pos + 1] most mutations at one position along a root path
+    const DevWalk* walks;         // [n_streams] device array
 };
+
+// A placement call sorts its reads into PLANS: plan id = (class << 4) | stream.  Class = how the read is
+// placed: by the per-read walk of its own events (k_walk) when it lists at most WALK8_K / WALK16_K positions and
+// the intervals it can hold open at once (sum of maxnest over its positions) fit WALK8_STACK / WALK16_STACK, by a
+// sweep of the whole stream otherwise.
+constexpr uint32_t MAX_PLANS = 64;
+constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC = 3;
+// PLAN_WALKC: a read with many events at its positions (a frequently mutated site) walks them as several
+// independent JOBS of about WALK_JOB_EVENTS events each -- node ranges cut at quantiles of its longest list;
+// a job finds the state of a sequential walk at its first node by binary searches in the read's lists and
+// the chains of enclosing entries (ix_up) -- whose (score, rank, count) partials k_finalize_jobs combines.
+constexpr uint32_t WALK_JOB_EVENTS = 32;
+constexpr uint32_t WALK_MAX_EVENTS = 48;   // reads with more events at their positions (in their stream) are swept
+constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
+constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
+struct WalkPlanDev {
+    uint32_t tier, n_list, wave_end, job0;   // wave_end = first wave (of the launch) after this plan;
+    const uint32_t* list;                    // chunked: n_list jobs numbered from job0, list = the class's whole list
+};
+// what a chunked walk needs beside its plans
+struct WalkJobs {
+    uint32_t n_list, pad;        // reads of the class
+    const uint32_t* job_off;     // [n_list] first job of the read at a list position (ascending: a job finds its read by bisection)
+    const uint32_t* job_n;       // [n_reads] jobs of a read (by read index)
+    int32_t* part_score;         // [jobs]
+    uint32_t* part_rank;
+    uint32_t* part_cnt;
+};
+struct WalkPlans {
+    uint32_t n;
+    WalkPlanDev p[MAX_STREAMS];
+};
+// cls = 0 / 1: the plans of one class in ONE launch, a wave = 64 reads; writes the final per-read results
+hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const uint32_t* d_read_off,
+                       const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
+                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream);
+// the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
+hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
+hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, const WalkJobs& jb, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
+                            hipStream_t stream);
+hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t n_list, const WalkJobs& jb,
+                                const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t* best_bfs_j,
+                                int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
+hipError_t scan_u32_temp_bytes(uint32_t n, size_t* bytes);
+hipError_t launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
+                                     hipStream_t stream);
 
 // the plain plans of one call, fused into one launch (k_sweep_multi)
 struct SweepPlanDev {
@@ -74,7 +139,7 @@ constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chain
 // route: tier of every read + per-(block, tier) counts and per-tier max entries; also clears tier_info_next,
 // the counters the next call will use (they must be zero before its k_route)
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
+                        int use_crowns, uint32_t walk_max_events, uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
                         uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
@@ -147,7 +212,9 @@ hipError_t launch_excess(const DevMAT& m, const uint32_t* d_read_off, const uint
                          const unsigned long long* d_out_off, uint32_t* d_counts, uint32_t* d_out, hipStream_t stream);
 hipError_t sweep_set_max_lds(uint32_t bytes);
 
-// layout of tier_info (uint32): [0..8) counts, [8..16) max entries of one read, [16..25) offsets into the list
-constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_STREAMS, TI_OFF = 2 * MAX_STREAMS, TI_WORDS = 3 * MAX_STREAMS + 1;
+// layout of tier_info (uint32), indexed by plan id: counts, max entries of one read, offsets into the list
+// then, per stream, the jobs of its chunked walks
+constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
+                   TI_WORDS = TI_JOBS + MAX_STREAMS;
 
 }  // namespace wepp

@@ -153,6 +153,94 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
         }
         st.blk_sum[b] = s;
     }
+    // ---- position index and range-query tables of the walk ------------------------------
+    {
+        const uint32_t np = f.max_pos + 1;
+        st.ix_off.assign((size_t)np + 1, 0);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t g = sel[i];
+            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) st.ix_off[(f.words[w] & W_POS_MASK) + 1]++;
+        }
+        for (uint32_t p = 0; p < np; p++) st.ix_off[p + 1] += st.ix_off[p] + 1;   // + the sentinel of list p
+        const size_t total = st.ix_off[np];
+        st.ix_node.assign(total, IX_NONE);
+        st.ix_end.assign(total, 0);
+        st.ix_word.assign(total, W_PAD);
+        std::vector<uint32_t> fill(st.ix_off.begin(), st.ix_off.end() - 1);
+        for (uint32_t i = 0; i < n; i++) {          // ascending node index: every list ends up in stream order
+            const uint32_t g = sel[i];
+            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+                const uint32_t e = fill[f.words[w] & W_POS_MASK]++;
+                st.ix_node[e] = i;
+                st.ix_end[e] = lend[i] + 1;
+                st.ix_word[e] = f.words[w];
+            }
+        }
+        // innermost enclosing entry of every entry of a list: the subtrees are nested, so a stack of the
+        // entries still open does it
+        st.ix_up.assign(total, IX_NONE);
+        {
+            std::vector<uint32_t> open;
+            for (uint32_t p = 0; p < np; p++) {
+                open.clear();
+                for (uint32_t e = st.ix_off[p]; e + 1 < st.ix_off[p + 1]; e++) {
+                    while (!open.empty() && st.ix_end[open.back()] <= st.ix_node[e]) open.pop_back();
+                    if (!open.empty()) st.ix_up[e] = open.back();
+                    open.push_back(e);
+                }
+            }
+        }
+        const SegNode none{SCORE_INF, 0xFFFFFFFFu, 0};
+        auto join = [](const SegNode& a, const SegNode& b) {
+            if (b.base < a.base) return b;
+            if (b.base > a.base) return a;
+            return SegNode{a.base, std::min(a.rank, b.rank), a.cnt + b.cnt};
+        };
+        st.sp_levels = 1;
+        while ((2u << (st.sp_levels - 1)) <= n) st.sp_levels++;      // levels 0 .. floor(log2 n)
+        st.sp.assign((size_t)st.sp_levels * n, SP_NONE);
+        st.rq_pre.assign(n, none);
+        st.rq_suf.assign(n, none);
+        st.rq_blocks = (n + RQ_BLK - 1) / RQ_BLK;
+        st.rq_levels = 1;
+        while ((1u << st.rq_levels) < st.rq_blocks) st.rq_levels++;   // rows 0 .. highest bit two block indices can differ in
+        st.rq_dst.assign((size_t)st.rq_levels * st.rq_blocks, none);
+        auto leaf = [&](uint32_t i) {
+            if (!(st.nstat[i] & NS_ELIG0)) return none;
+            return SegNode{(int32_t)(st.nkey[i] >> 32), (uint32_t)(st.nkey[i] & 0xFFFFFFFFll), 1};
+        };
+        for (uint32_t i = 0; i < n; i++)
+            if (st.nstat[i] & NS_ELIG0) st.sp[i] = (uint8_t)std::max(0, std::min<int32_t>((int32_t)(st.nkey[i] >> 32), SP_CLAMP));
+        for (uint32_t b = 0; b < st.rq_blocks; b++) {
+            const uint32_t lo = b * RQ_BLK, hi = std::min(n, lo + RQ_BLK);
+            SegNode run = none;
+            for (uint32_t i = lo; i < hi; i++) { run = join(run, leaf(i)); st.rq_pre[i] = run; }
+            st.rq_dst[b] = run;
+            run = none;
+            for (uint32_t i = hi; i-- > lo;) { run = join(run, leaf(i)); st.rq_suf[i] = run; }
+        }
+        for (uint32_t l = 1; l < st.rq_levels; l++) {
+            // row l serves the pairs of blocks whose indices differ in bit l at the highest: they sit in the two
+            // halves of one 2^(l+1)-aligned group, and row l holds every block's aggregate towards the middle of
+            // its group (row 0, the blocks themselves, is that for adjacent pairs)
+            SegNode* row = st.rq_dst.data() + (size_t)l * st.rq_blocks;
+            const uint32_t half = 1u << l, size = half << 1;
+            for (uint32_t c = 0; c < st.rq_blocks; c += size) {
+                const uint32_t mid = c + half;
+                if (mid >= st.rq_blocks) break;
+                SegNode run = none;
+                for (uint32_t i = mid; i-- > c;) { run = join(run, st.rq_dst[i]); row[i] = run; }
+                run = none;
+                for (uint32_t i = mid; i < std::min(c + size, st.rq_blocks); i++) { run = join(run, st.rq_dst[i]); row[i] = run; }
+            }
+        }
+        for (uint32_t l = 1; l < st.sp_levels; l++) {
+            const uint32_t half = 1u << (l - 1);
+            const uint8_t* lo = st.sp.data() + (size_t)(l - 1) * n;
+            uint8_t* hi = st.sp.data() + (size_t)l * n;
+            for (uint32_t i = 0; i + (half << 1) <= n; i++) hi[i] = std::min(lo[i], lo[i + half]);
+        }
+    }
     // checkpoints
     st.cp_stride = std::max<uint32_t>(1, (st.NB + 1023) / 1024);   // <= 1024 places where a sweep may start
     {
@@ -321,6 +409,8 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
     // state[p] = allele mask of the most recent mutation at p on the current
     // root path (0 = none); refm[p] = the (single) ref mask seen at p.
     std::vector<uint8_t> state((size_t)max_pos + 1, 0), refm((size_t)max_pos + 1, 0);
+    std::vector<uint8_t> nest((size_t)max_pos + 1, 0);     // mutations at p on the current root path (saturating)
+    f.maxnest.assign((size_t)max_pos + 1, 0);
     std::vector<int32_t> D0(N, 0);
     std::vector<int32_t> base(N, 0);
     {
@@ -331,8 +421,10 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             while (!open.empty() && f.dfs_end[open.back()] < d) {
                 uint32_t x = open.back();
                 open.pop_back();
-                for (uint32_t w = f.node_woff[x + 1]; w > f.node_woff[x]; w--)
+                for (uint32_t w = f.node_woff[x + 1]; w > f.node_woff[x]; w--) {
                     state[f.words[w - 1] & W_POS_MASK] = undo[w - 1];
+                    if (nest[f.words[w - 1] & W_POS_MASK] != 255) nest[f.words[w - 1] & W_POS_MASK]--;
+                }
             }
             uint32_t id = f.dfs2id[d];
             int32_t dpar = (d == 0) ? 0 : D0[f.parent_dfs[d]];
@@ -349,6 +441,8 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
                 f.words[w] = w_pack((uint32_t)p, (uint32_t)__builtin_ctz(ref), par, mut);
                 undo[w] = (uint8_t)par;
                 state[p] = (uint8_t)mut;
+                if (nest[p] != 255) nest[p]++;          // (a position that ever saturates stays at 255)
+                f.maxnest[p] = std::max(f.maxnest[p], nest[p]);
                 dcur += (int32_t)cost0(mut, ref) - (int32_t)cost0(par, ref);
                 if (mut == ref) { ncommon0++; nback_cost += cost0(par, ref); }
                 w++;

@@ -56,6 +56,17 @@ struct BlkSum {          // read-independent summary of one sweep block
     uint32_t pad0, pad1; // 32-byte records: one s_load_dwordx8 per block
 };
 
+// Aggregate of a range of stream nodes, as the walk's range queries return it: the best statically
+// eligible node (static score, its tie-break rank, how many tie it); identity = {SCORE_INF, ~0, 0}
+struct SegNode {
+    int32_t base;
+    uint32_t rank;
+    uint32_t cnt;
+};
+constexpr uint32_t RQ_BLK = 16;              // nodes per block of the exact range query
+constexpr uint32_t IX_NONE = 0xFFFFFFFFu;    // sentinel node index closing every position's list
+constexpr uint8_t SP_NONE = 255, SP_CLAMP = 254;   // sparse table: no eligible node in the range / score >= 254
+
 // One sweep stream: the events of an ancestor-closed subset of the nodes (a
 // "crown": every node whose static score is <= tau, plus all their ancestors),
 // or of the whole tree.  Node indices inside a stream are local (0..n-1, DFS
@@ -78,6 +89,27 @@ struct Stream {
     // reaches block i*cp_stride (node blk_node0[..]-1 unless it closes there, and its ancestors)
     std::vector<uint32_t> cp_off;      // [ncp+1]
     std::vector<uint32_t> cp_word;
+    // ---- the same crown addressed by genome position, for the per-read walk (k_walk) ----
+    // list of position p = entries [ix_off[p], ix_off[p+1]) in stream order, the last one a sentinel
+    // (ix_node == IX_NONE): the mutations of the stream's nodes at p with the node's local index, one past
+    // the last local index of its subtree (the nodes that inherit the allele are (node, end)), and the word
+    std::vector<uint32_t> ix_off;      // [max_pos + 2]
+    std::vector<uint32_t> ix_node, ix_end, ix_word;
+    std::vector<uint32_t> ix_up;       // entry (same list) of the innermost enclosing mutation of the position, or
+                                       // IX_NONE: lets a walk that starts mid-stream find the intervals open there
+    // range queries over the statically eligible nodes.
+    // (1) "can anything in [a, b) matter": a sparse table of the minimum score, sp[l * n + i] = min over
+    //     [i, i + 2^l) clamped to SP_CLAMP, SP_NONE when the range holds no eligible node: two byte loads.
+    // (2) the exact (score, rank, count) of [a, b): nodes are grouped in blocks of RQ_BLK; rq_pre[i] /
+    //     rq_suf[i] aggregate a node's block up to / from the node, and rq_dst is a disjoint sparse table
+    //     over the block aggregates (row 0 = the blocks; row l, entry i = the aggregate from block i to the
+    //     middle of its 2^(l+1)-aligned group of blocks, towards that middle): a range that spans blocks is
+    //     suffix + table[l][first whole block] + table[l][last whole block] + prefix, l = the highest bit in
+    //     which the two block indices differ -- four independent loads, whatever the range.
+    uint32_t sp_levels = 1, rq_blocks = 0, rq_levels = 1;
+    std::vector<uint8_t> sp;           // [sp_levels * n]
+    std::vector<SegNode> rq_pre, rq_suf;   // [n]
+    std::vector<SegNode> rq_dst;       // [rq_levels * rq_blocks]
     // bytes one sweep reads whatever the reads are: event words, block offsets and summaries, and -- on
     // a crown (tau finite), where the per-event bounds are fetched with the event words -- one bound byte
     // per event; node keys / flags / event offsets are only touched by node-by-node evaluations
@@ -103,6 +135,8 @@ struct FlatMAT {
     std::vector<uint32_t> parent_dfs;  // [N] DFS index of parent (root: 0)  (host only)
     std::vector<uint32_t> dfs_end;     // [N] last DFS index of the subtree  (host only)
     std::vector<uint32_t> num_leaves;  // [N]                                (host only)
+    std::vector<uint8_t> maxnest;      // [max_pos+1] most mutations at one position along any root path (clamped to 255):
+                                       //             bounds the open intervals a walking read keeps on its stack
     // streams[0 .. n-2] = crowns of increasing tau, streams.back() = whole tree
     std::vector<Stream> streams;
     // EPP event stream (epp_kernels.hip): every non-masked mutation twice, in the order a

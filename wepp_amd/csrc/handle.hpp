@@ -18,6 +18,9 @@ struct wepp_mat {
     int device = 0;
     DevMAT dev{};
     std::vector<DevStream> streams;
+    std::vector<DevWalk> walks;       // position index + range-query structures of every stream (k_walk)
+    int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
+    unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset
     std::vector<uint64_t> stream_bytes;
     wepp_mat_stats stats{};
     std::vector<uint32_t> bfs2id;
@@ -40,6 +43,8 @@ struct wepp_mat {
     // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    void* ws2 = nullptr;              // grow-only workspace of the chunked walks (job tables, partials)
+    size_t ws2_bytes = 0;
     uint32_t* d_info = nullptr;       // two sets of tier_info (TI_WORDS each, used alternately: k_route clears the other one) followed by blk_counts
     uint32_t info_idx = 0;            // the set the next call uses (zero: cleared at creation or by the previous call's k_route)
     uint32_t* h_info = nullptr;       // pinned copy of tier_info
@@ -50,6 +55,7 @@ struct wepp_mat {
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_timed = 0;             // placement calls since the last timing reset
     uint64_t last_passes = 0, last_bytes = 0;
+    uint64_t last_walk_reads = 0;     // reads of the most recent call that walked their own events (k_walk)
     uint32_t last_n_reads = 0;        // reads of the most recent placement call (wepp_mat_last_tiers)
 };
 

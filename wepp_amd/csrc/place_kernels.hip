@@ -163,17 +163,19 @@ __device__ __forceinline__ uint32_t find_entry(SPtr S, uint32_t off, uint32_t k,
 // -----------------------------------------------------------------------------
 __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_t* __restrict__ read_off,
                                                           const uint32_t* __restrict__ read_word, uint32_t n_reads,
-                                                          int use_crowns, uint8_t* __restrict__ tier_of,
+                                                          int use_crowns, uint32_t walk_max_events,
+                                                          uint32_t* __restrict__ job_n, uint8_t* __restrict__ tier_of,
                                                           int32_t* __restrict__ root_score,
                                                           uint32_t* __restrict__ blk_counts,
                                                           uint32_t* __restrict__ tier_info,
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next) {
-    __shared__ uint32_t cnt[MAX_STREAMS], mx[MAX_STREAMS];
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[MAX_STREAMS];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
-    if (threadIdx.x < MAX_STREAMS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
+    if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
+    if (threadIdx.x < MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
@@ -212,19 +214,49 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         if (use_crowns)
             for (uint32_t i = 0; i + 1 < m.n_streams; i++)
                 if (theta <= m.tau[i]) { t = i; break; }
+        // how the read is placed (device_mat.hpp): by walking its own events when it lists few positions and
+        // the intervals it can hold open at once fit the walk's stack, by a sweep of the stream otherwise
+        // A walk runs a read's events one after the other: reads with many events in their stream (a
+        // frequently mutated position) are left to the sweeps, whose cost does not depend on it.
+        uint32_t cls = PLAN_SWEEP;
+        if (walk_max_events && k <= WALK16_K) {
+            uint32_t open_max = 0, events = 0, longest = 0;
+            const uint32_t* ix_off = m.walks[t].ix_off;
+            for (uint32_t j = 0; j < k; j++) {
+                const uint32_t p = w_pos(j < 2 ? fw[u][j] : read_word[so + j]);
+                if (p <= m.max_pos) {
+                    open_max += (uint32_t)m.maxnest[p];
+                    const uint32_t len = ix_off[p + 1] - ix_off[p] - 1u;      // (every list ends in a sentinel)
+                    events += len;
+                    longest = max(longest, len);
+                }
+            }
+            if (events <= walk_max_events) {
+                if (k <= WALK8_K && open_max <= WALK8_STACK) cls = PLAN_WALK8;
+                else if (open_max <= WALK16_STACK) cls = PLAN_WALK16;
+            } else if (open_max <= WALK16_STACK) {
+                // many events: jobs of about WALK_JOB_EVENTS, cut at quantiles of the longest list
+                cls = PLAN_WALKC;
+                const uint32_t nj = min((events + WALK_JOB_EVENTS - 1) / WALK_JOB_EVENTS, longest);
+                job_n[r] = nj;
+                atomicAdd(&jobs_of[t], nj);
+            }
+        }
+        t |= cls << 4;
         tier_of[r] = (uint8_t)t;
-        slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the tier (k_scatter)
+        slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the plan (k_scatter)
         atomicMax(&mx[t], k);
       }
     }
     __syncthreads();
-    if (threadIdx.x < MAX_STREAMS) {
-        blk_counts[blockIdx.x * MAX_STREAMS + threadIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x < MAX_PLANS) {
+        blk_counts[blockIdx.x * MAX_PLANS + threadIdx.x] = cnt[threadIdx.x];
         if (cnt[threadIdx.x]) {
             atomicAdd(&tier_info[TI_COUNT + threadIdx.x], cnt[threadIdx.x]);
             atomicMax(&tier_info[TI_MAXK + threadIdx.x], mx[threadIdx.x]);
         }
     }
+    if (threadIdx.x < MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
 }
 
 // -----------------------------------------------------------------------------
@@ -236,27 +268,27 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
                                                             const uint32_t* __restrict__ blk_counts,
                                                             uint32_t* __restrict__ tier_info,
                                                             uint32_t* __restrict__ list) {
-    __shared__ uint32_t base[MAX_STREAMS], before[MAX_STREAMS];
-    if (threadIdx.x < MAX_STREAMS) before[threadIdx.x] = 0;
+    __shared__ uint32_t base[MAX_PLANS], before[MAX_PLANS];
+    if (threadIdx.x < MAX_PLANS) before[threadIdx.x] = 0;
     __syncthreads();
     // reads of every tier in the blocks before this one: thread = (tier, one earlier block in 64), so that a
     // wave's sixteen-lane groups read whole 64-byte rows and only four lanes of a wave add to the same LDS
     // word (one thread per row with sixteen adds each serialised 64 lanes on every word)
     {
-        const uint32_t t = threadIdx.x & (MAX_STREAMS - 1), c0 = threadIdx.x / MAX_STREAMS;
+        const uint32_t t = threadIdx.x & (MAX_PLANS - 1), c0 = threadIdx.x / MAX_PLANS;
         uint32_t acc = 0;
-        for (uint32_t b = c0; b < blockIdx.x; b += blockDim.x / MAX_STREAMS) acc += blk_counts[b * MAX_STREAMS + t];
+        for (uint32_t b = c0; b < blockIdx.x; b += blockDim.x / MAX_PLANS) acc += blk_counts[b * MAX_PLANS + t];
         if (acc) atomicAdd(&before[t], acc);
     }
     __syncthreads();
-    if (threadIdx.x < MAX_STREAMS) {
+    if (threadIdx.x < MAX_PLANS) {
         const uint32_t t = threadIdx.x;
-        uint32_t off = 0;                       // start of tier t in the list
+        uint32_t off = 0;                       // start of plan t in the list
         for (uint32_t i = 0; i < t; i++) off += tier_info[TI_COUNT + i];
         base[t] = off + before[t];
         if (blockIdx.x == 0) {
             tier_info[TI_OFF + t] = off;
-            if (t == MAX_STREAMS - 1) tier_info[TI_OFF + MAX_STREAMS] = off + tier_info[TI_COUNT + t];
+            if (t == MAX_PLANS - 1) tier_info[TI_OFF + MAX_PLANS] = off + tier_info[TI_COUNT + t];
         }
     }
     __syncthreads();
@@ -922,6 +954,37 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void k_sweep_multi(SweepPlans pl,
 // reference's BFS index and recompute its has_unique flag
 // (usher_mapper.cpp:184,199,262,472,492).
 // -----------------------------------------------------------------------------
+// the per-read outputs from a read's best (score, rank, count): the reference's BFS index of the winner and
+// its has_unique flag recomputed from its own mutations (usher_mapper.cpp:184,199,262,472,492)
+__device__ __forceinline__ void emit_result(const DevMAT& m, uint32_t r, const uint32_t* __restrict__ read_off,
+                                            const uint32_t* __restrict__ read_word, int bs, uint32_t br, uint32_t cnt,
+                                            uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
+                                            uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
+    // the root always competes, so some chunk reports it or better; the clamp only keeps a broken
+    // invariant from becoming an out-of-bounds read
+    const uint32_t d = m.rank2dfs[br < m.N ? br : 0u];
+    const uint32_t st = m.nstat[d];
+    uint32_t hu = 0;
+    if (!(st & NS_ROOT_DEV)) {
+        if (st & NS_MASKED_DEV) hu = 1;
+        else {
+            int ncom = (int)((st >> 14) & NS_CNT_MASK_DEV);
+            int dummy = 0;
+            const uint32_t so = read_off[r], k = read_off[r + 1] - so;
+            for (uint32_t w = m.node_woff[d]; w < m.node_woff[d + 1]; w++) {
+                const uint32_t tw = m.words[w];
+                const uint32_t s = find_entry(read_word, so, k, w_pos(tw));
+                if (s != NONE) own_adjust(tw, s, dummy, ncom);
+            }
+            hu = (ncom < (int)(st & NS_CNT_MASK_DEV)) ? 1u : 0u;
+        }
+    }
+    if (best_bfs_j) best_bfs_j[r] = m.dfs2bfs[d];
+    if (score) score[r] = bs;
+    if (num_best) num_best[r] = cnt;
+    if (flags) flags[r] = hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+}
+
 template <uint32_t LPR>
 __device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, const uint32_t* __restrict__ read_off,
                            const uint32_t* __restrict__ read_word, const uint32_t* __restrict__ list,
@@ -976,30 +1039,7 @@ __device__ __forceinline__ void finalize_reads(const DevMAT& m, uint32_t blk, co
         }
     }
     if (sub != 0 || !valid) return;
-    const uint32_t r = list[i];
-    // the root always competes, so some chunk reports it or better; the clamp only keeps a broken
-    // invariant from becoming an out-of-bounds read
-    const uint32_t d = m.rank2dfs[br < m.N ? br : 0u];
-    const uint32_t st = m.nstat[d];
-    uint32_t hu = 0;
-    if (!(st & NS_ROOT_DEV)) {
-        if (st & NS_MASKED_DEV) hu = 1;
-        else {
-            int ncom = (int)((st >> 14) & NS_CNT_MASK_DEV);
-            int dummy = 0;
-            const uint32_t so = read_off[r], k = read_off[r + 1] - so;
-            for (uint32_t w = m.node_woff[d]; w < m.node_woff[d + 1]; w++) {
-                const uint32_t tw = m.words[w];
-                const uint32_t s = find_entry(read_word, so, k, w_pos(tw));
-                if (s != NONE) own_adjust(tw, s, dummy, ncom);
-            }
-            hu = (ncom < (int)(st & NS_CNT_MASK_DEV)) ? 1u : 0u;
-        }
-    }
-    if (best_bfs_j) best_bfs_j[r] = m.dfs2bfs[d];
-    if (score) score[r] = bs;
-    if (num_best) num_best[r] = cnt;
-    if (flags) flags[r] = hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+    emit_result(m, list[i], read_off, read_word, bs, br, cnt, best_bfs_j, score, num_best, flags);
 }
 
 template <uint32_t LPR>
@@ -1031,6 +1071,354 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
         default: FIN(64); break;
     }
 #undef FIN
+}
+
+// -----------------------------------------------------------------------------
+// k_walk: a read visits only the events of the positions IT lists.
+//
+// lane = read.  The stream's position index (DevWalk) gives, per listed position, the mutations of
+// the stream's nodes at that position in stream order, each with the node's index and the end of its
+// subtree: the read merges its (at most KW) lists, keeps the intervals it has entered on a stack
+// (they are nested: subtrees), and between two consecutive events -- where its running c_S is
+// constant and no node carries one of its positions -- asks a range query for the best statically
+// eligible node: a sparse table of the minimum static score says whether anything in the range can
+// reach the read's best (almost never), and only then a segment tree gives the exact (score, rank,
+// count).  The node of an event is evaluated with the formula of the sweep's node-by-node path.
+// Work per read ~ events at its positions in the stream, instead of the whole stream per tile:
+// 2 events instead of 270 blocks on the 17 K-node crown, ~3.5 K instead of 250 K blocks on the
+// whole tree for a read with three entries.  Same results (tests/walk_model.py is the CPU model).
+// -----------------------------------------------------------------------------
+template <int KW, int SD, bool CHUNKED>
+__global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, const uint32_t* __restrict__ read_off,
+                                              const uint32_t* __restrict__ read_word,
+                                              const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
+                                              int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best,
+                                              uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter) {
+    // wave-private LDS: the read words [KW][64], the list cursors [KW][64], the interval stack [SD][64]
+    __shared__ uint32_t lds_all[4 * (2 * KW + SD) * 64];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* S_l = lds_all + wv * (2 * KW + SD) * 64;
+    uint32_t* cur_l = S_l + KW * 64;
+    uint32_t* stk = cur_l + KW * 64;
+    const uint32_t unit = blockIdx.x * 4 + wv;
+    if (unit >= pl.p[pl.n - 1].wave_end) return;
+    uint32_t pi = 0;
+    while (pi + 1 < pl.n && unit >= pl.p[pi].wave_end) pi++;
+    const WalkPlanDev& q = pl.p[pi];
+    const uint32_t tile = unit - (pi ? pl.p[pi - 1].wave_end : 0u);
+    const DevWalk ix = m.walks[q.tier];
+    const uint32_t slot = tile * 64 + lane;
+    const bool have = slot < q.n_list;
+    // plain: a lane = a read of the plan's list.  CHUNKED: a lane = a job = (read, chunk of its walk)
+    uint32_t rd = 0, chunk = 0, n_chunks = 1, job = 0;
+    if (CHUNKED) {
+        if (have) {
+            // the read a job belongs to: last list position whose first job is <= job (job_off ascends)
+            job = q.job0 + slot;
+            uint32_t lo = 0, hi = jb.n_list;              // invariant: job_off[lo] <= job, job_off[hi] > job (or hi == n)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (jb.job_off[mid] <= job) lo = mid; else hi = mid;
+            }
+            rd = q.list[lo];
+            chunk = job - jb.job_off[lo];
+            n_chunks = jb.job_n[rd];
+        }
+    } else {
+        rd = have ? q.list[slot] : 0u;
+    }
+    const uint32_t so = have ? read_off[rd] : 0u;
+    const uint32_t k = have ? read_off[rd + 1] - so : 0u;
+    const int root_sc = have ? root_score[rd] : 0;
+
+    // ---- set-up: the read's words, the start of every position's list, its first node ----
+    uint32_t head[KW];
+    int c = 0;
+    uint32_t long_off = 0, long_len = 0;     // CHUNKED: the read's longest list (the chunks are its quantiles)
+#pragma unroll
+    for (int j = 0; j < KW; j++) {
+        head[j] = NONE;
+        if ((uint32_t)j < k) {
+            const uint32_t w = read_word[so + j];
+            const uint32_t p = w_pos(w);
+            // a position beyond the tree's last mutated one has no list: the last sentinel stands in
+            const uint32_t e = p <= m.max_pos ? ix.ix_off[p] : ix.last_ent;
+            S_l[j * 64 + lane] = w;
+            cur_l[j * 64 + lane] = e;
+            if (CHUNKED) {
+                const uint32_t len = p <= m.max_pos ? ix.ix_off[p + 1] - e - 1u : 0u;
+                if (len > long_len) { long_len = len; long_off = e; }
+            } else {
+                head[j] = ix.ix_node[e];
+            }
+            if (!rw_missing(w)) c += ((rw_mut(w) & rw_ref(w)) == 0) ? 1 : 0;
+        }
+    }
+    uint32_t n = ix.n;              // one past the last node this lane looks at
+    uint32_t pos = 0;               // next node nobody has looked at
+    uint32_t sp = 0;                // open intervals on the stack
+    uint32_t top_end = NONE;
+    int top_d = 0;
+    if (CHUNKED) {
+        // this job's nodes [pos, n): cut at the quantiles of the longest list (k_route made sure it has at
+        // least n_chunks entries)
+        if (chunk + 1 < n_chunks) n = ix.ix_node[long_off + (uint32_t)(((uint64_t)(chunk + 1) * long_len) / n_chunks)];
+        if (chunk) pos = ix.ix_node[long_off + (uint32_t)(((uint64_t)chunk * long_len) / n_chunks)];
+        // ---- the state of a sequential walk when it reaches `pos` ----
+        // every list's cursor at its first entry >= pos: binary searches, four lists side by side (their
+        // loads in flight together); cursors and words live in LDS, so the loops over the lists stay rolled
+        const bool mid_stream = have && chunk != 0;
+#pragma unroll 1
+        for (uint32_t j0 = 0; j0 < (uint32_t)KW; j0 += 4) {
+            if (!__ballot(mid_stream && j0 < k)) break;
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                lo[u] = 0; hi[u] = 0;
+                if (j0 + u < k && mid_stream) {
+                    const uint32_t p = w_pos(S_l[(j0 + u) * 64 + lane]);
+                    lo[u] = cur_l[(j0 + u) * 64 + lane];
+                    hi[u] = p <= m.max_pos ? ix.ix_off[p + 1] - 1u : lo[u];       // (the sentinel stays out)
+                }
+            }
+            // first entry of the list goes to the stack region for a moment: the predecessor test below needs it
+            bool searching = true;
+            const uint32_t first0 = lo[0], first1 = lo[1], first2 = lo[2], first3 = lo[3];
+            while (__ballot(searching)) {
+                uint32_t probe[4];
+                searching = false;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) probe[u] = lo[u] < hi[u] ? ix.ix_node[(lo[u] + hi[u]) >> 1] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    if (lo[u] < hi[u]) {
+                        const uint32_t mid = (lo[u] + hi[u]) >> 1;
+                        if (probe[u] < pos) lo[u] = mid + 1; else hi[u] = mid;
+                        searching = searching || lo[u] < hi[u];
+                    }
+                }
+            }
+            // the intervals open at `pos`: a list's predecessor entry if its subtree reaches past pos, else the
+            // first one up its chain of enclosing entries that does, and every entry enclosing that one
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                if (j0 + u < k && mid_stream) {
+                    const uint32_t first = u == 0 ? first0 : u == 1 ? first1 : u == 2 ? first2 : first3;
+                    const uint32_t sw = S_l[(j0 + u) * 64 + lane];
+                    cur_l[(j0 + u) * 64 + lane] = lo[u];
+                    uint32_t e = lo[u] > first ? lo[u] - 1u : NONE;
+                    while (e != NONE && ix.ix_end[e] <= pos) e = ix.ix_up[e];
+                    while (e != NONE) {
+                        const int d = enter_delta(ix.ix_word[e], sw);
+                        c += d;
+                        if (d != 0) {
+                            // insertion by subtree end, outermost at the bottom (the intervals are nested)
+                            const uint32_t end = ix.ix_end[e];
+                            uint32_t at = sp;
+                            while (at > 0 && (stk[(at - 1) * 64 + lane] >> 7) < end) { stk[at * 64 + lane] = stk[(at - 1) * 64 + lane]; at--; }
+                            stk[at * 64 + lane] = (end << 7) | (uint32_t)(d + 64);
+                            sp++;
+                        }
+                        e = ix.ix_up[e];
+                    }
+                }
+            }
+        }
+        if (sp) {
+            const uint32_t e = stk[(sp - 1) * 64 + lane];
+            top_end = e >> 7;
+            top_d = (int)(e & 127u) - 64;
+        }
+#pragma unroll
+        for (int j = 0; j < KW; j++)
+            if ((uint32_t)j < k) head[j] = ix.ix_node[cur_l[j * 64 + lane]];
+    }
+    if (!have) pos = n;
+    int bs = root_sc + 1;          // the root always competes: nothing worse can win or tie
+    uint32_t br = 0xFFFFFFFFu, cnt = 0;
+    uint32_t iters = 0;
+
+    auto take = [&](int sc, uint32_t rk, uint32_t kk) {
+        if (sc < bs) { bs = sc; br = rk; cnt = kk; }
+        else if (sc == bs) { cnt += kk; br = min(br, rk); }
+    };
+
+    while (__ballot(pos < n)) {
+        iters++;
+        uint32_t i_next = head[0];
+#pragma unroll
+        for (int j = 1; j < KW; j++) i_next = min(i_next, head[j]);
+        const bool live = pos < n;
+        const uint32_t stop = min(min(i_next, top_end), n);
+        // the node of the next event: its static key and flags are requested now, used after the range query
+        const bool at_node = live && i_next < top_end && i_next < n;
+        int64_t key = 0;
+        uint32_t nst = 0;
+        if (at_node) { key = ix.nkey[i_next]; nst = ix.nstat[i_next]; }
+        // ---- the nodes [pos, stop): none of them carries a listed position, c is constant ----
+        if (live && stop > pos) {
+            const uint32_t len = stop - pos;
+            const uint32_t lvl = 31u - (uint32_t)__builtin_clz(len);
+            const uint8_t* row = ix.sp + (size_t)lvl * ix.n;
+            const uint32_t a = row[pos], b = row[stop - (1u << lvl)];
+            const uint32_t mn = min(a, b);
+            const bool pass = mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
+            if (__ballot(pass)) {
+                if (pass) {
+                    // exact (score, rank, count) of the best statically eligible node of [pos, stop): suffix of
+                    // the first node's block, disjoint sparse table over the whole blocks in between, prefix of
+                    // the last node's block -- four independent loads (flatmat.hpp)
+                    const uint32_t last = stop - 1;
+                    const uint32_t ba = pos / RQ_BLK, bl = last / RQ_BLK;
+                    int eb = SCORE_INF_DEV;
+                    uint32_t er = 0xFFFFFFFFu, ec = 0;
+                    auto join = [&](const SegNode x) {
+                        if (x.base < eb) { eb = x.base; er = x.rank; ec = x.cnt; }
+                        else if (x.base == eb) { ec += x.cnt; er = min(er, x.rank); }
+                    };
+                    if (ba == bl) {
+                        for (uint32_t i = pos; i < stop; i++) {          // inside one block: node by node
+                            const uint32_t st_i = ix.nstat[i];
+                            const int64_t k_i = ix.nkey[i];
+                            if (st_i & NS_ELIG0_DEV) join(SegNode{(int)(k_i >> 32), (uint32_t)(k_i & 0xFFFFFFFFll), 1u});
+                        }
+                    } else {
+                        const uint32_t lo = ba + 1, hi = bl - 1;
+                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u};
+                        const uint32_t L = lo < hi ? 31u - (uint32_t)__builtin_clz(lo ^ hi) : 0u;
+                        const SegNode* trow = ix.rq_dst + (size_t)L * ix.rq_blocks;
+                        const SegNode s1 = ix.rq_suf[pos], s2 = ix.rq_pre[last];
+                        const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
+                        join(s1); join(s2); join(s3); join(s4);
+                    }
+                    if (ec && eb + c <= bs) take(eb + c, er, ec);
+                }
+            }
+            pos = stop;
+        }
+        if (live && pos < n) {
+            if (!at_node) {
+                // the innermost open interval ends here: its nodes are behind us
+                c -= top_d;
+                sp--;
+                if (sp) {
+                    const uint32_t e = stk[(sp - 1) * 64 + lane];
+                    top_end = e >> 7;
+                    top_d = (int)(e & 127u) - 64;
+                } else { top_end = NONE; top_d = 0; }
+            }
+        }
+        if (__ballot(at_node)) {
+            if (at_node) {
+                // every listed mutation the node carries (nearly always one)
+                const uint32_t node = i_next;
+                int adj = 0, dcom = 0, dsum = 0;
+                uint32_t end = 0;
+                bool more = true;
+                while (more) {
+                    int js = 0;
+#pragma unroll
+                    for (int j = KW - 1; j >= 0; j--) js = head[j] == node ? j : js;
+                    const uint32_t sw = S_l[js * 64 + lane];
+                    const uint32_t e = cur_l[js * 64 + lane];
+                    const uint32_t w = ix.ix_word[e];
+                    end = ix.ix_end[e];
+                    const uint32_t nh = ix.ix_node[e + 1];
+                    cur_l[js * 64 + lane] = e + 1;
+                    own_adjust(w, sw, adj, dcom);
+                    // descendants take the allele; the root also scores itself with it (usher_mapper.cpp:266-271)
+                    if (end > node + 1 || node == 0) dsum += enter_delta(w, sw);
+                    more = false;
+#pragma unroll
+                    for (int j = 0; j < KW; j++) {
+                        if (j == js) head[j] = nh;
+                        more = more || head[j] == node;
+                    }
+                }
+                const int base = (int)(key >> 32);
+                const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
+                const uint32_t nmut = nst & NS_CNT_MASK_DEV, ncom0 = (nst >> 14) & NS_CNT_MASK_DEV;
+                const bool leaf = nst & NS_LEAF_DEV, masked = nst & NS_MASKED_DEV, root = nst & NS_ROOT_DEV;
+                bool elig;
+                int sc;
+                if (root) { elig = true; sc = base + c + dsum; }
+                else if (masked) { elig = false; sc = 0; }
+                else {
+                    sc = base + c + adj;
+                    const int ncom = (int)ncom0 + dcom;
+                    elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
+                }
+                if (elig && sc <= bs) take(sc, rank, 1u);
+                if (dsum != 0 && end > node + 1) {
+                    // k_route admits a read only if its open intervals always fit (sum of maxnest <= SD)
+                    stk[sp * 64 + lane] = (end << 7) | (uint32_t)(dsum + 64);
+                    sp++;
+                    top_end = end;
+                    top_d = dsum;
+                }
+                c += dsum;
+                pos = node + 1;
+            }
+        }
+    }
+    if (have) {
+        if (CHUNKED) {
+            jb.part_score[job] = bs;
+            jb.part_rank[job] = br;
+            jb.part_cnt[job] = cnt;
+        } else {
+            emit_result(m, rd, read_off, read_word, bs, br, cnt, best_bfs_j, score_out, num_best, flags);
+        }
+    }
+    // (1024 counters: thousands of waves adding to ONE address queue up at the memory side)
+    if (work_counter && lane == 0) atomicAdd(work_counter + (unit & (WALK_COUNTERS - 1)), (unsigned long long)iters);
+}
+
+// job counts in list order (the input of the scan)
+__global__ void k_gather_jobs(const uint32_t* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ job_n,
+                              uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_list) out[i] = job_n[list[i]];
+}
+// a wave per 64 reads of the chunked class: a read with few jobs is combined by its own lane, one with many
+// by the whole wave (lane-strided loads, butterfly reduction)
+__global__ __launch_bounds__(256) void k_finalize_jobs(DevMAT m, const uint32_t* __restrict__ list, uint32_t n_list, WalkJobs jb,
+                                const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                                uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
+                                uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n_list;
+    const uint32_t r = valid ? list[i] : 0u;
+    const uint32_t j0 = valid ? jb.job_off[i] : 0u, nj = valid ? jb.job_n[r] : 0u;
+    int bs = 0x7FFFFFFF;
+    uint32_t br = 0xFFFFFFFFu, cnt = 0;
+    auto take = [&](int& b, uint32_t& rk, uint32_t& ct, int s, uint32_t pr, uint32_t pc) {
+        if (pc == 0) return;
+        if (s < b) { b = s; rk = pr; ct = pc; }
+        else if (s == b) { ct += pc; rk = min(rk, pr); }
+    };
+    constexpr uint32_t SMALL = 8;
+    if (nj <= SMALL)
+        for (uint32_t c = 0; c < nj; c++) take(bs, br, cnt, jb.part_score[j0 + c], jb.part_rank[j0 + c], jb.part_cnt[j0 + c]);
+    unsigned long long big = __ballot(nj > SMALL);
+    while (big) {
+        const int l = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t bj0 = (uint32_t)__builtin_amdgcn_readlane((int)j0, l), bnj = (uint32_t)__builtin_amdgcn_readlane((int)nj, l);
+        int ws = 0x7FFFFFFF;
+        uint32_t wr = 0xFFFFFFFFu, wc = 0;
+        for (uint32_t c = lane; c < bnj; c += 64) take(ws, wr, wc, jb.part_score[bj0 + c], jb.part_rank[bj0 + c], jb.part_cnt[bj0 + c]);
+#pragma unroll
+        for (int msk = 1; msk < 64; msk <<= 1) {
+            const int os = __shfl_xor(ws, msk, 64);
+            const uint32_t orr = (uint32_t)__shfl_xor((int)wr, msk, 64), oc = (uint32_t)__shfl_xor((int)wc, msk, 64);
+            take(ws, wr, wc, os, orr, oc);
+        }
+        if ((int)lane == l) { bs = ws; br = wr; cnt = wc; }
+    }
+    if (valid) emit_result(m, r, read_off, read_word, bs, br, cnt, best_bfs_j, score, num_best, flags);
 }
 
 // -----------------------------------------------------------------------------
@@ -1299,10 +1687,11 @@ __global__ void k_excess(DevMAT m, const uint32_t* __restrict__ read_off, const 
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream) {
+                        int use_crowns, uint32_t walk_max_events, uint32_t* job_n, uint8_t* tier_of, int32_t* root_score,
+                        uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next,
+                        hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
-                       n_reads, use_crowns, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
+                       n_reads, use_crowns, walk_max_events, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
     return hipGetLastError();
 }
 
@@ -1374,6 +1763,48 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
     else if (lpr == 16) FIN(16);
     else FIN(64);
 #undef FIN
+    return hipGetLastError();
+}
+
+hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const uint32_t* d_read_off,
+                       const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
+                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    const uint32_t waves = pl.p[pl.n - 1].wave_end;
+    const dim3 grid((waves + 3) / 4), block(256);
+    const WalkJobs none{};
+    if (cls == PLAN_WALK8)
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, 0, stream, m, pl, none, d_read_off,
+                           d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+    else
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, 0, stream, m, pl, none, d_read_off,
+                           d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream) {
+    if (n_list == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_jobs, dim3((n_list + 255) / 256), dim3(256), 0, stream, list, n_list, job_n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, const WalkJobs& jb, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
+                            hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    const uint32_t waves = pl.p[pl.n - 1].wave_end;
+    hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), dim3((waves + 3) / 4), dim3(256), 0, stream, m, pl, jb,
+                       d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, work_counter);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t n_list, const WalkJobs& jb,
+                                const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t* best_bfs_j,
+                                int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
+    if (n_list == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_jobs, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, list, n_list, jb, d_read_off,
+                       d_read_word, best_bfs_j, score, num_best, flags);
     return hipGetLastError();
 }
 
