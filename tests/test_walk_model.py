@@ -37,8 +37,7 @@ def test_walk_model_matches_oracle_fuzz(oracle):
             rs = _root_score(fv, S)
             for m in (models[-1], models[tiers.route(S)]):
                 got = m.result(S, rs)
-                assert got == (o["score"], o["best_j"], o["num_best"]), (S, got, o, m.stream)
-                assert m.max_stack <= m.stack_bound(S) or True
+                assert got == (o["score"], o["best_j"], o["num_best"], o["has_unique"]), (S, got, o, m.stream)
                 deepest = max(deepest, m.max_stack)
                 exact += m.n_exact
                 segs += m.n_segments
@@ -71,7 +70,7 @@ def test_chunked_walk_matches_oracle(oracle):
                         continue
                     m.max_stack = 0
                     got = m.result(S, rs, C)
-                    assert got == (o["score"], o["best_j"], o["num_best"]), (S, C, got, o, m.stream)
+                    assert got == (o["score"], o["best_j"], o["num_best"], o["has_unique"]), (S, C, got, o, m.stream)
                     assert m.max_stack <= m.stack_bound(S)
                     multi += C > 1
             n += 1
@@ -99,7 +98,8 @@ def test_index_layout_invariants():
     g = w.generate_tree(9, 20000)
     fv = w.FlatView(g.tree)
     for s in (0, fv.n_streams - 1):
-        off, node, end = fv.get("ix_off", s), fv.get("ix_node", s), fv.get("ix_end", s)
+        head, ent = fv.get("ix_head", s), fv.get("ix_ent", s)
+        off, node, end = head[:, 0], ent[:, 0], ent[:, 1]
         n = len(fv.get("nkey", s))
         assert off[0] == 0 and off[-1] == len(node)
         assert (node[off[1:] - 1] == wm.IX_NONE).all()                 # every list ends in its sentinel
@@ -133,9 +133,12 @@ def test_range_queries_against_brute_force():
             b = int(rng.integers(a + 1, min(m.n, a + int(rng.choice([3, 20, 200, 5000]))) + 1))
             sel = np.nonzero(elig[a:b])[0] + a
             if len(sel) == 0:
-                assert m.range_min(a, b) == wm.SP_NONE and m.range_exact(a, b)[2] == 0
+                assert m.range_exact(a, b)[2] == 0
                 continue
             mn = int(base[sel].min())
             at = sel[base[sel] == mn]
-            assert m.range_min(a, b) == min(mn, wm.SP_CLAMP)
-            assert m.range_exact(a, b) == (mn, int(rank[at].min()), len(at))
+            # the pre-test reads the minimum of a superset of the range at most twice as long
+            ln = b - a
+            sup = np.nonzero(elig[a:min(m.n, a + (1 << (ln - 1).bit_length()))])[0] + a
+            assert m.range_min(a, b) == min(int(base[sup].min()), wm.SP_CLAMP) <= min(mn, wm.SP_CLAMP)
+            assert m.range_exact(a, b)[:3] == (mn, int(rank[at].min()), len(at))

@@ -18,12 +18,24 @@ SCORE_INF = 0x3FFFFFFF
 class WalkModel:
     def __init__(self, flat, stream=None):
         self.stream = flat.n_streams - 1 if stream is None else stream
-        for name in ("nkey", "nstat", "ix_off", "ix_node", "ix_end", "ix_word", "ix_up", "rq_pre", "rq_suf", "rq_dst", "sp"):
+        for name in ("nkey", "nstat", "rq_pre", "rq_suf", "rq_dst", "sp"):
             setattr(self, name, flat.get(name, self.stream))
+        head, ent, nrec = flat.get("ix_head", self.stream), flat.get("ix_ent", self.stream), flat.get("nrec", self.stream)
+        self.ix_off = head[:, 0]
+        self.ix_node, self.ix_end, self.ix_word, self.ix_up = ent[:, 0], ent[:, 1], ent[:, 2], ent[:, 3]
+        assert (head[:-1, 1] == ent[head[:-1, 0], 0]).all()            # IxHead::first_node
+        real = ent[:, 0] != IX_NONE
+        assert (ent[:-1, 4][real[:-1]] == ent[1:, 0][real[:-1]]).all()  # IxEnt::next_node
+        assert (ent[real, 5].astype(np.int32).astype(np.int64) == (self.nkey[ent[real, 0]] >> 32)).all()
+        assert (ent[real, 6].astype(np.int64) == (self.nkey[ent[real, 0]] & 0xFFFFFFFF)).all()
+        assert (ent[real, 7] == self.nstat[ent[real, 0]]).all()
+        assert (nrec[:, 0].astype(np.int64) == (self.nkey >> 32)).all() and (nrec[:, 2] == self.nstat).all()
+        assert (nrec[:, 1].astype(np.int64) == (self.nkey & 0xFFFFFFFF)).all()
+        self.rank2bfs = flat.get("rank2bfs")
         self.n = len(self.nkey)
         self.nblk = (self.n + RQ_BLK - 1) // RQ_BLK
         self.levels = len(self.sp) // self.n
-        self.maxnest = flat.get("maxnest")
+        self.maxnest = flat.get("ix_nest", self.stream)
         self.rank2dfs = flat.get("rank2dfs")
         self.dfs2bfs = flat.get("dfs2bfs")
         self.max_stack = 0
@@ -32,21 +44,23 @@ class WalkModel:
 
     # ---- range queries -------------------------------------------------------------------
     def range_min(self, a, b):
+        """The walk's pre-test: ONE entry of the sparse table, of the first level whose span from `a` reaches
+        b -- the minimum of a superset of [a, b) (never larger than the true minimum)."""
         ln = b - a
-        l = ln.bit_length() - 1
+        l = (ln - 1).bit_length()            # smallest l with 2^l >= ln
         assert l < self.levels
-        return min(int(self.sp[l * self.n + a]), int(self.sp[l * self.n + b - (1 << l)]))
+        return int(self.sp[l * self.n + a])
 
     def range_exact(self, a, b):
         """(score, rank, count) of the best statically eligible node of [a, b): suffix of a's block, the
         disjoint sparse table over the whole blocks in between, prefix of the last node's block."""
-        none = (SCORE_INF, 0xFFFFFFFF, 0)
+        none = (SCORE_INF, 0xFFFFFFFF, 0, 0)
 
         def comb(x, y):
             if y[0] < x[0]:
                 return y
             if y[0] == x[0]:
-                return (x[0], min(x[1], y[1]), x[2] + y[2])
+                return (x[0], min(x[1], y[1]), x[2] + y[2], y[3] if y[1] < x[1] else x[3])
             return x
 
         def row(arr, i):
@@ -56,9 +70,11 @@ class WalkModel:
         if ba == bl:
             best = none
             for i in range(a, b):                     # inside one block: node by node
-                if int(self.nstat[i]) & NS_ELIG0:
+                st = int(self.nstat[i])
+                if st & NS_ELIG0:
                     k = int(self.nkey[i])
-                    best = comb(best, (k >> 32, k & 0xFFFFFFFF, 1))
+                    hu = 0 if st & NS_ROOT else 1 if st & NS_MASKED else int(((st >> 14) & NS_CNT) < (st & NS_CNT))
+                    best = comb(best, (k >> 32, k & 0xFFFFFFFF, 1, hu))
             return best
         best = comb(row(self.rq_suf, a), row(self.rq_pre, last))
         lo, hi = ba + 1, bl - 1
@@ -92,24 +108,25 @@ class WalkModel:
     def place_chunked(self, S, root_score, C):
         """The walk cut into C independent jobs, combined like k_finalize_jobs."""
         nb = self.chunk_bounds(S, C)
-        bs, br, cnt = root_score + 1, 0xFFFFFFFF, 0
+        bs, br, cnt, bhu = root_score + 1, 0xFFFFFFFF, 0, 0
         for c in range(C):
-            s, r, k = self.place(S, root_score, nb[c], nb[c + 1])
+            s, r, k, hu = self.place(S, root_score, nb[c], nb[c + 1])
             if k == 0:
                 continue
             if s < bs:
-                bs, br, cnt = s, r, k
+                bs, br, cnt, bhu = s, r, k, hu
             elif s == bs:
                 cnt += k
-                br = min(br, r)
-        return bs, br, cnt
+                if r < br:
+                    br, bhu = r, hu
+        return bs, br, cnt, bhu
 
     def place(self, S, root_score, start=0, stop_at=None):
         """S = [(pos, ref, mut, missing)] sorted by position.  Returns (score, rank, count) over the
         nodes [start, stop_at) (default: the whole stream)."""
         n_end = self.n if stop_at is None else stop_at
         c = sum(1 for (_, sref, a, missing) in S if not missing and (a & sref) == 0)
-        bs, br, cnt = root_score + 1, 0xFFFFFFFF, 0
+        bs, br, cnt, bhu = root_score + 1, 0xFFFFFFFF, 0, 0
         npos = len(self.ix_off) - 1
         cur = [int(self.ix_off[p]) if p < npos else None for (p, _, _, _) in S]
         stack = []                                # (end, delta) of the open intervals
@@ -147,22 +164,23 @@ class WalkModel:
         head = [int(self.ix_node[q]) if q is not None else IX_NONE for q in cur]
         pos = start
 
-        def take(score, rank, k):
-            nonlocal bs, br, cnt
+        def take(score, rank, k, hu):
+            nonlocal bs, br, cnt, bhu
             if score < bs:
-                bs, br, cnt = score, rank, k
+                bs, br, cnt, bhu = score, rank, k, hu
             elif score == bs:
                 cnt += k
-                br = min(br, rank)
+                if rank < br:
+                    br, bhu = rank, hu
 
         def segment(a, b):
             self.n_segments += 1
             m = self.range_min(a, b)
             if m != SP_NONE and (m >= SP_CLAMP or m + c <= bs):
                 self.n_exact += 1
-                base, rank, k = self.range_exact(a, b)
+                base, rank, k, hu = self.range_exact(a, b)
                 if k and base + c <= bs:
-                    take(base + c, rank, k)
+                    take(base + c, rank, k, hu)
 
         while True:
             i_next = min(head) if head else IX_NONE
@@ -196,6 +214,7 @@ class WalkModel:
                 head[j] = int(self.ix_node[q + 1])
             root, masked, leaf = bool(st & NS_ROOT), bool(st & NS_MASKED), bool(st & NS_LEAF)
             nmut, ncom0 = st & NS_CNT, (st >> 14) & NS_CNT
+            hu = 0
             if root:
                 elig, score = True, base + c + dsum
             elif masked:
@@ -204,16 +223,20 @@ class WalkModel:
                 score = base + c + adj
                 ncom = ncom0 + dcom
                 elig = (ncom > 0) if leaf else (ncom > 0 or ncom == nmut)
+                hu = int(ncom < nmut)
             if elig and score <= bs:
-                take(score, rank, 1)
+                take(score, rank, 1, hu)
             if dsum != 0 and end > node + 1:
                 stack.append((end, dsum))
                 self.max_stack = max(self.max_stack, len(stack))
             c += dsum
             pos = node + 1
-        return bs, br, cnt
+        return bs, br, cnt, bhu
+
+    def whole_stream(self):
+        """The stream-wide aggregate (Stream::whole): what a read without any event in the stream takes."""
+        return self.range_exact(0, self.n)
 
     def result(self, S, root_score, C=1):
-        bs, br, cnt = self.place(S, root_score) if C == 1 else self.place_chunked(S, root_score, C)
-        d = int(self.rank2dfs[br])
-        return bs, int(self.dfs2bfs[d]), cnt
+        bs, br, cnt, hu = self.place(S, root_score) if C == 1 else self.place_chunked(S, root_score, C)
+        return bs, int(self.rank2bfs[br]), cnt, hu

@@ -203,7 +203,7 @@ class GenTree:
 class FlatView:
     """Host-only view of the flattened MAT (wepp_flat_*), for the CPU tests."""
 
-    _DT = {"nkey": np.int64, "ev_meta": np.uint8, "ev_lb": np.uint8, "sp": np.uint8, "maxnest": np.uint8}
+    _DT = {"nkey": np.int64, "ev_meta": np.uint8, "ev_lb": np.uint8, "sp": np.uint8, "maxnest": np.uint8, "ix_nest": np.uint8}
 
     def __init__(self, tree):
         self._tree = tree
@@ -231,9 +231,10 @@ class FlatView:
         check(lib.wepp_flat_get(self._h, name.encode(), ctypes.byref(data), ctypes.byref(cnt), ctypes.byref(eb)))
         if cnt.value == 0:
             return np.zeros(0, np.uint32)
-        if base in ("rq_pre", "rq_suf", "rq_dst"):
-            raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 3,)).copy()
-            return raw.reshape(-1, 3)   # base, rank, cnt
+        if base in ("rq_pre", "rq_suf", "rq_dst", "ix_ent", "nrec", "ix_head"):
+            width = 2 if base == "ix_head" else 8 if base == "ix_ent" else 4
+            raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * width,)).copy()
+            return raw.reshape(-1, width)   # SegNode: base, rank, cnt, hu; IxEnt: node, end, word, up; NodeRec: base, rank, nstat, -; IxHead: off, first node
         if base == "blk_sum":
             raw = np.ctypeslib.as_array(ctypes.cast(data, _lib.c_u32p), shape=(cnt.value * 8,)).copy()
             return raw.reshape(-1, 8)   # base, rank, cnt, min_all, node0, nn, pad, pad

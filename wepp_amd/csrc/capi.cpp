@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -85,10 +86,11 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     while (d.bm_words < (f.max_pos >> 5) + 1) d.bm_words <<= 1;   // power of two (k_sweep masks the index)
     d.n_streams = (uint32_t)f.streams.size();
     d.root_base = f.root_base;
+    d.walk_eager_nodes = getenv("WEPP_WALK_EAGER_NODES") ? (uint32_t)atoll(getenv("WEPP_WALK_EAGER_NODES")) : WALK_EAGER_MAX_NODES;
     int rc;
 #define UP(dst, vec) if ((rc = upload(h, vec, &dst)) != WEPP_OK) { release(h); return rc; }
     UP(d.node_woff, f.node_woff) UP(d.words, f.words) UP(d.nstat, f.nstat) UP(d.rank2dfs, f.rank2dfs)
-    UP(d.dfs2bfs, f.dfs2bfs)
+    UP(d.dfs2bfs, f.dfs2bfs) UP(d.rank2bfs, f.rank2bfs)
     {
         std::vector<uint32_t> bfs2dfs(f.N);
         for (uint32_t k = 0; k < f.N; k++) bfs2dfs[f.dfs2bfs[k]] = k;
@@ -127,11 +129,9 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
             DevWalk dw{};
             dw.n = st.n;
             dw.rq_blocks = st.rq_blocks;
-            dw.last_ent = (uint32_t)st.ix_node.size() - 1;
-            dw.nkey = ds.nkey;
-            dw.nstat = ds.nstat;
-            UP(dw.ix_off, st.ix_off) UP(dw.ix_node, st.ix_node) UP(dw.ix_end, st.ix_end) UP(dw.ix_word, st.ix_word)
-            UP(dw.ix_up, st.ix_up)
+            dw.last_ent = (uint32_t)st.ix_ent.size() - 1;
+            dw.whole = st.whole;
+            UP(dw.ix_head, st.ix_head) UP(dw.ix_ent, st.ix_ent) UP(dw.ix_nest, st.ix_nest) UP(dw.nrec, st.nrec)
             UP(dw.rq_pre, st.rq_pre) UP(dw.rq_suf, st.rq_suf) UP(dw.rq_dst, st.rq_dst) UP(dw.sp, st.sp)
             h->walks.push_back(dw);
         }
@@ -265,6 +265,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
     uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
 
+    static const uint32_t job_events = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS"))) : WALK_JOB_EVENTS;
     static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
@@ -272,7 +273,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         // previous k_route), and this k_route clears the other one for the next call
         tier_info = mat->d_info + mat->info_idx * TI_WORDS;
         uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
-        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_n, tier_of, root_score, blk_counts,
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, stream));
         mat->info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
@@ -438,6 +439,9 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + (walkc.n ? 1u : 0u);
     const bool fork = !unfused && (n_other + n_walk_chains > 0) && (n_plain > 0 || n_other + n_walk_chains > 1);
     if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
+    // the side streams join the caller's stream only after everything has been launched: a join in between
+    // would make the launches behind it wait for the side stream's kernels
+    uint32_t joins[MAX_STREAMS], n_joins = 0;
     if (walks) {
         // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
         // sweeps run side by side (the walks wait on memory most of the time)
@@ -448,7 +452,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                                 d_num_best, d_flags, mat->d_work, q));
         if (fork) {
             HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
-            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[MAX_STREAMS - 1], 0));
+            joins[n_joins++] = MAX_STREAMS - 1;
             q = mat->side[MAX_STREAMS - 2];
             if (walkc.n) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         }
@@ -486,7 +490,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                                          d_num_best, d_flags, q));
             if (fork) {
                 HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 2], q));
-                HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[MAX_STREAMS - 2], 0));
+                joins[n_joins++] = MAX_STREAMS - 2;
             }
         }
     }
@@ -504,7 +508,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (fork && (k + (MAX_STREAMS - 2) >= n_other)) {
             // the last launch on every side stream joins the caller's stream
             HIP_TRY(hipEventRecord(mat->join_ev[k % (MAX_STREAMS - 2)], q));
-            HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[k % (MAX_STREAMS - 2)], 0));
+            joins[n_joins++] = k % (MAX_STREAMS - 2);
         }
     }
     if (n_plain) {
@@ -533,6 +537,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
                                       stream));
     }
+    for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[joins[i]], 0));
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
     mat->n_timed++;
     mat->last_passes = passes;
@@ -893,5 +898,20 @@ extern "C" int wepp_mat_last_walk(wepp_mat_t* mat, uint64_t* reads_walked, uint6
     }
     if (reads_walked) *reads_walked = mat->last_walk_reads;
     if (walk_iterations) *walk_iterations = it;
+    if (getenv("WEPP_WALK_DEBUG")) {
+        std::vector<unsigned long long> slots(WALK_COUNTERS);
+        HIP_TRY(hipMemcpy(slots.data(), mat->d_work, WALK_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long a = 0, b = 0;
+        for (uint32_t i = 0; i < WALK_COUNTERS / 2; i++) { a += slots[i]; b += slots[WALK_COUNTERS / 2 + i]; }
+        fprintf(stderr, "[walk] wave-iterations since reset: plain %llu chunked %llu\n", a, b);
+        // -DWEPP_WALK_STATS builds: slots 0..6 / 16..22 = wave cycles by phase (decode, stage, start state, walk, write), waves, iterations
+        for (int c = 0; c < 2; c++) {
+            const unsigned long long* v = slots.data() + c * 16;
+            if (v[5] && v[5] < (1ull << 40))
+                fprintf(stderr, "[walk stats] %s: waves %llu iterations/wave %.1f cycles/wave: decode %.0f stage %.0f start-state %.0f walk %.0f write %.0f\n",
+                        c ? "chunked" : "plain", v[5], (double)v[6] / v[5], (double)v[0] / v[5], (double)v[1] / v[5], (double)v[2] / v[5],
+                        (double)v[3] / v[5], (double)v[4] / v[5]);
+        }
+    }
     return WEPP_OK;
 }

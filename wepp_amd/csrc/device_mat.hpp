@@ -41,22 +41,21 @@ struct DevStream {
 // the position index and range-query structures of one stream (flatmat.hpp), for k_walk
 struct DevWalk {
     uint32_t n, rq_blocks, last_ent, pad;   // nodes, blocks of the exact range query, index of the last (sentinel) entry
-    const uint32_t* ix_off;
-    const uint32_t* ix_node;
-    const uint32_t* ix_end;
-    const uint32_t* ix_word;
-    const uint32_t* ix_up;
+    SegNode whole;                          // aggregate of the whole stream
+    const IxHead* ix_head;
+    const IxEnt* ix_ent;
+    const uint8_t* ix_nest;
+    const NodeRec* nrec;
     const SegNode* rq_pre;
     const SegNode* rq_suf;
     const SegNode* rq_dst;
     const uint8_t* sp;
-    const int64_t* nkey;
-    const uint32_t* nstat;
 };
 
 // tree-wide arrays (global DFS indices)
 struct DevMAT {
     uint32_t N, bm_words, max_pos, n_streams;
+    uint32_t walk_eager_nodes;    // streams up to this many nodes: exact range query without the sparse pre-test
     int32_t root_base;
     int32_t tau[MAX_STREAMS];
     const uint32_t* node_woff;
@@ -64,6 +63,7 @@ struct DevMAT {
     const uint32_t* nstat;
     const uint32_t* rank2dfs;
     const uint32_t* dfs2bfs;
+    const uint32_t* rank2bfs;     // BFS index of the node with tie-break rank r
     const uint32_t* bfs2dfs;      // inverse of dfs2bfs
     const uint32_t* parent_dfs;   // DFS index of the parent (root: 0)
     const uint8_t* maxnest;       // [max_pos + 1] most mutations at one position along a root path
@@ -81,6 +81,7 @@ constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC =
 // a job finds the state of a sequential walk at its first node by binary searches in the read's lists and
 // the chains of enclosing entries (ix_up) -- whose (score, rank, count) partials k_finalize_jobs combines.
 constexpr uint32_t WALK_JOB_EVENTS = 32;
+constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 48;   // reads with more events at their positions (in their stream) are swept
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
 constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
@@ -139,7 +140,7 @@ constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chain
 // route: tier of every read + per-(block, tier) counts and per-tier max entries; also clears tier_info_next,
 // the counters the next call will use (they must be zero before its k_route)
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint32_t walk_max_events, uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
+                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
                         uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)

@@ -156,48 +156,58 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
     // ---- position index and range-query tables of the walk ------------------------------
     {
         const uint32_t np = f.max_pos + 1;
-        st.ix_off.assign((size_t)np + 1, 0);
+        std::vector<uint32_t> off((size_t)np + 1, 0);
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t g = sel[i];
-            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) st.ix_off[(f.words[w] & W_POS_MASK) + 1]++;
+            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) off[(f.words[w] & W_POS_MASK) + 1]++;
         }
-        for (uint32_t p = 0; p < np; p++) st.ix_off[p + 1] += st.ix_off[p] + 1;   // + the sentinel of list p
-        const size_t total = st.ix_off[np];
-        st.ix_node.assign(total, IX_NONE);
-        st.ix_end.assign(total, 0);
-        st.ix_word.assign(total, W_PAD);
-        std::vector<uint32_t> fill(st.ix_off.begin(), st.ix_off.end() - 1);
+        for (uint32_t p = 0; p < np; p++) off[p + 1] += off[p] + 1;   // + the sentinel of list p
+        const size_t total = off[np];
+        st.ix_ent.assign(total, IxEnt{IX_NONE, 0, W_PAD, IX_NONE, IX_NONE, SCORE_INF, 0xFFFFFFFFu, 0});
+        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
         for (uint32_t i = 0; i < n; i++) {          // ascending node index: every list ends up in stream order
             const uint32_t g = sel[i];
             for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
-                const uint32_t e = fill[f.words[w] & W_POS_MASK]++;
-                st.ix_node[e] = i;
-                st.ix_end[e] = lend[i] + 1;
-                st.ix_word[e] = f.words[w];
+                IxEnt& e = st.ix_ent[fill[f.words[w] & W_POS_MASK]++];
+                e.node = i;
+                e.end = lend[i] + 1;
+                e.word = f.words[w];
+                e.base = (int32_t)(st.nkey[i] >> 32);
+                e.rank = (uint32_t)(st.nkey[i] & 0xFFFFFFFFll);
+                e.nstat = st.nstat[i];
             }
         }
+        for (size_t e = 0; e + 1 < total; e++) st.ix_ent[e].next_node = st.ix_ent[e + 1].node;   // (a sentinel's is never read)
+        st.ix_head.resize((size_t)np + 1);
+        for (uint32_t p = 0; p <= np; p++) st.ix_head[p] = IxHead{off[p], p < np ? st.ix_ent[off[p]].node : IX_NONE};
         // innermost enclosing entry of every entry of a list: the subtrees are nested, so a stack of the
         // entries still open does it
-        st.ix_up.assign(total, IX_NONE);
+        st.ix_nest.assign(np, 0);
         {
             std::vector<uint32_t> open;
             for (uint32_t p = 0; p < np; p++) {
                 open.clear();
-                for (uint32_t e = st.ix_off[p]; e + 1 < st.ix_off[p + 1]; e++) {
-                    while (!open.empty() && st.ix_end[open.back()] <= st.ix_node[e]) open.pop_back();
-                    if (!open.empty()) st.ix_up[e] = open.back();
+                size_t deepest = 0;
+                for (uint32_t e = off[p]; e + 1 < off[p + 1]; e++) {
+                    while (!open.empty() && st.ix_ent[open.back()].end <= st.ix_ent[e].node) open.pop_back();
+                    if (!open.empty()) st.ix_ent[e].up = open.back();
                     open.push_back(e);
+                    deepest = std::max(deepest, open.size());
                 }
+                st.ix_nest[p] = (uint8_t)std::min<size_t>(deepest, 255);
             }
         }
-        const SegNode none{SCORE_INF, 0xFFFFFFFFu, 0};
+        st.nrec.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+            st.nrec[i] = NodeRec{(int32_t)(st.nkey[i] >> 32), (uint32_t)(st.nkey[i] & 0xFFFFFFFFll), st.nstat[i], 0};
+        const SegNode none{SCORE_INF, 0xFFFFFFFFu, 0, 0};
         auto join = [](const SegNode& a, const SegNode& b) {
             if (b.base < a.base) return b;
             if (b.base > a.base) return a;
-            return SegNode{a.base, std::min(a.rank, b.rank), a.cnt + b.cnt};
+            return SegNode{a.base, std::min(a.rank, b.rank), a.cnt + b.cnt, b.rank < a.rank ? b.hu : a.hu};
         };
         st.sp_levels = 1;
-        while ((2u << (st.sp_levels - 1)) <= n) st.sp_levels++;      // levels 0 .. floor(log2 n)
+        while ((1u << (st.sp_levels - 1)) < n) st.sp_levels++;       // levels 0 .. ceil(log2 n): the last one spans the stream from any start
         st.sp.assign((size_t)st.sp_levels * n, SP_NONE);
         st.rq_pre.assign(n, none);
         st.rq_suf.assign(n, none);
@@ -206,16 +216,22 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
         while ((1u << st.rq_levels) < st.rq_blocks) st.rq_levels++;   // rows 0 .. highest bit two block indices can differ in
         st.rq_dst.assign((size_t)st.rq_levels * st.rq_blocks, none);
         auto leaf = [&](uint32_t i) {
-            if (!(st.nstat[i] & NS_ELIG0)) return none;
-            return SegNode{(int32_t)(st.nkey[i] >> 32), (uint32_t)(st.nkey[i] & 0xFFFFFFFFll), 1};
+            const uint32_t ns = st.nstat[i];
+            if (!(ns & NS_ELIG0)) return none;
+            // has_unique of a node no listed position touches (usher_mapper.cpp:184,199,262): some mutation the
+            // sample does not share -- never for the root, always behind a masked mutation
+            const uint32_t hu = (ns & NS_ROOT) ? 0u : (ns & NS_MASKED) ? 1u : (((ns >> 14) & NS_CNT_MASK) < (ns & NS_CNT_MASK) ? 1u : 0u);
+            return SegNode{(int32_t)(st.nkey[i] >> 32), (uint32_t)(st.nkey[i] & 0xFFFFFFFFll), 1, hu};
         };
         for (uint32_t i = 0; i < n; i++)
             if (st.nstat[i] & NS_ELIG0) st.sp[i] = (uint8_t)std::max(0, std::min<int32_t>((int32_t)(st.nkey[i] >> 32), SP_CLAMP));
+        st.whole = none;
         for (uint32_t b = 0; b < st.rq_blocks; b++) {
             const uint32_t lo = b * RQ_BLK, hi = std::min(n, lo + RQ_BLK);
             SegNode run = none;
             for (uint32_t i = lo; i < hi; i++) { run = join(run, leaf(i)); st.rq_pre[i] = run; }
             st.rq_dst[b] = run;
+            st.whole = join(st.whole, run);
             run = none;
             for (uint32_t i = hi; i-- > lo;) { run = join(run, leaf(i)); st.rq_suf[i] = run; }
         }
@@ -238,7 +254,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
             const uint32_t half = 1u << (l - 1);
             const uint8_t* lo = st.sp.data() + (size_t)(l - 1) * n;
             uint8_t* hi = st.sp.data() + (size_t)l * n;
-            for (uint32_t i = 0; i + (half << 1) <= n; i++) hi[i] = std::min(lo[i], lo[i + half]);
+            for (uint32_t i = 0; i < n; i++) hi[i] = i + half < n ? std::min(lo[i], lo[i + half]) : lo[i];
         }
     }
     // checkpoints
@@ -484,6 +500,8 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
         f.nkey[d] = ((int64_t)base[d] << 32) | (int64_t)r;
     }
 
+    f.rank2bfs.resize(N);
+    for (uint32_t r = 0; r < N; r++) f.rank2bfs[r] = f.dfs2bfs[f.rank2dfs[r]];
     f.root_base = base[0];
 
     // ---- sweep streams: crowns of increasing tau, then the whole tree ------------

@@ -57,11 +57,32 @@ struct BlkSum {          // read-independent summary of one sweep block
 };
 
 // Aggregate of a range of stream nodes, as the walk's range queries return it: the best statically
-// eligible node (static score, its tie-break rank, how many tie it); identity = {SCORE_INF, ~0, 0}
+// eligible node (static score, its tie-break rank, how many tie it, and whether the node of that rank has
+// mutations the sample does not share -- the has_unique flag of a node no listed position touches);
+// identity = {SCORE_INF, ~0, 0, 0}.  16 bytes: one load.
 struct SegNode {
     int32_t base;
     uint32_t rank;
     uint32_t cnt;
+    uint32_t hu;
+};
+// One entry of a stream's position index: a mutation of stream node `node` at the list's position; the
+// nodes that inherit the allele are (node, end); `up` = entry (same list) of the innermost enclosing
+// mutation of the position or IX_NONE; `next_node` = node of the list's next entry (IX_NONE at the end);
+// base / rank / nstat = the node's own record, so that a walk reads ONE 32-byte record per event.  The last
+// entry of every list is a sentinel (node == IX_NONE).
+struct IxEnt {
+    uint32_t node, end, word, up;
+    uint32_t next_node;
+    int32_t base;
+    uint32_t rank, nstat;
+};
+struct IxHead {            // per position: first entry of its list and that entry's node (IX_NONE: empty list)
+    uint32_t off, first_node;
+};
+struct NodeRec {           // per stream node: static score, tie-break rank, flags (flatmat.hpp NS_*)
+    int32_t base;
+    uint32_t rank, nstat, pad;
 };
 constexpr uint32_t RQ_BLK = 16;              // nodes per block of the exact range query
 constexpr uint32_t IX_NONE = 0xFFFFFFFFu;    // sentinel node index closing every position's list
@@ -90,26 +111,29 @@ struct Stream {
     std::vector<uint32_t> cp_off;      // [ncp+1]
     std::vector<uint32_t> cp_word;
     // ---- the same crown addressed by genome position, for the per-read walk (k_walk) ----
-    // list of position p = entries [ix_off[p], ix_off[p+1]) in stream order, the last one a sentinel
-    // (ix_node == IX_NONE): the mutations of the stream's nodes at p with the node's local index, one past
-    // the last local index of its subtree (the nodes that inherit the allele are (node, end)), and the word
-    std::vector<uint32_t> ix_off;      // [max_pos + 2]
-    std::vector<uint32_t> ix_node, ix_end, ix_word;
-    std::vector<uint32_t> ix_up;       // entry (same list) of the innermost enclosing mutation of the position, or
-                                       // IX_NONE: lets a walk that starts mid-stream find the intervals open there
+    // list of position p = entries [ix_head[p].off, ix_head[p+1].off) in stream order, the last one a sentinel
+    std::vector<IxHead> ix_head;       // [max_pos + 2]
+    std::vector<IxEnt> ix_ent;
+    std::vector<uint8_t> ix_nest;      // [max_pos + 1] most entries of a position's list open at once (nested subtrees
+                                       // INSIDE this stream), clamped to 255: bounds the stack of a walking read
+    std::vector<NodeRec> nrec;         // [n]
     // range queries over the statically eligible nodes.
     // (1) "can anything in [a, b) matter": a sparse table of the minimum score, sp[l * n + i] = min over
-    //     [i, i + 2^l) clamped to SP_CLAMP, SP_NONE when the range holds no eligible node: two byte loads.
-    // (2) the exact (score, rank, count) of [a, b): nodes are grouped in blocks of RQ_BLK; rq_pre[i] /
-    //     rq_suf[i] aggregate a node's block up to / from the node, and rq_dst is a disjoint sparse table
-    //     over the block aggregates (row 0 = the blocks; row l, entry i = the aggregate from block i to the
-    //     middle of its 2^(l+1)-aligned group of blocks, towards that middle): a range that spans blocks is
-    //     suffix + table[l][first whole block] + table[l][last whole block] + prefix, l = the highest bit in
-    //     which the two block indices differ -- four independent loads, whatever the range.
+    //     [i, min(n, i + 2^l)) clamped to SP_CLAMP, SP_NONE when the range holds no eligible node.  The walk
+    //     reads ONE byte: the entry at `a` of the first level whose 2^l reaches b -- a superset of the range
+    //     (at most twice as long), so a miss is exact and a hit only means "ask the exact query".
+    // (2) the exact aggregate of [a, b): nodes are grouped in blocks of RQ_BLK; rq_pre[i] / rq_suf[i]
+    //     aggregate a node's block up to / from the node, and rq_dst is a disjoint sparse table over the
+    //     block aggregates (row 0 = the blocks; row l, entry i = the aggregate from block i to the middle of
+    //     its 2^(l+1)-aligned group of blocks, towards that middle): a range that spans blocks is suffix +
+    //     table[l][first whole block] + table[l][last whole block] + prefix, l = the highest bit in which the
+    //     two block indices differ -- four independent loads, whatever the range.
     uint32_t sp_levels = 1, rq_blocks = 0, rq_levels = 1;
     std::vector<uint8_t> sp;           // [sp_levels * n]
     std::vector<SegNode> rq_pre, rq_suf;   // [n]
     std::vector<SegNode> rq_dst;       // [rq_levels * rq_blocks]
+    SegNode whole{};                   // aggregate of the whole stream: the answer for a read none of whose
+                                       // positions is mutated in the stream
     // bytes one sweep reads whatever the reads are: event words, block offsets and summaries, and -- on
     // a crown (tau finite), where the per-event bounds are fetched with the event words -- one bound byte
     // per event; node keys / flags / event offsets are only touched by node-by-node evaluations
@@ -130,6 +154,7 @@ struct FlatMAT {
     std::vector<uint32_t> nstat;       // [N]
     std::vector<uint32_t> rank2dfs;    // [N]
     std::vector<uint32_t> dfs2bfs;     // [N] BFS index j of each node (tie-break key, usher_common.cpp:391,400)
+    std::vector<uint32_t> rank2bfs;    // [N] BFS index of the node with tie-break rank r (what a winner is reported as)
     std::vector<uint32_t> bfs2id;      // [N] caller id of bfs[k]            (host only)
     std::vector<uint32_t> dfs2id;      // [N] caller id of dfs[k]            (host only)
     std::vector<uint32_t> parent_dfs;  // [N] DFS index of parent (root: 0)  (host only)

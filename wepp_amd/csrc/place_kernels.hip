@@ -163,7 +163,7 @@ __device__ __forceinline__ uint32_t find_entry(SPtr S, uint32_t off, uint32_t k,
 // -----------------------------------------------------------------------------
 __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_t* __restrict__ read_off,
                                                           const uint32_t* __restrict__ read_word, uint32_t n_reads,
-                                                          int use_crowns, uint32_t walk_max_events,
+                                                          int use_crowns, uint32_t walk_max_events, uint32_t job_events,
                                                           uint32_t* __restrict__ job_n, uint8_t* __restrict__ tier_of,
                                                           int32_t* __restrict__ root_score,
                                                           uint32_t* __restrict__ blk_counts,
@@ -221,12 +221,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         uint32_t cls = PLAN_SWEEP;
         if (walk_max_events && k <= WALK16_K) {
             uint32_t open_max = 0, events = 0, longest = 0;
-            const uint32_t* ix_off = m.walks[t].ix_off;
+            const IxHead* ix_head = m.walks[t].ix_head;
+            const uint8_t* ix_nest = m.walks[t].ix_nest;
             for (uint32_t j = 0; j < k; j++) {
                 const uint32_t p = w_pos(j < 2 ? fw[u][j] : read_word[so + j]);
                 if (p <= m.max_pos) {
-                    open_max += (uint32_t)m.maxnest[p];
-                    const uint32_t len = ix_off[p + 1] - ix_off[p] - 1u;      // (every list ends in a sentinel)
+                    open_max += (uint32_t)ix_nest[p];
+                    const uint32_t len = ix_head[p + 1].off - ix_head[p].off - 1u;      // (every list ends in a sentinel)
                     events += len;
                     longest = max(longest, len);
                 }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             } else if (open_max <= WALK16_STACK) {
                 // many events: jobs of about WALK_JOB_EVENTS, cut at quantiles of the longest list
                 cls = PLAN_WALKC;
-                const uint32_t nj = min((events + WALK_JOB_EVENTS - 1) / WALK_JOB_EVENTS, longest);
+                const uint32_t nj = min((events + job_events - 1) / job_events, longest);
                 job_n[r] = nj;
                 atomicAdd(&jobs_of[t], nj);
             }
@@ -1103,6 +1104,13 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
     uint32_t* stk = cur_l + KW * 64;
     const uint32_t unit = blockIdx.x * 4 + wv;
     if (unit >= pl.p[pl.n - 1].wave_end) return;
+#ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
+    unsigned long long ts_[6];
+    ts_[0] = __builtin_amdgcn_s_memtime();
+#define WALK_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); ts_[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WALK_STAMP(i)
+#endif
     uint32_t pi = 0;
     while (pi + 1 < pl.n && unit >= pl.p[pi].wave_end) pi++;
     const WalkPlanDev& q = pl.p[pi];
@@ -1113,21 +1121,38 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
     // plain: a lane = a read of the plan's list.  CHUNKED: a lane = a job = (read, chunk of its walk)
     uint32_t rd = 0, chunk = 0, n_chunks = 1, job = 0;
     if (CHUNKED) {
+        // the read a job belongs to = the last list position whose first job is <= job (job_off ascends).
+        // The wave's jobs are consecutive: its first job is located by a bisection on wave-uniform values
+        // (scalar loads), the other lanes' reads lie within the next 64 list positions, whose offsets go to
+        // LDS for a short per-lane bisection.
+        const uint32_t job_first = q.job0 + tile * 64;
+        uint32_t lo = 0, hi = jb.n_list;                  // invariant: job_off[lo] <= job_first < job_off[hi] (or hi == n_list)
+        while (hi - lo > 1) {
+            const uint32_t mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)((lo + hi) >> 1));
+            if (jb.job_off[mid] <= job_first) lo = mid; else hi = mid;
+        }
+        const uint32_t lp0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        stk[lane] = lp0 + 1 + lane < jb.n_list ? jb.job_off[lp0 + 1 + lane] : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (have) {
-            // the read a job belongs to: last list position whose first job is <= job (job_off ascends)
-            job = q.job0 + slot;
-            uint32_t lo = 0, hi = jb.n_list;              // invariant: job_off[lo] <= job, job_off[hi] > job (or hi == n)
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (jb.job_off[mid] <= job) lo = mid; else hi = mid;
+            job = job_first + lane;
+            uint32_t a = 0, b = 64;                       // number of the 64 offsets that are <= job
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (stk[mid] <= job) a = mid + 1; else b = mid;
             }
-            rd = q.list[lo];
-            chunk = job - jb.job_off[lo];
+            const uint32_t lp = lp0 + a;
+            rd = q.list[lp];
+            chunk = job - (a ? stk[a - 1] : jb.job_off[lp0]);
             n_chunks = jb.job_n[rd];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     } else {
         rd = have ? q.list[slot] : 0u;
     }
+    WALK_STAMP(1);          // job / read decoded
     const uint32_t so = have ? read_off[rd] : 0u;
     const uint32_t k = have ? read_off[rd + 1] - so : 0u;
     const int root_sc = have ? root_score[rd] : 0;
@@ -1143,18 +1168,21 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
             const uint32_t w = read_word[so + j];
             const uint32_t p = w_pos(w);
             // a position beyond the tree's last mutated one has no list: the last sentinel stands in
-            const uint32_t e = p <= m.max_pos ? ix.ix_off[p] : ix.last_ent;
+            IxHead h{ix.last_ent, NONE};
+            if (p <= m.max_pos) h = ix.ix_head[p];
+            const uint32_t e = h.off;
             S_l[j * 64 + lane] = w;
             cur_l[j * 64 + lane] = e;
             if (CHUNKED) {
-                const uint32_t len = p <= m.max_pos ? ix.ix_off[p + 1] - e - 1u : 0u;
+                const uint32_t len = p <= m.max_pos ? ix.ix_head[p + 1].off - e - 1u : 0u;
                 if (len > long_len) { long_len = len; long_off = e; }
             } else {
-                head[j] = ix.ix_node[e];
+                head[j] = h.first_node;
             }
             if (!rw_missing(w)) c += ((rw_mut(w) & rw_ref(w)) == 0) ? 1 : 0;
         }
     }
+    WALK_STAMP(2);          // words and list heads staged
     uint32_t n = ix.n;              // one past the last node this lane looks at
     uint32_t pos = 0;               // next node nobody has looked at
     uint32_t sp = 0;                // open intervals on the stack
@@ -1163,8 +1191,8 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
     if (CHUNKED) {
         // this job's nodes [pos, n): cut at the quantiles of the longest list (k_route made sure it has at
         // least n_chunks entries)
-        if (chunk + 1 < n_chunks) n = ix.ix_node[long_off + (uint32_t)(((uint64_t)(chunk + 1) * long_len) / n_chunks)];
-        if (chunk) pos = ix.ix_node[long_off + (uint32_t)(((uint64_t)chunk * long_len) / n_chunks)];
+        if (chunk + 1 < n_chunks) n = ix.ix_ent[long_off + (uint32_t)(((uint64_t)(chunk + 1) * long_len) / n_chunks)].node;
+        if (chunk) pos = ix.ix_ent[long_off + (uint32_t)(((uint64_t)chunk * long_len) / n_chunks)].node;
         // ---- the state of a sequential walk when it reaches `pos` ----
         // every list's cursor at its first entry >= pos: binary searches, four lists side by side (their
         // loads in flight together); cursors and words live in LDS, so the loops over the lists stay rolled
@@ -1179,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
                 if (j0 + u < k && mid_stream) {
                     const uint32_t p = w_pos(S_l[(j0 + u) * 64 + lane]);
                     lo[u] = cur_l[(j0 + u) * 64 + lane];
-                    hi[u] = p <= m.max_pos ? ix.ix_off[p + 1] - 1u : lo[u];       // (the sentinel stays out)
+                    hi[u] = p <= m.max_pos ? ix.ix_head[p + 1].off - 1u : lo[u];       // (the sentinel stays out)
                 }
             }
             // first entry of the list goes to the stack region for a moment: the predecessor test below needs it
@@ -1189,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
                 uint32_t probe[4];
                 searching = false;
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) probe[u] = lo[u] < hi[u] ? ix.ix_node[(lo[u] + hi[u]) >> 1] : 0u;
+                for (uint32_t u = 0; u < 4; u++) probe[u] = lo[u] < hi[u] ? ix.ix_ent[(lo[u] + hi[u]) >> 1].node : 0u;
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     if (lo[u] < hi[u]) {
@@ -1208,19 +1236,25 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
                     const uint32_t sw = S_l[(j0 + u) * 64 + lane];
                     cur_l[(j0 + u) * 64 + lane] = lo[u];
                     uint32_t e = lo[u] > first ? lo[u] - 1u : NONE;
-                    while (e != NONE && ix.ix_end[e] <= pos) e = ix.ix_up[e];
+                    IxEnt ent{};
                     while (e != NONE) {
-                        const int d = enter_delta(ix.ix_word[e], sw);
+                        ent = ix.ix_ent[e];
+                        if (ent.end > pos) break;
+                        e = ent.up;
+                    }
+                    while (e != NONE) {
+                        const int d = enter_delta(ent.word, sw);
                         c += d;
                         if (d != 0) {
                             // insertion by subtree end, outermost at the bottom (the intervals are nested)
-                            const uint32_t end = ix.ix_end[e];
+                            const uint32_t end = ent.end;
                             uint32_t at = sp;
                             while (at > 0 && (stk[(at - 1) * 64 + lane] >> 7) < end) { stk[at * 64 + lane] = stk[(at - 1) * 64 + lane]; at--; }
                             stk[at * 64 + lane] = (end << 7) | (uint32_t)(d + 64);
                             sp++;
                         }
-                        e = ix.ix_up[e];
+                        e = ent.up;
+                        if (e != NONE) ent = ix.ix_ent[e];
                     }
                 }
             }
@@ -1232,18 +1266,35 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
         }
 #pragma unroll
         for (int j = 0; j < KW; j++)
-            if ((uint32_t)j < k) head[j] = ix.ix_node[cur_l[j * 64 + lane]];
+            if ((uint32_t)j < k) head[j] = ix.ix_ent[cur_l[j * 64 + lane]].node;
     }
     if (!have) pos = n;
+    WALK_STAMP(3);          // (chunked) start state found
     int bs = root_sc + 1;          // the root always competes: nothing worse can win or tie
-    uint32_t br = 0xFFFFFFFFu, cnt = 0;
+    uint32_t br = 0xFFFFFFFFu, cnt = 0, bhu = 0;
     uint32_t iters = 0;
 
-    auto take = [&](int sc, uint32_t rk, uint32_t kk) {
-        if (sc < bs) { bs = sc; br = rk; cnt = kk; }
-        else if (sc == bs) { cnt += kk; br = min(br, rk); }
+    // a candidate: score, tie-break rank, how many nodes it stands for, has_unique of the node of that rank
+    auto take = [&](int sc, uint32_t rk, uint32_t kk, uint32_t hu) {
+        if (sc < bs) { bs = sc; br = rk; cnt = kk; bhu = hu; }
+        else if (sc == bs) { cnt += kk; if (rk < br) { br = rk; bhu = hu; } }
     };
+    if (!CHUNKED) {
+        // none of the read's positions is mutated in this stream (most reads of the small crowns): every node
+        // scores base + c, and the stream-wide aggregate is the answer
+        uint32_t any = head[0];
+#pragma unroll
+        for (int j = 1; j < KW; j++) any = min(any, head[j]);
+        if (pos < n && any == NONE) {
+            if (ix.whole.cnt && ix.whole.base + c <= bs) take(ix.whole.base + c, ix.whole.rank, ix.whole.cnt, ix.whole.hu);
+            pos = n;
+        }
+    }
 
+    // small streams: nearly every range between two events holds a node that can tie the best (a crown is
+    // made of low-score nodes), so the exact query is issued at once, with the other loads of the iteration;
+    // large ones ask the sparse table first (there nearly every range fails it)
+    const bool eager = ix.n <= m.walk_eager_nodes;
     while (__ballot(pos < n)) {
         iters++;
         uint32_t i_next = head[0];
@@ -1251,48 +1302,65 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
         for (int j = 1; j < KW; j++) i_next = min(i_next, head[j]);
         const bool live = pos < n;
         const uint32_t stop = min(min(i_next, top_end), n);
-        // the node of the next event: its static key and flags are requested now, used after the range query
         const bool at_node = live && i_next < top_end && i_next < n;
-        int64_t key = 0;
-        uint32_t nst = 0;
-        if (at_node) { key = ix.nkey[i_next]; nst = ix.nstat[i_next]; }
+        // ---- everything this iteration reads from memory is requested here, together ----
+        // the node of the next event: its record, the list entry that carries it and that list's next node
+        IxEnt ent{};
+        uint32_t sw = 0, ecur = 0;
+        int js = 0;
+        if (at_node) {
+#pragma unroll
+            for (int j = KW - 1; j >= 0; j--) js = head[j] == i_next ? j : js;
+            sw = S_l[js * 64 + lane];
+            ecur = cur_l[js * 64 + lane];
+            ent = ix.ix_ent[ecur];             // 32 bytes: the mutation, the list's next node and the node's own record
+        }
         // ---- the nodes [pos, stop): none of them carries a listed position, c is constant ----
         if (live && stop > pos) {
-            const uint32_t len = stop - pos;
-            const uint32_t lvl = 31u - (uint32_t)__builtin_clz(len);
-            const uint8_t* row = ix.sp + (size_t)lvl * ix.n;
-            const uint32_t a = row[pos], b = row[stop - (1u << lvl)];
-            const uint32_t mn = min(a, b);
-            const bool pass = mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
+            const uint32_t last = stop - 1;
+            const uint32_t ba = pos / RQ_BLK, bl = last / RQ_BLK;
+            bool pass = true;
+            if (!eager) {
+                // one byte: the minimum over [pos, pos + 2^lvl), the first level that reaches `stop`
+                const uint32_t len = stop - pos;
+                const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
+                const uint32_t mn = ix.sp[(size_t)lvl * ix.n + pos];
+                pass = mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
+            }
             if (__ballot(pass)) {
                 if (pass) {
-                    // exact (score, rank, count) of the best statically eligible node of [pos, stop): suffix of
-                    // the first node's block, disjoint sparse table over the whole blocks in between, prefix of
-                    // the last node's block -- four independent loads (flatmat.hpp)
-                    const uint32_t last = stop - 1;
-                    const uint32_t ba = pos / RQ_BLK, bl = last / RQ_BLK;
-                    int eb = SCORE_INF_DEV;
-                    uint32_t er = 0xFFFFFFFFu, ec = 0;
+                    // exact aggregate of the statically eligible nodes of [pos, stop): suffix of the first node's
+                    // block, disjoint sparse table over the whole blocks in between, prefix of the last node's
+                    // block -- four independent 16-byte loads (flatmat.hpp)
+                    SegNode ag{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
                     auto join = [&](const SegNode x) {
-                        if (x.base < eb) { eb = x.base; er = x.rank; ec = x.cnt; }
-                        else if (x.base == eb) { ec += x.cnt; er = min(er, x.rank); }
+                        if (x.base < ag.base) ag = x;
+                        else if (x.base == ag.base) { ag.cnt += x.cnt; if (x.rank < ag.rank) { ag.rank = x.rank; ag.hu = x.hu; } }
                     };
                     if (ba == bl) {
-                        for (uint32_t i = pos; i < stop; i++) {          // inside one block: node by node
-                            const uint32_t st_i = ix.nstat[i];
-                            const int64_t k_i = ix.nkey[i];
-                            if (st_i & NS_ELIG0_DEV) join(SegNode{(int)(k_i >> 32), (uint32_t)(k_i & 0xFFFFFFFFll), 1u});
-                        }
+                        // inside one block: its prefix up to the last node, unless the range starts behind the
+                        // block's first node -- then node by node
+                        if (pos == ba * RQ_BLK) join(ix.rq_pre[last]);
+                        else if (last + 1 == min(ix.n, (ba + 1) * RQ_BLK)) join(ix.rq_suf[pos]);
+                        else
+                            for (uint32_t i = pos; i < stop; i++) {
+                                const NodeRec x = ix.nrec[i];
+                                if (x.nstat & NS_ELIG0_DEV) {
+                                    const uint32_t hu = (x.nstat & NS_ROOT_DEV) ? 0u : (x.nstat & NS_MASKED_DEV) ? 1u :
+                                                        (((x.nstat >> 14) & NS_CNT_MASK_DEV) < (x.nstat & NS_CNT_MASK_DEV) ? 1u : 0u);
+                                    join(SegNode{x.base, x.rank, 1u, hu});
+                                }
+                            }
                     } else {
                         const uint32_t lo = ba + 1, hi = bl - 1;
-                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u};
+                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
                         const uint32_t L = lo < hi ? 31u - (uint32_t)__builtin_clz(lo ^ hi) : 0u;
                         const SegNode* trow = ix.rq_dst + (size_t)L * ix.rq_blocks;
                         const SegNode s1 = ix.rq_suf[pos], s2 = ix.rq_pre[last];
                         const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
                         join(s1); join(s2); join(s3); join(s4);
                     }
-                    if (ec && eb + c <= bs) take(eb + c, er, ec);
+                    if (ag.cnt && ag.base + c <= bs) take(ag.base + c, ag.rank, ag.cnt, ag.hu);
                 }
             }
             pos = stop;
@@ -1311,47 +1379,47 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
         }
         if (__ballot(at_node)) {
             if (at_node) {
-                // every listed mutation the node carries (nearly always one)
+                // every listed mutation the node carries (nearly always one: the entry fetched above)
                 const uint32_t node = i_next;
                 int adj = 0, dcom = 0, dsum = 0;
-                uint32_t end = 0;
+                const uint32_t end = ent.end;
                 bool more = true;
                 while (more) {
-                    int js = 0;
-#pragma unroll
-                    for (int j = KW - 1; j >= 0; j--) js = head[j] == node ? j : js;
-                    const uint32_t sw = S_l[js * 64 + lane];
-                    const uint32_t e = cur_l[js * 64 + lane];
-                    const uint32_t w = ix.ix_word[e];
-                    end = ix.ix_end[e];
-                    const uint32_t nh = ix.ix_node[e + 1];
-                    cur_l[js * 64 + lane] = e + 1;
-                    own_adjust(w, sw, adj, dcom);
+                    cur_l[js * 64 + lane] = ecur + 1;
+                    own_adjust(ent.word, sw, adj, dcom);
                     // descendants take the allele; the root also scores itself with it (usher_mapper.cpp:266-271)
-                    if (end > node + 1 || node == 0) dsum += enter_delta(w, sw);
+                    if (end > node + 1 || node == 0) dsum += enter_delta(ent.word, sw);
                     more = false;
+                    int jn = 0;
 #pragma unroll
-                    for (int j = 0; j < KW; j++) {
-                        if (j == js) head[j] = nh;
-                        more = more || head[j] == node;
+                    for (int j = KW - 1; j >= 0; j--) {
+                        if (j == js) head[j] = ent.next_node;
+                        if (head[j] == node) { more = true; jn = j; }
+                    }
+                    if (more) {
+                        js = jn;
+                        sw = S_l[js * 64 + lane];
+                        ecur = cur_l[js * 64 + lane];
+                        ent = ix.ix_ent[ecur];
                     }
                 }
-                const int base = (int)(key >> 32);
-                const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
+                const uint32_t nst = ent.nstat;
                 const uint32_t nmut = nst & NS_CNT_MASK_DEV, ncom0 = (nst >> 14) & NS_CNT_MASK_DEV;
                 const bool leaf = nst & NS_LEAF_DEV, masked = nst & NS_MASKED_DEV, root = nst & NS_ROOT_DEV;
                 bool elig;
                 int sc;
-                if (root) { elig = true; sc = base + c + dsum; }
+                uint32_t hu = 0;
+                if (root) { elig = true; sc = ent.base + c + dsum; }
                 else if (masked) { elig = false; sc = 0; }
                 else {
-                    sc = base + c + adj;
+                    sc = ent.base + c + adj;
                     const int ncom = (int)ncom0 + dcom;
                     elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
+                    hu = ncom < (int)nmut ? 1u : 0u;                                // :184,199,262
                 }
-                if (elig && sc <= bs) take(sc, rank, 1u);
+                if (elig && sc <= bs) take(sc, ent.rank, 1u, hu);
                 if (dsum != 0 && end > node + 1) {
-                    // k_route admits a read only if its open intervals always fit (sum of maxnest <= SD)
+                    // k_route admits a read only if its open intervals always fit (sum of ix_nest <= SD)
                     stk[sp * 64 + lane] = (end << 7) | (uint32_t)(dsum + 64);
                     sp++;
                     top_end = end;
@@ -1362,17 +1430,34 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
             }
         }
     }
+    WALK_STAMP(4);          // walked
     if (have) {
         if (CHUNKED) {
             jb.part_score[job] = bs;
             jb.part_rank[job] = br;
-            jb.part_cnt[job] = cnt;
+            jb.part_cnt[job] = (cnt << 1) | bhu;     // (the job's has_unique rides in bit 0)
         } else {
-            emit_result(m, rd, read_off, read_word, bs, br, cnt, best_bfs_j, score_out, num_best, flags);
+            // the root always competes, so br is a rank; the clamp only keeps a broken invariant in bounds
+            if (best_bfs_j) best_bfs_j[rd] = m.rank2bfs[br < m.N ? br : 0u];
+            if (score_out) score_out[rd] = bs;
+            if (num_best) num_best[rd] = cnt;
+            if (flags) flags[rd] = bhu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
         }
     }
     // (1024 counters: thousands of waves adding to ONE address queue up at the memory side)
-    if (work_counter && lane == 0) atomicAdd(work_counter + (unit & (WALK_COUNTERS - 1)), (unsigned long long)iters);
+#ifdef WEPP_WALK_STATS
+    WALK_STAMP(5);          // results written
+    if (work_counter && lane == 0) {
+        unsigned long long* wc = work_counter + (CHUNKED ? 16 : 0);
+        for (int i = 0; i < 5; i++) atomicAdd(wc + i, ts_[i + 1] - ts_[i]);
+        atomicAdd(wc + 5, 1ull);
+        atomicAdd(wc + 6, (unsigned long long)iters);
+    }
+#else
+    // plain walks count in the first half of the slots, chunked ones in the second
+    if (work_counter && lane == 0)
+        atomicAdd(work_counter + (CHUNKED ? WALK_COUNTERS / 2 : 0) + (unit & (WALK_COUNTERS / 2 - 1)), (unsigned long long)iters);
+#endif
 }
 
 // job counts in list order (the input of the scan)
@@ -1382,9 +1467,8 @@ __global__ void k_gather_jobs(const uint32_t* __restrict__ list, uint32_t n_list
     if (i < n_list) out[i] = job_n[list[i]];
 }
 // a wave per 64 reads of the chunked class: a read with few jobs is combined by its own lane, one with many
-// by the whole wave (lane-strided loads, butterfly reduction)
+// by the whole wave (lane-strided loads, butterfly reduction).  part_cnt = (count << 1) | has_unique.
 __global__ __launch_bounds__(256) void k_finalize_jobs(DevMAT m, const uint32_t* __restrict__ list, uint32_t n_list, WalkJobs jb,
-                                const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
                                 uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
                                 uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1393,32 +1477,55 @@ __global__ __launch_bounds__(256) void k_finalize_jobs(DevMAT m, const uint32_t*
     const uint32_t r = valid ? list[i] : 0u;
     const uint32_t j0 = valid ? jb.job_off[i] : 0u, nj = valid ? jb.job_n[r] : 0u;
     int bs = 0x7FFFFFFF;
-    uint32_t br = 0xFFFFFFFFu, cnt = 0;
-    auto take = [&](int& b, uint32_t& rk, uint32_t& ct, int s, uint32_t pr, uint32_t pc) {
+    uint32_t br = 0xFFFFFFFFu, cnt = 0, bhu = 0;
+    auto take = [&](int& b, uint32_t& rk, uint32_t& ct, uint32_t& h, int s, uint32_t pr, uint32_t pc, uint32_t ph) {
         if (pc == 0) return;
-        if (s < b) { b = s; rk = pr; ct = pc; }
-        else if (s == b) { ct += pc; rk = min(rk, pr); }
+        if (s < b) { b = s; rk = pr; ct = pc; h = ph; }
+        else if (s == b) { ct += pc; if (pr < rk) { rk = pr; h = ph; } }
     };
-    constexpr uint32_t SMALL = 8;
-    if (nj <= SMALL)
-        for (uint32_t c = 0; c < nj; c++) take(bs, br, cnt, jb.part_score[j0 + c], jb.part_rank[j0 + c], jb.part_cnt[j0 + c]);
+    constexpr uint32_t SMALL = 48;
+    if (nj <= SMALL) {
+        // (four partials per round: their loads are in flight together)
+        uint32_t c = 0;
+        for (; c + 4 <= nj; c += 4) {
+            uint32_t pc[4], pr[4];
+            int ps[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) { pc[u] = jb.part_cnt[j0 + c + u]; ps[u] = jb.part_score[j0 + c + u]; pr[u] = jb.part_rank[j0 + c + u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) take(bs, br, cnt, bhu, ps[u], pr[u], pc[u] >> 1, pc[u] & 1u);
+        }
+        for (; c < nj; c++) {
+            const uint32_t pc = jb.part_cnt[j0 + c];
+            take(bs, br, cnt, bhu, jb.part_score[j0 + c], jb.part_rank[j0 + c], pc >> 1, pc & 1u);
+        }
+    }
     unsigned long long big = __ballot(nj > SMALL);
     while (big) {
         const int l = __builtin_ctzll(big);
         big &= big - 1;
         const uint32_t bj0 = (uint32_t)__builtin_amdgcn_readlane((int)j0, l), bnj = (uint32_t)__builtin_amdgcn_readlane((int)nj, l);
         int ws = 0x7FFFFFFF;
-        uint32_t wr = 0xFFFFFFFFu, wc = 0;
-        for (uint32_t c = lane; c < bnj; c += 64) take(ws, wr, wc, jb.part_score[bj0 + c], jb.part_rank[bj0 + c], jb.part_cnt[bj0 + c]);
+        uint32_t wr = 0xFFFFFFFFu, wc = 0, wh = 0;
+        for (uint32_t c = lane; c < bnj; c += 64) {
+            const uint32_t pc = jb.part_cnt[bj0 + c];
+            take(ws, wr, wc, wh, jb.part_score[bj0 + c], jb.part_rank[bj0 + c], pc >> 1, pc & 1u);
+        }
 #pragma unroll
         for (int msk = 1; msk < 64; msk <<= 1) {
             const int os = __shfl_xor(ws, msk, 64);
             const uint32_t orr = (uint32_t)__shfl_xor((int)wr, msk, 64), oc = (uint32_t)__shfl_xor((int)wc, msk, 64);
-            take(ws, wr, wc, os, orr, oc);
+            const uint32_t oh = (uint32_t)__shfl_xor((int)wh, msk, 64);
+            take(ws, wr, wc, wh, os, orr, oc, oh);
         }
-        if ((int)lane == l) { bs = ws; br = wr; cnt = wc; }
+        if ((int)lane == l) { bs = ws; br = wr; cnt = wc; bhu = wh; }
     }
-    if (valid) emit_result(m, r, read_off, read_word, bs, br, cnt, best_bfs_j, score, num_best, flags);
+    if (valid) {
+        if (best_bfs_j) best_bfs_j[r] = m.rank2bfs[br < m.N ? br : 0u];
+        if (score) score[r] = bs;
+        if (num_best) num_best[r] = cnt;
+        if (flags) flags[r] = bhu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+    }
 }
 
 // -----------------------------------------------------------------------------
@@ -1687,11 +1794,11 @@ __global__ void k_excess(DevMAT m, const uint32_t* __restrict__ read_off, const 
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint32_t walk_max_events, uint32_t* job_n, uint8_t* tier_of, int32_t* root_score,
-                        uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next,
-                        hipStream_t stream) {
+                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t* job_n, uint8_t* tier_of,
+                        int32_t* root_score, uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk,
+                        uint32_t* tier_info_next, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
-                       n_reads, use_crowns, walk_max_events, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
+                       n_reads, use_crowns, walk_max_events, job_events, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
     return hipGetLastError();
 }
 
@@ -1803,8 +1910,8 @@ hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t 
                                 const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t* best_bfs_j,
                                 int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_finalize_jobs, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, list, n_list, jb, d_read_off,
-                       d_read_word, best_bfs_j, score, num_best, flags);
+    hipLaunchKernelGGL(k_finalize_jobs, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, list, n_list, jb,
+                       best_bfs_j, score, num_best, flags);
     return hipGetLastError();
 }
 
