@@ -303,33 +303,32 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t bm_bytes = mat->dev.bm_words * 4;
     if (bm_bytes > 128 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
     // walk plans (device_mat.hpp): the reads of one (class, stream) that walk their own events
-    WalkPlans walk[2]{}, walkc{};
-    uint64_t walk_reads = 0, n_jobs = 0;
-    uint32_t walkc_reads = 0;
-    // a walk is one wave per 64 reads, each running its reads' events one after the other: a handful of reads
-    // on a large stream (thousands of events per read) is placed faster by a sweep cut into many chunks
-    static const uint32_t walk_min_reads = getenv("WEPP_WALK_MIN_READS") ? (uint32_t)atoi(getenv("WEPP_WALK_MIN_READS")) : 2048;
+    WalkPlans walk[2]{}, walkc[2]{};
+    uint64_t walk_reads = 0, n_jobs[2] = {0, 0};
+    uint32_t walkc_reads[2] = {0, 0};
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
         const uint32_t t = id & 15u, cls = id >> 4;
-        if (t >= ns) return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
-        if (cls == PLAN_WALKC) {
-            // the reads with many events: their walks are cut into jobs (below); the plans of the class are
-            // the streams, the jobs of stream t numbered behind those of the streams before it
-            WalkPlanDev& d = walkc.p[walkc.n];
+        if (t >= ns || cls > PLAN_WALKC16) return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+        if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
+            // the reads with many events: their walks are cut into jobs (below); the plans of a chunked class
+            // are the streams, the jobs of stream t numbered behind those of the streams before it
+            const uint32_t cc = cls - PLAN_WALKC8;
+            WalkPlans& wc = walkc[cc];
+            WalkPlanDev& d = wc.p[wc.n];
             d.tier = t;
-            d.n_list = info[TI_JOBS + t];
-            d.job0 = (uint32_t)n_jobs;
-            d.list = list + info[TI_OFF + (PLAN_WALKC << 4)];
-            d.wave_end = (walkc.n ? walkc.p[walkc.n - 1].wave_end : 0u) + (d.n_list + 63) / 64;
-            walkc.n++;
-            n_jobs += d.n_list;
-            walkc_reads += count;
+            d.n_list = info[TI_JOBS + cc * MAX_STREAMS + t];
+            d.job0 = (uint32_t)n_jobs[cc];
+            d.list = list + info[TI_OFF + (cls << 4)];
+            d.wave_end = (wc.n ? wc.p[wc.n - 1].wave_end : 0u) + (d.n_list + 63) / 64;
+            wc.n++;
+            n_jobs[cc] += d.n_list;
+            walkc_reads[cc] += count;
             walk_reads += count;
             continue;
         }
-        if (cls != PLAN_SWEEP && (count >= walk_min_reads || mat->streams[t].n <= (1u << 16))) {
+        if (cls != PLAN_SWEEP) {
             WalkPlans& wp = walk[cls];
             WalkPlanDev& d = wp.p[wp.n];
             d.tier = t;
@@ -431,12 +430,13 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         bytes += (uint64_t)plans[i].ntiles * mat->stream_bytes[plans[i].t];
     }
     std::sort(order, order + n_plain, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
-    const bool walks = walk[0].n || walk[1].n || walkc.n;
-    if (n_jobs >= (1ull << 31)) return set_error(WEPP_ELIMIT, "too many walk jobs in one call; split the batch");
+    const bool walks = walk[0].n || walk[1].n || walkc[0].n || walkc[1].n;
+    if (n_jobs[0] + n_jobs[1] >= (1ull << 31)) return set_error(WEPP_ELIMIT, "too many walk jobs in one call; split the batch");
     for (uint32_t cls = 0; cls < 2; cls++)
         if (walk[cls].n) passes += walk[cls].p[walk[cls].n - 1].wave_end;   // a walk "pass" = one wave of 64 reads
-    if (walkc.n) passes += walkc.p[walkc.n - 1].wave_end;
-    const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + (walkc.n ? 1u : 0u);
+    for (uint32_t cc = 0; cc < 2; cc++)
+        if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
+    const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
     const bool fork = !unfused && (n_other + n_walk_chains > 0) && (n_plain > 0 || n_other + n_walk_chains > 1);
     if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
     // the side streams join the caller's stream only after everything has been launched: a join in between
@@ -453,50 +453,61 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (fork) {
             HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
             joins[n_joins++] = MAX_STREAMS - 1;
-            q = mat->side[MAX_STREAMS - 2];
-            if (walkc.n) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         }
-        if (walkc.n) {
-            // chunked walks: jobs per read in list order -> exclusive scan -> job -> read table -> the walk
-            // (a partial per job) -> one combination per read.  Buffers: a second grow-only workspace.
-            const uint32_t R3 = walkc_reads, J = (uint32_t)n_jobs;
-            size_t scan_temp = 0;
-            HIP_TRY(scan_u32_temp_bytes(R3, &scan_temp));
+        if (walkc[0].n || walkc[1].n) {
+            // chunked walks, per class: jobs per read in list order -> exclusive scan -> the walk (a partial per
+            // job; a job finds its read by bisection in the scanned offsets) -> one combination per read.
+            // Buffers: a second grow-only workspace holding both classes.
             auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-            const size_t b_cnt = pad((size_t)R3 * 4), b_off = pad((size_t)R3 * 4), b_tmp = pad(scan_temp), b_job = pad((size_t)J * 4);
-            const size_t need = b_cnt + b_off + b_tmp + 3 * b_job;
+            size_t scan_temp[2] = {0, 0}, need = 0, base[2] = {0, 0};
+            for (uint32_t cc = 0; cc < 2; cc++) {
+                if (!walkc[cc].n) continue;
+                HIP_TRY(scan_u32_temp_bytes(walkc_reads[cc], &scan_temp[cc]));
+                base[cc] = need;
+                need += 2 * pad((size_t)walkc_reads[cc] * 4) + pad(scan_temp[cc]) + 3 * pad((size_t)n_jobs[cc] * 4);
+            }
             if (need > mat->ws2_bytes) {
                 if (mat->ws2) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->ws2); mat->ws2 = nullptr; mat->ws2_bytes = 0; }
                 hipError_t e2 = hipMalloc(&mat->ws2, need + need / 4);
                 if (e2 != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc walk workspace: ") + hipGetErrorString(e2));
                 mat->ws2_bytes = need + need / 4;
             }
-            char* w2 = (char*)mat->ws2;
-            uint32_t* jcnt = (uint32_t*)w2; w2 += b_cnt;
-            uint32_t* joff = (uint32_t*)w2; w2 += b_off;
-            void* jtmp = w2; w2 += b_tmp;
-            WalkJobs jb{};
-            jb.n_list = R3;
-            jb.job_off = joff;
-            jb.job_n = job_n;
-            jb.part_score = (int32_t*)w2; w2 += b_job;
-            jb.part_rank = (uint32_t*)w2; w2 += b_job;
-            jb.part_cnt = (uint32_t*)w2;
-            const uint32_t* list3 = walkc.p[0].list;
-            HIP_TRY(launch_gather_jobs(list3, R3, job_n, jcnt, q));
-            HIP_TRY(launch_exclusive_scan_u32(jcnt, joff, R3, jtmp, scan_temp, q));
-            HIP_TRY(launch_walk_jobs(mat->dev, walkc, jb, d_read_off, d_read_word, root_score, mat->d_work, q));
-            HIP_TRY(launch_finalize_jobs(mat->dev, list3, R3, jb, d_read_off, d_read_word, d_best_bfs_j, d_score,
-                                         d_num_best, d_flags, q));
-            if (fork) {
-                HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 2], q));
-                joins[n_joins++] = MAX_STREAMS - 2;
+            for (uint32_t cc = 0; cc < 2; cc++) {
+                if (!walkc[cc].n) continue;
+                // each class on a side stream of its own: a chain of short, latency-bound launches
+                if (fork) {
+                    q = mat->side[MAX_STREAMS - 2 - cc];
+                    HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+                }
+                const uint32_t R3 = walkc_reads[cc], J = (uint32_t)n_jobs[cc];
+                const size_t b_cnt = pad((size_t)R3 * 4), b_tmp = pad(scan_temp[cc]), b_job = pad((size_t)J * 4);
+                char* w2 = (char*)mat->ws2 + base[cc];
+                uint32_t* jcnt = (uint32_t*)w2; w2 += b_cnt;
+                uint32_t* joff = (uint32_t*)w2; w2 += b_cnt;
+                void* jtmp = w2; w2 += b_tmp;
+                WalkJobs jb{};
+                jb.n_list = R3;
+                jb.job_off = joff;
+                jb.job_n = job_n;
+                jb.part_score = (int32_t*)w2; w2 += b_job;
+                jb.part_rank = (uint32_t*)w2; w2 += b_job;
+                jb.part_cnt = (uint32_t*)w2;
+                const uint32_t* list3 = walkc[cc].p[0].list;
+                HIP_TRY(launch_gather_jobs(list3, R3, job_n, jcnt, q));
+                HIP_TRY(launch_exclusive_scan_u32(jcnt, joff, R3, jtmp, scan_temp[cc], q));
+                HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, jb, d_read_off, d_read_word, root_score, mat->d_work, q));
+                HIP_TRY(launch_finalize_jobs(mat->dev, list3, R3, jb, d_read_off, d_read_word, d_best_bfs_j, d_score,
+                                             d_num_best, d_flags, q));
+                if (fork) {
+                    HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 2 - cc], q));
+                    joins[n_joins++] = MAX_STREAMS - 2 - cc;
+                }
             }
         }
     }
     for (uint32_t k = 0; k < n_other; k++) {
         const Plan& p = plans[others[k]];
-        hipStream_t q = fork ? mat->side[k % (MAX_STREAMS - 2)] : stream;
+        hipStream_t q = fork ? mat->side[k % (MAX_STREAMS - 3)] : stream;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
@@ -505,10 +516,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                              p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, p.lst, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
-        if (fork && (k + (MAX_STREAMS - 2) >= n_other)) {
+        if (fork && (k + (MAX_STREAMS - 3) >= n_other)) {
             // the last launch on every side stream joins the caller's stream
-            HIP_TRY(hipEventRecord(mat->join_ev[k % (MAX_STREAMS - 2)], q));
-            joins[n_joins++] = k % (MAX_STREAMS - 2);
+            HIP_TRY(hipEventRecord(mat->join_ev[k % (MAX_STREAMS - 3)], q));
+            joins[n_joins++] = k % (MAX_STREAMS - 3);
         }
     }
     if (n_plain) {

@@ -74,15 +74,15 @@ struct DevMAT {
 // placed: by the per-read walk of its own events (k_walk) when it lists at most WALK8_K / WALK16_K positions and
 // the intervals it can hold open at once (sum of maxnest over its positions) fit WALK8_STACK / WALK16_STACK, by a
 // sweep of the whole stream otherwise.
-constexpr uint32_t MAX_PLANS = 64;
-constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC = 3;
-// PLAN_WALKC: a read with many events at its positions (a frequently mutated site) walks them as several
+constexpr uint32_t MAX_PLANS = 128;
+constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC8 = 3, PLAN_WALKC16 = 4;
+// PLAN_WALKC8 / 16: a read with many events at its positions (a frequently mutated site) walks them as several
 // independent JOBS of about WALK_JOB_EVENTS events each -- node ranges cut at quantiles of its longest list;
 // a job finds the state of a sequential walk at its first node by binary searches in the read's lists and
 // the chains of enclosing entries (ix_up) -- whose (score, rank, count) partials k_finalize_jobs combines.
 constexpr uint32_t WALK_JOB_EVENTS = 32;
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
-constexpr uint32_t WALK_MAX_EVENTS = 48;   // reads with more events at their positions (in their stream) are swept
+constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
 constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
 struct WalkPlanDev {
@@ -108,7 +108,7 @@ hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const
                        uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
-hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, const WalkJobs& jb, const uint32_t* d_read_off,
+hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const WalkJobs& jb, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
                             hipStream_t stream);
 hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t n_list, const WalkJobs& jb,
@@ -214,8 +214,8 @@ hipError_t launch_excess(const DevMAT& m, const uint32_t* d_read_off, const uint
 hipError_t sweep_set_max_lds(uint32_t bytes);
 
 // layout of tier_info (uint32), indexed by plan id: counts, max entries of one read, offsets into the list
-// then, per stream, the jobs of its chunked walks
+// then, per chunked class and stream, the jobs of its chunked walks
 constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
-                   TI_WORDS = TI_JOBS + MAX_STREAMS;
+                   TI_WORDS = TI_JOBS + 2 * MAX_STREAMS;
 
 }  // namespace wepp

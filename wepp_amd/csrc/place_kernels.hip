@@ -170,12 +170,12 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           uint32_t* __restrict__ tier_info,
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next) {
-    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[MAX_STREAMS];
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
     if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
-    if (threadIdx.x < MAX_STREAMS) jobs_of[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
@@ -236,11 +236,12 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 if (k <= WALK8_K && open_max <= WALK8_STACK) cls = PLAN_WALK8;
                 else if (open_max <= WALK16_STACK) cls = PLAN_WALK16;
             } else if (open_max <= WALK16_STACK) {
-                // many events: jobs of about WALK_JOB_EVENTS, cut at quantiles of the longest list
-                cls = PLAN_WALKC;
+                // many events: jobs of about `job_events`, cut at quantiles of the longest list
+                const uint32_t small = (k <= WALK8_K && open_max <= WALK8_STACK) ? 1u : 0u;
+                cls = small ? PLAN_WALKC8 : PLAN_WALKC16;
                 const uint32_t nj = min((events + job_events - 1) / job_events, longest);
                 job_n[r] = nj;
-                atomicAdd(&jobs_of[t], nj);
+                atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
             }
         }
         t |= cls << 4;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             atomicMax(&tier_info[TI_MAXK + threadIdx.x], mx[threadIdx.x]);
         }
     }
-    if (threadIdx.x < MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
+    if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
 }
 
 // -----------------------------------------------------------------------------
@@ -1895,14 +1896,20 @@ hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint3
     return hipGetLastError();
 }
 
-hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, const WalkJobs& jb, const uint32_t* d_read_off,
+hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const WalkJobs& jb, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
                             hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
     const uint32_t waves = pl.p[pl.n - 1].wave_end;
-    hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), dim3((waves + 3) / 4), dim3(256), 0, stream, m, pl, jb,
-                       d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, work_counter);
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (cls == PLAN_WALKC8)
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, 0, stream, m, pl, jb, d_read_off,
+                           d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, work_counter);
+    else
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, 0, stream, m, pl, jb, d_read_off,
+                           d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, work_counter);
     return hipGetLastError();
 }
 
