@@ -142,39 +142,59 @@ def pmc_profile(mode):
 
 
 def sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch):
-    """The two roofline objects of one measurement: the binding one (vector instruction issue: the
-    streams are shared by all tiles and served by the L2s) and the HBM one."""
+    """The roofline objects of one measurement.  `hbm`: algorithmic and counter traffic against the 8 TB/s
+    peak.  The other candidates come from the committed rocprofv3 --pmc profile of this workload and this
+    build: vector instruction issue (256 CUs x one wave-instruction per cycle) and the vector memory address
+    units (TA busy cycles: a gather whose 64 lanes touch 64 cache lines keeps its CU's unit busy for 64+
+    cycles -- what bounds the per-read walks).  `binding` = the candidate with the largest utilisation."""
     prof = pmc_profile(mode)
     secs = sweep_ms * 1e-3
     alg = alg_bytes / secs / 1e9
-    issue = {"bound": "valu_issue", "kernel": "k_sweep", "peak": VALU_ISSUE_PEAK, "unit": "G wave-instructions/s",
-             "peak_note": "256 CUs x one vector instruction per cycle (4 SIMDs, one wave-instruction per 4 cycles each) "
-                          "x 2.4 GHz max clock; the clock the chip really holds under load is lower, so frac is a lower bound",
-             "kernel_ms_per_step": sweep_ms, "steps_timed": n_launch}
-    hbm = {"bound": "hbm", "kernel": "k_sweep", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg / HBM_PEAK_GBS,
-           "achieved_note": "ALGORITHMIC bytes (every tile of 64 reads sweeps its stream once; DESIGN.md 4.1) over the "
-                            "live kernel time.  The streams are shared between tiles and served by the L2s: this is "
-                            "not the HBM traffic (see traffic / traffic_gbs) and frac is not an HBM efficiency",
-           "algorithmic_bytes_per_step": alg_bytes, "stream_sweeps_per_step": passes, "kernel_ms_per_step": sweep_ms}
+    hbm = {"bound": "hbm", "kernel": "placement kernels (k_walk / k_sweep / k_finalize)", "achieved": alg, "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
+           "achieved_note": "ALGORITHMIC bytes over the live kernel time: a sweep reads its stream once per 64-read tile, "
+                            "a walk 26 bytes per loop iteration (DESIGN.md 4.1, 4.2).  Streams and index are shared between "
+                            "reads and largely served by the L2s / Infinity Cache: see traffic / traffic_gbs for what left the L2s",
+           "algorithmic_bytes_per_step": alg_bytes, "passes_per_step": passes, "kernel_ms_per_step": sweep_ms,
+           "steps_timed": n_launch, "traffic": None, "traffic_gbs": None, "traffic_frac": None}
+    cands = []
     if prof is None:
-        issue.update({"achieved": None, "frac": None, "traffic": None,
-                      "provenance": "no rocprofv3 --pmc profile of this workload for this build of the kernels is committed "
-                                    "(profiles/pmc_counters.json, tools/profile.sh)"})
-        hbm.update({"traffic": None, "traffic_gbs": None, "traffic_frac": None})
-        return issue, hbm
-    a = prof["valu_insts_per_step"] / secs / 1e9
-    issue.update({"achieved": a, "frac": a / VALU_ISSUE_PEAK, "traffic": prof["traffic_bytes_per_step"],
-                  "valu_insts_per_step": prof["valu_insts_per_step"], "salu_insts_per_step": prof.get("salu_insts_per_step"),
-                  "salu_frac": (prof["salu_insts_per_step"] / secs / 1e9 / VALU_ISSUE_PEAK) if prof.get("salu_insts_per_step") else None,
-                  "provenance": f"SQ_INSTS_VALU / SQ_INSTS_SALU per step from {prof['profile']} (rocprofv3 --pmc run of this "
-                                f"workload, kernel hash {prof['kernel_hash']}); duration measured live with HIP events; "
-                                f"profiled kernel time {prof.get('kernel_ms_per_step_trace')} ms per step"})
-    hbm.update({"traffic": prof["traffic_bytes_per_step"], "traffic_gbs": prof["traffic_bytes_per_step"] / secs / 1e9,
-                "traffic_frac": prof["traffic_bytes_per_step"] / secs / 1e9 / HBM_PEAK_GBS,
-                "traffic_note": "bytes per step leaving the L2s, (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes; "
-                                "Infinity-Cache hits are counted, so true HBM traffic is lower still"})
-    return issue, hbm
+        binding = {"bound": "unknown", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                   "kernel_ms_per_step": sweep_ms, "steps_timed": n_launch,
+                   "provenance": "no rocprofv3 --pmc profile of this workload for this build of the kernels is committed "
+                                 "(profiles/pmc_counters.json, tools/profile.sh + tools/summarize_profile.py)"}
+        return binding, hbm, cands
+    prov = (f"counters per step from {prof['profile']} (rocprofv3 --pmc runs of this workload, kernel hash "
+            f"{prof['kernel_hash']}); duration measured live with HIP events; the profiled run's kernel time was "
+            f"{prof.get('kernel_ms_per_step_trace')} ms per step")
+    if prof.get("traffic_bytes_per_step") is not None:
+        hbm.update({"traffic": prof["traffic_bytes_per_step"], "traffic_gbs": prof["traffic_bytes_per_step"] / secs / 1e9,
+                    "traffic_frac": prof["traffic_bytes_per_step"] / secs / 1e9 / HBM_PEAK_GBS,
+                    "l2_hit_rate": prof.get("l2_hit_rate"),
+                    "traffic_note": "bytes per step leaving the L2s, (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes; "
+                                    "Infinity-Cache hits are counted, so true HBM traffic is lower still"})
+        cands.append({"bound": "hbm", "achieved": hbm["traffic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (counter traffic)",
+                      "frac": hbm["traffic_frac"]})
+    if prof.get("valu_insts_per_step") is not None:
+        a = prof["valu_insts_per_step"] / secs / 1e9
+        cands.append({"bound": "valu_issue", "achieved": a, "peak": VALU_ISSUE_PEAK, "unit": "G wave-instructions/s",
+                      "frac": a / VALU_ISSUE_PEAK, "valu_insts_per_step": prof["valu_insts_per_step"],
+                      "salu_insts_per_step": prof.get("salu_insts_per_step"),
+                      "peak_note": "256 CUs x one vector instruction per cycle x 2.4 GHz max clock (the clock held under load is "
+                                   "lower: frac is a lower bound)"})
+    if prof.get("ta_busy_cycles_per_step") is not None:
+        a = prof["ta_busy_cycles_per_step"] / secs / 1e9
+        cands.append({"bound": "vmem_address", "achieved": a, "peak": VALU_ISSUE_PEAK, "unit": "G busy cycles/s over the 256 address units",
+                      "frac": a / VALU_ISSUE_PEAK, "ta_busy_cycles_per_step": prof["ta_busy_cycles_per_step"],
+                      "vmem_read_insts_per_step": prof.get("vmem_rd_insts_per_step"),
+                      "tcp_cache_accesses_per_step": prof.get("tcp_cache_accesses_per_step"),
+                      "peak_note": "TA_TA_BUSY summed over the 256 vector-memory address units / (256 x 2.4 GHz x kernel time): the "
+                                   "share of the time the units were busy splitting gathers into cache-line requests"})
+    best = max(cands, key=lambda c: c["frac"]) if cands else None
+    binding = dict(best) if best else {"bound": "unknown", "achieved": None, "peak": None, "unit": None, "frac": None}
+    binding.update({"kernel": "placement kernels (k_walk / k_sweep / k_finalize)", "traffic": prof.get("traffic_bytes_per_step"),
+                    "kernel_ms_per_step": sweep_ms, "steps_timed": n_launch, "provenance": prov})
+    return binding, hbm, cands
 
 
 class DeviceBatch:
@@ -273,6 +293,7 @@ def main():
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     sweep_ms, n_launch, passes, alg_bytes = mat.last_timing()
+    walk_reads, walk_iters = mat.last_walk()
     tiers = mat.last_tiers(R)
     ref_out = [t.clone() for t in batch.out]
 
@@ -347,8 +368,8 @@ def main():
                    "num_best": ref_out[2].cpu().numpy().view(np.uint32), "flags": ref_out[3].cpu().numpy().view(np.uint32)}
         total_reads = R * world * args.steps
         value = total_reads / elapsed
-        mode = "long_reads" if long_reads else ("whole_tree" if args.no_crowns else "short_reads")
-        issue, hbm = sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch)
+        mode = "long_reads" if long_reads else ("whole_tree" if (args.no_crowns and args.no_walk) else "short_reads")
+        issue, hbm, cands = sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch)
         shape = (f"{R} synthetic midnight-amplicon-like {args.read_len} bp reads per GPU per step (3 % substitutions, "
                  f"N rate {p_n}; seed 24+rank); BASELINE.json configs[4] shape on one GPU" if long_reads else
                  f"{R} synthetic ARTIC-like {args.read_len} bp reads per GPU per step (0.1 % substitutions, N rate {p_n}; "
@@ -388,18 +409,21 @@ def main():
             },
             "roofline": issue,
             "roofline_hbm": hbm,
+            "roofline_candidates": cands,
+            "walk": {"reads_walked_per_step": int(walk_reads), "wave_iterations_per_step": int(walk_iters // max(1, args.steps)),
+                     "enabled": not args.no_walk},
             "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]), "bytes": int(st.stream_bytes_of[i]),
                          "reads_routed": int(counts[i])} for i in range(st.n_streams)],
         }
         if whole is not None:
-            wi, wh = sweep_roofline("whole_tree", whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],
-                                    whole["stream_sweeps_per_step"], whole["steps_timed"])
+            wi, wh, wc = sweep_roofline("whole_tree", whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],
+                                        whole["stream_sweeps_per_step"], whole["steps_timed"])
             out["roofline_whole_tree"] = {
                 "what": "same batch with work skipping off: every 64-read tile streams the whole-tree event "
                         "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`",
                 "reads_per_s": R / (whole["kernel_ms_per_step"] * 1e-3),
                 "results_identical_to_timed_run": whole["results_identical_to_timed_run"],
-                "issue": wi, "hbm": wh,
+                "binding": wi, "hbm": wh, "candidates": wc,
                 "served_from": "L2 (chunk-major 1 MB chunks)", "l2_peak": L2_PEAK_GBS,
                 "algorithmic_frac_of_l2_peak": wh["achieved"] / L2_PEAK_GBS}
         out["sensitivity"] = sens
