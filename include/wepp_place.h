@@ -277,6 +277,20 @@ int wepp_fitch_sites(const wepp_tree_desc *tree, int device, uint32_t n_sites, c
                      uint64_t capacity, uint64_t *n_out, uint32_t *out_site, uint32_t *out_node,
                      uint8_t *out_par, uint8_t *out_mut);
 
+/* The same with the tree-dependent work done once: read_vcf runs mapper_body row after row on ONE tree
+ * (src/mutation_annotated_tree.cpp:1962-2031); a plan keeps the flattened topology, the level tables and the
+ * decision-table memory on the device, so that repeated calls (batches of VCF rows) only pay for their rows.
+ * wepp_fitch_sites == create + run + destroy.  A plan is bound to one device and is not re-entrant. */
+typedef struct wepp_fitch_plan wepp_fitch_plan_t;
+int wepp_fitch_plan_create(const wepp_tree_desc *tree, int device, wepp_fitch_plan_t **out);
+int wepp_fitch_plan_run(wepp_fitch_plan_t *plan, uint32_t n_sites, const uint8_t *site_ref, const uint32_t *var_off,
+                        const uint32_t *var_node, const uint8_t *var_nuc, uint64_t capacity, uint64_t *n_out,
+                        uint32_t *out_site, uint32_t *out_node, uint8_t *out_par, uint8_t *out_mut);
+int wepp_fitch_plan_destroy(wepp_fitch_plan_t *plan);
+/* wall time of the calling thread's last wepp_fitch_plan_run by phase (ms): host preparation of the rows, uploads,
+ * kernels, sort + decode + copy-out of the mutations */
+int wepp_fitch_last_timing(double *prep_ms, double *upload_ms, double *kernels_ms, double *output_ms);
+
 /* ---- WEPP's own read placement: EPP sets and haplotype scores -------------- *
  * Replaces wepp_filter::cartesian_map (src/WEPP/initial_filter.cpp:140-239) with
  * single_read_tree (:41-136), the range trees it walks (src/WEPP/arena.cpp:68-169)

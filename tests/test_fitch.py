@@ -167,3 +167,30 @@ def test_fitch_argument_errors():
     assert ei.value.code == 1
     with pytest.raises(w.WeppError):
         w.fitch_sites(t, [A], [0, 1], [7], [G])
+
+
+@pytest.mark.gpu
+def test_fitch_plan_reuse_vs_oracle(oracle):
+    """wepp_fitch_plan_*: the tree-dependent work done once, several batches of rows on the same plan
+    (what read_vcf does row after row), each equal to the oracle and to the one-shot call."""
+    rng = np.random.default_rng(41)
+    tree, _ = ft.random_tree(rng, n_nodes=180, genome=30)
+    bare = Tree(tree.parent, np.zeros(tree.n_nodes + 1, np.uint32), [], [], [])
+    ot = oracle.OracleTree(bare)
+    plan = w.FitchPlan(bare)
+    for n_rows in (3, 70, 1, 300):
+        site_ref, var_off, var_node, var_nuc = _random_rows(rng, bare, n_rows)
+        got = plan.run(site_ref, var_off, var_node, var_nuc)
+        one = w.fitch_sites(bare, site_ref, var_off, var_node, var_nuc)
+        assert all((a == b).all() for a, b in zip(got, one))
+        k = 0
+        for r in range(n_rows):
+            x, y = int(var_off[r]), int(var_off[r + 1])
+            want = ot.mapper_body(int(site_ref[r]), var_node[x:y].astype(np.int32), var_nuc[x:y])
+            rows = [(int(got[1][i]), int(got[2][i]), int(got[3][i])) for i in range(k, k + len(want))]
+            assert rows == want and (got[0][k:k + len(want)] == r).all()
+            k += len(want)
+        assert k == len(got[0])
+        t = w.fitch_last_timing()
+        assert t["kernels_ms"] > 0
+    plan.close()

@@ -26,12 +26,21 @@ var_off = (np.arange(a.rows + 1, dtype=np.uint64) * per).astype(np.uint32)
 var_node = np.concatenate([rng.choice(leaves, per, replace=False) for _ in range(a.rows)]).astype(np.uint32)
 var_nuc = (1 << rng.integers(0, 4, a.rows * per)).astype(np.uint8)
 bare = w.Tree(tree.parent, np.zeros(n + 1, np.uint32), [], [], [])
-w.fitch_sites(bare, site_ref[:64], var_off[:65], var_node[:64 * per], var_nuc[:64 * per])   # warm-up
 t0 = time.perf_counter()
-s, nd, par, mut = w.fitch_sites(bare, site_ref, var_off, var_node, var_nuc)
+plan = w.FitchPlan(bare)
+t_plan = time.perf_counter() - t0
+plan.run(site_ref[:64], var_off[:65], var_node[:64 * per], var_nuc[:64 * per])   # warm-up (uploads the topology)
+cap = int(1.2 * a.rows * per + a.rows)
+t0 = time.perf_counter()
+s, nd, par, mut = plan.run(site_ref, var_off, var_node, var_nuc, capacity=cap)     # (sizes the plan's decision tables)
+dt_first = time.perf_counter() - t0
+t0 = time.perf_counter()
+s, nd, par, mut = plan.run(site_ref, var_off, var_node, var_nuc, capacity=cap)
 dt = time.perf_counter() - t0
+phases = w.fitch_last_timing()
 out = {"row": "fitch_sankoff (mapper_body)", "nodes": n, "rows": a.rows, "variants_per_row": per,
-       "mutations_out": int(len(s)), "wall_s_incl_flatten_and_copies": dt, "rows_per_s_wall": a.rows / dt,
+       "mutations_out": int(len(s)), "plan_create_s": t_plan, "wall_s_first_run_on_the_plan": dt_first, "wall_s_of_one_run_on_the_plan": dt, "rows_per_s_wall": a.rows / dt,
+       "phases_ms": phases, "rows_per_s_kernels": a.rows / (phases["kernels_ms"] * 1e-3),
        "algorithmic_bytes": 2 * n * a.rows}
 if a.cpu_rows:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -133,6 +133,11 @@ _SIGS = {
     ),
     "wepp_fitch_sites": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.c_int, ctypes.c_uint32, _V, _V, _V, _V,
                                         ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), _V, _V, _V, _V]),
+    "wepp_fitch_plan_create": (ctypes.c_int, [ctypes.POINTER(TreeDescC), ctypes.c_int, ctypes.POINTER(_V)]),
+    "wepp_fitch_plan_run": (ctypes.c_int, [_V, ctypes.c_uint32, _V, _V, _V, _V, ctypes.c_uint64,
+                                           ctypes.POINTER(ctypes.c_uint64), _V, _V, _V, _V]),
+    "wepp_fitch_plan_destroy": (ctypes.c_int, [_V]),
+    "wepp_fitch_last_timing": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)] * 4),
     "wepp_epp_map": (ctypes.c_int, [_V, ctypes.POINTER(EppReadsC), ctypes.c_uint32, ctypes.c_uint32,
                                     ctypes.POINTER(EppOutC)]),
     "wepp_mat_dfs_order": (ctypes.c_int, [_V, _V]),

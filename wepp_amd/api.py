@@ -254,16 +254,49 @@ class FlatView:
             pass
 
 
-def fitch_sites(tree, site_ref, var_off, var_node, var_nuc, device=0, capacity=None):
-    """Per-site Fitch-Sankoff (wepp_fitch_sites): returns arrays (site, node id, par_nuc, mut_nuc)
-    of the mutations mapper_body would add, rows in order, BFS order inside a row."""
+def fitch_last_timing():
+    """Wall time by phase (ms) of this thread's last Fitch-Sankoff run: rows prepared on the host, uploads,
+    kernels, sort + decode + copy-out."""
+    d = [ctypes.c_double() for _ in range(4)]
+    check(lib.wepp_fitch_last_timing(*[ctypes.byref(x) for x in d]))
+    return dict(prep_ms=d[0].value, upload_ms=d[1].value, kernels_ms=d[2].value, output_ms=d[3].value)
+
+
+class FitchPlan:
+    """wepp_fitch_plan_*: the tree-dependent part of the Fitch-Sankoff pass, done once."""
+
+    def __init__(self, tree, device=0):
+        self._h = ctypes.c_void_p()
+        self._keep = tree
+        d = tree.desc()
+        check(lib.wepp_fitch_plan_create(ctypes.byref(d), int(device), ctypes.byref(self._h)))
+
+    def run(self, site_ref, var_off, var_node, var_nuc, capacity=None):
+        return fitch_sites(None, site_ref, var_off, var_node, var_nuc, capacity=capacity, plan=self)
+
+    def close(self):
+        if self._h:
+            lib.wepp_fitch_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fitch_sites(tree, site_ref, var_off, var_node, var_nuc, device=0, capacity=None, plan=None):
+    """Per-site Fitch-Sankoff (wepp_fitch_sites, or wepp_fitch_plan_run with plan=): returns arrays
+    (site, node id, par_nuc, mut_nuc) of the mutations mapper_body would add, rows in order, BFS order
+    inside a row."""
     site_ref = np.ascontiguousarray(site_ref, np.uint8)
     var_off = np.ascontiguousarray(var_off, np.uint32)
     var_node = np.ascontiguousarray(var_node, np.uint32)
     var_nuc = np.ascontiguousarray(var_nuc, np.uint8)
     n_sites = int(site_ref.shape[0])
     cap = int(capacity if capacity is not None else max(1024, 4 * int(var_off[-1]) + n_sites))
-    d = tree.desc()
+    d = tree.desc() if plan is None else None
     while True:
         o_site = np.zeros(cap, np.uint32)
         o_node = np.zeros(cap, np.uint32)
@@ -272,9 +305,13 @@ def fitch_sites(tree, site_ref, var_off, var_node, var_nuc, device=0, capacity=N
         n_out = ctypes.c_uint64()
         vn = var_node if var_node.size else np.zeros(1, np.uint32)
         vc = var_nuc if var_nuc.size else np.zeros(1, np.uint8)
-        rc = lib.wepp_fitch_sites(ctypes.byref(d), int(device), n_sites, _ptr(site_ref), _ptr(var_off), _ptr(vn),
-                                  _ptr(vc), cap, ctypes.byref(n_out), _ptr(o_site), _ptr(o_node), _ptr(o_par),
-                                  _ptr(o_mut))
+        if plan is None:
+            rc = lib.wepp_fitch_sites(ctypes.byref(d), int(device), n_sites, _ptr(site_ref), _ptr(var_off), _ptr(vn),
+                                      _ptr(vc), cap, ctypes.byref(n_out), _ptr(o_site), _ptr(o_node), _ptr(o_par),
+                                      _ptr(o_mut))
+        else:
+            rc = lib.wepp_fitch_plan_run(plan._h, n_sites, _ptr(site_ref), _ptr(var_off), _ptr(vn), _ptr(vc), cap,
+                                         ctypes.byref(n_out), _ptr(o_site), _ptr(o_node), _ptr(o_par), _ptr(o_mut))
         if rc == 4 and n_out.value > cap and capacity is None:
             cap = int(n_out.value)
             continue

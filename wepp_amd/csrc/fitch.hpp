@@ -67,6 +67,14 @@ hipError_t launch_fitch_sort_keys(const uint2* out, uint64_t n, unsigned long lo
 hipError_t launch_fitch_decode(const unsigned long long* keys, const uint32_t* vals, const uint32_t* bfs2id, uint64_t n,
                                uint32_t* out_site, uint32_t* out_node, uint8_t* out_par, uint8_t* out_mut,
                                hipStream_t stream);
+// the rows of a call prepared on the device (sort_reads.hip): node ids -> keys, sorted per row, duplicates dropped;
+// the result is in (keys_b, nuc_b) or, after a second sort, in (keys_a, nuc_a).  hipErrorInvalidValue = a node id
+// out of range.  Synchronises the stream once (two flags come back).
+hipError_t fitch_rows_temp_bytes(uint64_t nv, uint32_t n_sites, size_t* bytes);
+hipError_t launch_fitch_prepare(const uint32_t* d_var_node, const uint8_t* d_var_nuc, const uint32_t* d_var_off,
+                                uint32_t n_sites, uint64_t nv, uint32_t N, const uint32_t* d_id2key, uint32_t* keys_a,
+                                uint8_t* nuc_a, uint32_t* keys_b, uint8_t* nuc_b, uint32_t* d_flags, void* temp,
+                                size_t temp_bytes, bool* result_in_b, hipStream_t stream);
 hipError_t sort_u64_u32_temp_bytes(uint64_t n, uint32_t end_bit, size_t* bytes);
 hipError_t launch_sort_u64_u32(const unsigned long long* keys_in, unsigned long long* keys_out, const uint32_t* vals_in,
                                uint32_t* vals_out, uint64_t n, uint32_t end_bit, void* temp, size_t temp_bytes,

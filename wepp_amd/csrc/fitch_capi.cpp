@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <numeric>
 #include <string>
@@ -32,19 +34,46 @@ struct DevBuf {
 };
 }  // namespace
 
-extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t n_sites, const uint8_t* site_ref,
-                                const uint32_t* var_off, const uint32_t* var_node, const uint8_t* var_nuc,
-                                uint64_t capacity, uint64_t* n_out, uint32_t* out_site, uint32_t* out_node,
-                                uint8_t* out_par, uint8_t* out_mut) {
-    if (!tree || !n_out || !var_off || (n_sites && !site_ref)) return set_error(WEPP_EINVAL, "null argument");
-    *n_out = 0;
-    if (n_sites == 0) return WEPP_OK;
+namespace {
+thread_local double g_fitch_ms[4] = {0, 0, 0, 0};     // host preparation of the rows, uploads, kernels, sort + decode + copy-out
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+extern "C" int wepp_fitch_last_timing(double* prep_ms, double* upload_ms, double* kernels_ms, double* output_ms) {
+    if (prep_ms) *prep_ms = g_fitch_ms[0];
+    if (upload_ms) *upload_ms = g_fitch_ms[1];
+    if (kernels_ms) *kernels_ms = g_fitch_ms[2];
+    if (output_ms) *output_ms = g_fitch_ms[3];
+    return WEPP_OK;
+}
+
+// Everything about a tree the Fitch-Sankoff pass needs, computed and uploaded ONCE: read_vcf runs
+// mapper_body row after row on one tree (src/mutation_annotated_tree.cpp:1962-2031); with a plan the
+// flattening, the level / chunk tables and their device copies are not redone per call.
+struct wepp_fitch_plan {
+    int device = 0;
+    FlatMAT f;
+    uint32_t N = 0, D = 0, C = 0;
+    bool sets_ok_tree = true;                  // no node has too many children for the set form's counters
+    std::vector<uint32_t> meta, id2dfs, depth, chunk_start, chunk_depth, chunk_min, chunk_open;
+    std::vector<uint32_t> level_off, l_coff, l_par;     // level-synchronous form (filled on first use)
+    DevBuf d_meta, d_cs, d_cd, d_cm, d_co, d_lcoff, d_lpar, d_b2i, d_tables, d_id2bfs, d_id2dfs;
+    size_t tables_bytes = 0;
+    bool dev_topology = false, dev_levels = false, dev_b2i = false;
+};
+
+extern "C" int wepp_fitch_plan_create(const wepp_tree_desc* tree, int device, wepp_fitch_plan_t** out) {
+    if (!tree || !out) return set_error(WEPP_EINVAL, "null argument");
+    *out = nullptr;
+    std::unique_ptr<wepp_fitch_plan> plan(new (std::nothrow) wepp_fitch_plan());
+    if (!plan) return set_error(WEPP_ENOMEM, "out of host memory");
+    plan->device = device;
     // topology only: the mutation lists of `tree` are ignored (a new MAT is being built)
     std::vector<uint32_t> zero_off((size_t)tree->n_nodes + 1, 0);
     wepp_tree_desc topo = *tree;
     topo.mut_off = zero_off.data();
     topo.mut_pos = nullptr; topo.mut_ref = nullptr; topo.mut_par = nullptr; topo.mut_mut = nullptr;
-    FlatMAT f;
+    FlatMAT& f = plan->f;
     std::string err;
     try {
         int rc = flatten_tree(topo, f, err, /*topology_only=*/true);
@@ -57,13 +86,13 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     if (f.max_depth > FITCH_MAX_DEPTH)
         return set_error(WEPP_ELIMIT, "tree depth " + std::to_string(f.max_depth) + " exceeds the LDS stack (" +
                                           std::to_string(FITCH_MAX_DEPTH) + ")");
-    std::vector<uint32_t> meta(N), id2dfs(N), depth(N, 0), nchild(N, 0);
+    std::vector<uint32_t>&meta = plan->meta, &id2dfs = plan->id2dfs, &depth = plan->depth;
+    meta.assign(N, 0); id2dfs.assign(N, 0); depth.assign(N, 0);
+    std::vector<uint32_t> nchild(N, 0);
     uint32_t max_children = 0;
     for (uint32_t d = 1; d < N; d++) max_children = std::max(max_children, ++nchild[f.parent_dfs[d]]);
     // the set form of the forward pass needs non-empty allele sets (checked per row below) and 15-bit counters
-    bool sets_ok = max_children <= FITCH_SETS_MAX_CHILDREN;
-    if (const char* env = std::getenv("WEPP_FITCH_SCORES"))      // test hook: force the score form
-        if (env[0] == '1') sets_ok = false;
+    plan->sets_ok_tree = max_children <= FITCH_SETS_MAX_CHILDREN;
     for (uint32_t d = 0; d < N; d++) {
         if (d) depth[d] = depth[f.parent_dfs[d]] + 1;
         meta[d] = depth[d] | ((f.nstat[d] & NS_LEAF) ? 0x80000000u : 0u);
@@ -74,7 +103,9 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     uint32_t C = std::max<uint32_t>(1, std::min<uint32_t>(256, N / 2048));
     if (const char* env = std::getenv("WEPP_FITCH_CHUNKS"))      // test hook: force the number of chunks
         C = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::atoi(env), N));
-    std::vector<uint32_t> chunk_start(C + 1), chunk_depth(C + 1), chunk_min(C), chunk_open((size_t)(C + 1) * D, 0);
+    std::vector<uint32_t>&chunk_start = plan->chunk_start, &chunk_depth = plan->chunk_depth, &chunk_min = plan->chunk_min,
+                         &chunk_open = plan->chunk_open;
+    chunk_start.assign(C + 1, 0); chunk_depth.assign(C + 1, 0); chunk_min.assign(C, 0); chunk_open.assign((size_t)(C + 1) * D, 0);
     for (uint32_t c = 0; c <= C; c++) chunk_start[c] = (uint32_t)((uint64_t)N * c / C);
     for (uint32_t c = 0; c <= C; c++) {
         // nodes open before node a (c < C): its strict ancestors; after the last node: the
@@ -94,6 +125,38 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         for (uint32_t d = chunk_start[c]; d < chunk_start[c + 1]; d++) mn = std::min(mn, depth[d]);
         chunk_min[c] = mn;
     }
+    plan->N = N;
+    plan->D = D;
+    plan->C = C;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return set_error(WEPP_EDEVICE, "no HIP device available (the Fitch-Sankoff pass has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(WEPP_EINVAL, "device index out of range");
+    *out = plan.release();
+    return WEPP_OK;
+}
+
+extern "C" int wepp_fitch_plan_destroy(wepp_fitch_plan_t* plan) {
+    if (plan) {
+        (void)hipSetDevice(plan->device);
+        delete plan;
+    }
+    return WEPP_OK;
+}
+
+extern "C" int wepp_fitch_plan_run(wepp_fitch_plan_t* plan, uint32_t n_sites, const uint8_t* site_ref,
+                                   const uint32_t* var_off, const uint32_t* var_node, const uint8_t* var_nuc,
+                                   uint64_t capacity, uint64_t* n_out, uint32_t* out_site, uint32_t* out_node,
+                                   uint8_t* out_par, uint8_t* out_mut) {
+    if (!plan || !n_out || !var_off || (n_sites && !site_ref)) return set_error(WEPP_EINVAL, "null argument");
+    *n_out = 0;
+    if (n_sites == 0) return WEPP_OK;
+    const int device = plan->device;
+    FlatMAT& f = plan->f;
+    const uint32_t N = plan->N, D = plan->D, C = plan->C;
+    const double t_begin = now_ms();
+    std::vector<uint32_t>&meta = plan->meta, &id2dfs = plan->id2dfs, &depth = plan->depth, &chunk_start = plan->chunk_start,
+                         &chunk_depth = plan->chunk_depth, &chunk_min = plan->chunk_min, &chunk_open = plan->chunk_open;
     // rows: reference base index, tree samples sorted by node index (BFS for the level-synchronous
     // form, DFS for the two stack forms)
     // the CSR over the rows is checked before anything is sized from it or written through it
@@ -102,76 +165,34 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         if (var_off[s + 1] < var_off[s]) return set_error(WEPP_EINVAL, "var_off not monotone");
     const uint64_t nv = var_off[n_sites];
     if (nv && (!var_node || !var_nuc)) return set_error(WEPP_EINVAL, "null variant arrays");
+    bool sets_ok = plan->sets_ok_tree;
+    if (const char* env = std::getenv("WEPP_FITCH_SCORES"))      // test hook: force the score form
+        if (env[0] == '1') sets_ok = false;
     for (uint64_t k = 0; k < nv; k++)
         if ((var_nuc[k] & 15) == 0) sets_ok = false;     // no base allowed: the scores leave the set forms' range
     bool levels = sets_ok;
     if (const char* env = std::getenv("WEPP_FITCH_DFS"))          // test hook: force the DFS stack forms
         if (env[0] == '1') levels = false;
-    std::vector<uint8_t> ref_idx(n_sites), vnuc(nv);
-    std::vector<uint32_t> vdfs(nv);
-    // rows are independent: host threads share them (one thread per row range; a 30 K-row VCF over 1 M
-    // nodes spent 0.4 s here on one thread, most of it sorting)
-    {
-        const uint32_t nthr = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::thread::hardware_concurrency(), 16ull, nv / 200000 + 1, (uint64_t)n_sites}));
-        std::vector<int> rcs(nthr, WEPP_OK);
-        std::vector<std::string> msgs(nthr);
-        auto work = [&](uint32_t t) {
-            std::vector<std::pair<uint32_t, uint8_t>> row;
-            const uint32_t s0 = (uint32_t)((uint64_t)n_sites * t / nthr), s1 = (uint32_t)((uint64_t)n_sites * (t + 1) / nthr);
-            for (uint32_t s = s0; s < s1; s++) {
-                const uint8_t r = site_ref[s] & 15;
-                if (r == 0 || (r & (r - 1))) {
-                    rcs[t] = WEPP_EINVAL;
-                    msgs[t] = "site_ref must be a single nucleotide (row " + std::to_string(s) + ")";
-                    return;
-                }
-                ref_idx[s] = (uint8_t)__builtin_ctz(r);
-                if (var_off[s + 1] < var_off[s]) { rcs[t] = WEPP_EINVAL; msgs[t] = "var_off not monotone"; return; }
-                row.clear();
-                bool sorted = true;
-                for (uint32_t k = var_off[s]; k < var_off[s + 1]; k++) {
-                    if (var_node[k] >= N) { rcs[t] = WEPP_EINVAL; msgs[t] = "var_node out of range"; return; }
-                    const uint32_t dd = id2dfs[var_node[k]];
-                    const uint32_t key = levels ? f.dfs2bfs[dd] : dd;
-                    if (!row.empty() && key <= row.back().first) sorted = false;
-                    row.emplace_back(key, var_nuc[k]);
-                }
-                // a node named twice in a row: the later entry wins, as the later assignment does at usher_mapper.cpp:57-62
-                if (!sorted)
-                    std::stable_sort(row.begin(), row.end(), [](const std::pair<uint32_t, uint8_t>& a,
-                                                                const std::pair<uint32_t, uint8_t>& b) { return a.first < b.first; });
-                uint32_t w = var_off[s];
-                for (size_t i = 0; i < row.size(); i++) {
-                    if (i + 1 < row.size() && row[i + 1].first == row[i].first) continue;
-                    vdfs[w] = row[i].first;
-                    vnuc[w] = row[i].second;
-                    w++;
-                }
-                for (; w < var_off[s + 1]; w++) { vdfs[w] = 0xFFFFFFFFu; vnuc[w] = 0; }   // dropped duplicates
-            }
-        };
-        if (nthr == 1) work(0);
-        else {
-            std::vector<std::thread> pool;
-            for (uint32_t t = 0; t < nthr; t++) pool.emplace_back(work, t);
-            for (auto& th : pool) th.join();
-        }
-        for (uint32_t t = 0; t < nthr; t++)
-            if (rcs[t] != WEPP_OK) return set_error(rcs[t], msgs[t]);
+    std::vector<uint8_t> ref_idx(n_sites);
+    for (uint32_t s2 = 0; s2 < n_sites; s2++) {
+        const uint8_t r = site_ref[s2] & 15;
+        if (r == 0 || (r & (r - 1)))
+            return set_error(WEPP_EINVAL, "site_ref must be a single nucleotide (row " + std::to_string(s2) + ")");
+        ref_idx[s2] = (uint8_t)__builtin_ctz(r);
     }
-
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return set_error(WEPP_EDEVICE, "no HIP device available (the Fitch-Sankoff pass has no CPU fallback)");
-    if (device < 0 || device >= ndev) return set_error(WEPP_EINVAL, "device index out of range");
+    if (nv >= (1ull << 32)) return set_error(WEPP_ELIMIT, "more than 2^32 variants in one call; split the rows");
+    // the rows themselves -- node ids to BFS / DFS indices, sorted per row, a node named twice keeping its later
+    // entry (usher_mapper.cpp:57-62) -- are prepared on the device (sort_reads.hip: launch_fitch_prepare)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hipf(e, "hipSetDevice");
+    const double t_prep = now_ms();
 
-    DevBuf d_meta, d_ref, d_voff, d_vdfs, d_vnuc, d_tables, d_count, d_out, d_cs, d_cd, d_cm, d_co, d_inh, d_outp;
-    DevBuf d_lcoff, d_lpar;
-    // level-synchronous form: the topology in BFS order (levels and sibling groups are contiguous)
-    std::vector<uint32_t> level_off, l_coff, l_par;
-    if (levels) {
+    DevBuf d_ref, d_voff, d_vdfs, d_vnuc, d_count, d_out, d_inh, d_outp, d_vraw, d_vnraw, d_vdfs2, d_vnuc2, d_ptmp, d_pflags;
+    DevBuf &d_meta = plan->d_meta, &d_cs = plan->d_cs, &d_cd = plan->d_cd, &d_cm = plan->d_cm, &d_co = plan->d_co,
+           &d_lcoff = plan->d_lcoff, &d_lpar = plan->d_lpar, &d_tables = plan->d_tables;
+    // level-synchronous form: the topology in BFS order (levels and sibling groups are contiguous); built once
+    std::vector<uint32_t>&level_off = plan->level_off, &l_coff = plan->l_coff, &l_par = plan->l_par;
+    if (levels && level_off.empty()) {
         std::vector<uint32_t> bfs2dfs(N);
         for (uint32_t d = 0; d < N; d++) bfs2dfs[f.dfs2bfs[d]] = d;
         l_coff.assign((size_t)N + 1, 0); l_par.assign(N, 0);
@@ -196,32 +217,75 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     const size_t per_batch = (size_t)N * rows_per_batch + 2 * part_bytes;
     const size_t budget = free_b / 2;
     const uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nbatches, budget / std::max<size_t>(per_batch, 1)));
-    if ((e = d_meta.alloc((size_t)N * 4)) != hipSuccess || (e = d_ref.alloc(n_sites)) != hipSuccess ||
+    // per-call buffers; the decision tables (tens of GB at 16 M nodes) and the topology stay with the plan
+    const size_t tables_need = (size_t)N * rows_per_batch * group;
+    if (tables_need > plan->tables_bytes) {
+        if (d_tables.p) { (void)hipFree(d_tables.p); d_tables.p = nullptr; plan->tables_bytes = 0; }
+        if ((e = d_tables.alloc(tables_need)) != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        plan->tables_bytes = tables_need;
+    }
+    if ((e = d_ref.alloc(n_sites)) != hipSuccess ||
         (e = d_voff.alloc((size_t)(n_sites + 1) * 4)) != hipSuccess || (e = d_vdfs.alloc(nv * 4)) != hipSuccess ||
-        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_tables.alloc((size_t)N * rows_per_batch * group)) != hipSuccess ||
+        (e = d_vnuc.alloc(nv)) != hipSuccess || (e = d_vraw.alloc(nv * 4)) != hipSuccess || (e = d_vnraw.alloc(nv)) != hipSuccess ||
+        (e = d_vdfs2.alloc(nv * 4)) != hipSuccess || (e = d_vnuc2.alloc(nv)) != hipSuccess || (e = d_pflags.alloc(8)) != hipSuccess ||
         (e = d_inh.alloc(part_bytes * group)) != hipSuccess || (e = d_outp.alloc(part_bytes * group)) != hipSuccess ||
-        (e = d_cs.alloc((C + 1) * 4)) != hipSuccess || (e = d_cd.alloc((C + 1) * 4)) != hipSuccess ||
-        (e = d_cm.alloc(C * 4)) != hipSuccess || (e = d_co.alloc(chunk_open.size() * 4)) != hipSuccess ||
-        (e = d_count.alloc(8)) != hipSuccess || (e = d_out.alloc(std::max<uint64_t>(capacity, 1) * 8)) != hipSuccess ||
-        (e = d_lcoff.alloc(l_coff.size() * 4)) != hipSuccess || (e = d_lpar.alloc(l_par.size() * 4)) != hipSuccess)
+        (e = d_count.alloc(8)) != hipSuccess || (e = d_out.alloc(std::max<uint64_t>(capacity, 1) * 8)) != hipSuccess)
         return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    e = hipMemcpy(d_meta.p, meta.data(), (size_t)N * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_ref.p, ref_idx.data(), n_sites, hipMemcpyHostToDevice);
+    if (!plan->dev_topology) {
+        if ((e = d_meta.alloc((size_t)N * 4)) != hipSuccess || (e = d_cs.alloc((C + 1) * 4)) != hipSuccess ||
+            (e = d_cd.alloc((C + 1) * 4)) != hipSuccess || (e = d_cm.alloc(C * 4)) != hipSuccess ||
+            (e = d_co.alloc(chunk_open.size() * 4)) != hipSuccess)
+            return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        e = hipMemcpy(d_meta.p, meta.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_cs.p, chunk_start.data(), (C + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_cd.p, chunk_depth.data(), (C + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_cm.p, chunk_min.data(), C * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_co.p, chunk_open.data(), chunk_open.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hipf(e, "upload of the topology");
+        plan->dev_topology = true;
+    }
+    if (levels && !plan->dev_levels) {
+        if ((e = d_lcoff.alloc(l_coff.size() * 4)) != hipSuccess || (e = d_lpar.alloc(l_par.size() * 4)) != hipSuccess)
+            return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        e = hipMemcpy(d_lcoff.p, l_coff.data(), l_coff.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_lpar.p, l_par.data(), l_par.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hipf(e, "upload of the level tables");
+        plan->dev_levels = true;
+    }
+    // node id -> key of the form in use (BFS index for the level-synchronous kernels, DFS index for the stack forms)
+    DevBuf& d_id2key = levels ? plan->d_id2bfs : plan->d_id2dfs;
+    if (!d_id2key.p) {
+        std::vector<uint32_t> id2key(N);
+        for (uint32_t i = 0; i < N; i++) id2key[i] = levels ? f.dfs2bfs[id2dfs[i]] : id2dfs[i];
+        if ((e = d_id2key.alloc((size_t)N * 4)) != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        if ((e = hipMemcpy(d_id2key.p, id2key.data(), (size_t)N * 4, hipMemcpyHostToDevice)) != hipSuccess) return hipf(e, "upload of the id map");
+    }
+    e = hipMemcpy(d_ref.p, ref_idx.data(), n_sites, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_voff.p, var_off, (size_t)(n_sites + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nv) e = hipMemcpy(d_vdfs.p, vdfs.data(), nv * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nv) e = hipMemcpy(d_vnuc.p, vnuc.data(), nv, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_cs.p, chunk_start.data(), (C + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_cd.p, chunk_depth.data(), (C + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_cm.p, chunk_min.data(), C * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_co.p, chunk_open.data(), chunk_open.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nv) e = hipMemcpy(d_vraw.p, var_node, nv * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nv) e = hipMemcpy(d_vnraw.p, var_nuc, nv, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_count.p, 0, 8);
-    if (e == hipSuccess && levels) e = hipMemcpy(d_lcoff.p, l_coff.data(), l_coff.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && levels) e = hipMemcpy(d_lpar.p, l_par.data(), l_par.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipf(e, "upload");
+    uint32_t* keys_final = d_vdfs.as<uint32_t>();
+    uint8_t* nuc_final = d_vnuc.as<uint8_t>();
+    {
+        size_t ptmp = 0;
+        e = fitch_rows_temp_bytes(nv, n_sites, &ptmp);
+        if (e == hipSuccess) e = d_ptmp.alloc(ptmp);
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc (row preparation): ") + hipGetErrorString(e));
+        bool in_b = true;
+        e = launch_fitch_prepare(d_vraw.as<uint32_t>(), d_vnraw.as<uint8_t>(), d_voff.as<uint32_t>(), n_sites, nv, N,
+                                 d_id2key.as<uint32_t>(), d_vdfs2.as<uint32_t>(), d_vnuc2.as<uint8_t>(), d_vdfs.as<uint32_t>(),
+                                 d_vnuc.as<uint8_t>(), d_pflags.as<uint32_t>(), d_ptmp.p, ptmp, &in_b, nullptr);
+        if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return set_error(WEPP_EINVAL, "var_node out of range"); }
+        if (e != hipSuccess) return hipf(e, "preparation of the rows");
+        if (!in_b) { keys_final = d_vdfs2.as<uint32_t>(); nuc_final = d_vnuc2.as<uint8_t>(); }
+    }
+    const double t_up = now_ms();
     FitchLevels fl{N, levels ? (uint32_t)level_off.size() - 1 : 0, d_lcoff.as<uint32_t>(), d_lpar.as<uint32_t>()};
     FitchTree ft{N, f.max_depth, C, d_meta.as<uint32_t>(), d_cs.as<uint32_t>(), d_cd.as<uint32_t>(),
                  d_cm.as<uint32_t>(), d_co.as<uint32_t>()};
-    FitchSites fs{n_sites, d_ref.as<uint8_t>(), d_voff.as<uint32_t>(), d_vdfs.as<uint32_t>(), d_vnuc.as<uint8_t>()};
+    FitchSites fs{n_sites, d_ref.as<uint8_t>(), d_voff.as<uint32_t>(), keys_final, nuc_final};
     for (uint32_t b0 = 0; b0 < nbatches; b0 += group) {
         const uint32_t nb = std::min(group, nbatches - b0);
         if (levels) {
@@ -242,6 +306,9 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
     unsigned long long cnt = 0;
     e = hipMemcpy(&cnt, d_count.p, 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return hipf(e, "Fitch-Sankoff kernels");
+    const double t_kern = now_ms();
+    struct Stamp { double a, b, c, d; ~Stamp() { g_fitch_ms[0] = b - a; g_fitch_ms[1] = c - b; g_fitch_ms[2] = d - c; g_fitch_ms[3] = now_ms() - d; } }
+        stamp{t_begin, t_prep, t_up, t_kern};
     *n_out = cnt;
     if (cnt > capacity) return set_error(WEPP_ELIMIT, "output buffers too small: " + std::to_string(cnt) + " mutations");
     if (cnt == 0) return WEPP_OK;
@@ -263,12 +330,18 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
                                     d_v1.as<uint32_t>(), cnt, 28 + site_bits, d_tmp.p, tmp_bytes, nullptr);
         // decoded on the device into the caller's four arrays (the raw queue entries are dead after the key
         // kernel: its memory takes the decoded rows and node ids), then copied out (staged_copy.hpp)
-        DevBuf d_b2i, d_pm;
+        DevBuf d_pm;
+        DevBuf& d_b2i = plan->d_b2i;
         uint32_t* d_site = d_out.as<uint32_t>();
         uint32_t* d_node = d_site + cnt;
-        if (e == hipSuccess && ((e = d_b2i.alloc((size_t)N * 4)) != hipSuccess || (e = d_pm.alloc(cnt * 2)) != hipSuccess))
+        if (e == hipSuccess && (e = d_pm.alloc(cnt * 2)) != hipSuccess)
             return set_error(WEPP_ENOMEM, std::string("hipMalloc (decoding the mutations): ") + hipGetErrorString(e));
-        if (e == hipSuccess) e = hipMemcpy(d_b2i.p, f.bfs2id.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !plan->dev_b2i) {
+            if ((e = d_b2i.alloc((size_t)N * 4)) != hipSuccess)
+                return set_error(WEPP_ENOMEM, std::string("hipMalloc (decoding the mutations): ") + hipGetErrorString(e));
+            e = hipMemcpy(d_b2i.p, f.bfs2id.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) plan->dev_b2i = true;
+        }
         if (e == hipSuccess)
             e = launch_fitch_decode(d_k1.as<unsigned long long>(), d_v1.as<uint32_t>(), d_b2i.as<uint32_t>(), cnt, d_site,
                                     d_node, d_pm.as<uint8_t>(), d_pm.as<uint8_t>() + cnt, nullptr);
@@ -299,4 +372,20 @@ extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t
         out_mut[i] = (uint8_t)(1u << ((r.y >> 30) & 3u));
     }
     return WEPP_OK;
+}
+
+extern "C" int wepp_fitch_sites(const wepp_tree_desc* tree, int device, uint32_t n_sites, const uint8_t* site_ref,
+                                const uint32_t* var_off, const uint32_t* var_node, const uint8_t* var_nuc,
+                                uint64_t capacity, uint64_t* n_out, uint32_t* out_site, uint32_t* out_node,
+                                uint8_t* out_par, uint8_t* out_mut) {
+    if (!tree || !n_out || !var_off || (n_sites && !site_ref)) return set_error(WEPP_EINVAL, "null argument");
+    *n_out = 0;
+    if (n_sites == 0) return WEPP_OK;
+    wepp_fitch_plan_t* plan = nullptr;
+    int rc = wepp_fitch_plan_create(tree, device, &plan);
+    if (rc != WEPP_OK) return rc;
+    rc = wepp_fitch_plan_run(plan, n_sites, site_ref, var_off, var_node, var_nuc, capacity, n_out, out_site, out_node, out_par,
+                             out_mut);
+    wepp_fitch_plan_destroy(plan);
+    return rc;
 }
