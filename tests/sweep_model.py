@@ -56,7 +56,11 @@ class FlatModel:
             setattr(self, name, flat.get(name, self.stream))
         self.NB = len(self.blk_node0) - 1
         self.N = len(self.nkey)
-        self.tau = int(flat.stats.stream_tau[self.stream])
+        # a window stream ("w<i>"): the whole tree as the reads of one genome window see it; elements stand for
+        # ncnt nodes each (pseudo-nodes for the runs of nodes the window's reads cannot tell apart)
+        self.window = isinstance(self.stream, str)
+        self.ncnt = flat.get("ncnt", self.stream) if self.window else None
+        self.tau = 0x7FFFFFFF if self.window else int(flat.stats.stream_tau[self.stream])
         self.cp_stride = max(1, (self.NB + 1023) // 1024)
 
     def _c_none(self, S):
@@ -114,7 +118,7 @@ class FlatModel:
             lbmin = 0x3FFFFFFF
             for e in hits:
                 # crown streams: per-event bound; whole-tree stream: the block minimum
-                eager = self.stream != self.f.n_streams - 1
+                eager = (not self.window) and self.stream != self.f.n_streams - 1
                 lbmin = min(lbmin, int(self.ev_lb[e]) if (eager and e < e0 + 128) else min(min_all, 0 if e >= e0 + 128 else min_all))
                 w = int(self.ev_word[e])
                 o = int(self.ev_meta[e]) & 63
@@ -174,10 +178,11 @@ class FlatModel:
                 if elig and pruned:
                     assert score > bs, "pruning bound violated"
                 if elig and not pruned:
+                    k = int(self.ncnt[n0 + i]) if self.window else 1
                     if score < bs:
-                        bs, br, cnt = score, rank, 1
+                        bs, br, cnt = score, rank, k
                     elif score == bs:
-                        cnt += 1
+                        cnt += k
                         br = min(br, rank)
             c += net
         return bs, br, cnt, c

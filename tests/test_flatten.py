@@ -197,3 +197,36 @@ def test_crown_is_ancestor_closed_and_covers_low_scores():
         have = set((keys & 0xFFFFFFFF).tolist())
         assert want <= have
         assert len(have) == fv.stats.stream_nodes[i] < 50000
+
+
+def test_window_streams_match_oracle(oracle):
+    """The whole tree as the reads of one genome window see it (touched nodes + pseudo-nodes for the runs in
+    between): the sweep model on a window stream against the oracle, for reads whose positions lie inside."""
+    from wepp_amd import _lib
+    rng = np.random.default_rng(21)
+    checked = 0
+    for it in range(12):
+        g = w.generate_tree(100 + it, int(rng.integers(300, 3000)), genome_len=5000, p_ambiguous=0.02, p_masked_node=0.01,
+                            root_mutations=int(rng.integers(0, 3)))
+        fv = w.FlatView(g.tree)
+        ot = oracle.OracleTree(g.tree)
+        reads = g.reads(200 + it, 40, read_len=900, amplicon_len=900, amplicon_step=700, p_substitution=0.02, p_n=0.01, p_iupac=0.1)
+        want = ot.place_batch(reads, 4)
+        models = {}
+        for r in range(reads.n_reads):
+            p, rf, a, ms = reads.entries(r)
+            if len(p) == 0:
+                continue
+            wi = int(p.min()) // 1024
+            if int(p.max()) >= wi * 1024 + 2560:
+                continue
+            if wi not in models:
+                models[wi] = sm.FlatModel(fv, "w%d" % wi)
+            S = [(int(p[i]), int(rf[i]), int(a[i]), int(ms[i])) for i in range(len(p))]
+            got = models[wi].place_full(S, nchunks=1 + r % 3)
+            assert (got["score"], got["num_best"], got["best_j"], got["has_unique"]) == \
+                (want["score"][r], want["num_best"][r], want["best_j"][r], want["has_unique"][r]), (it, r, wi)
+            checked += 1
+        for wi, m in models.items():
+            assert m.N < g.tree.n_nodes or g.tree.n_nodes < 50        # fewer elements than nodes
+    assert checked > 300

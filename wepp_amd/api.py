@@ -224,7 +224,7 @@ class FlatView:
         """Host array `name`; stream fields take stream=i (default: whole-tree stream)."""
         base = name
         if stream is not None:
-            name = f"{int(stream)}:{name}"
+            name = f"{stream}:{name}" if isinstance(stream, str) else f"{int(stream)}:{name}"   # "w3" = window stream 3
         data = ctypes.c_void_p()
         cnt = ctypes.c_uint64()
         eb = ctypes.c_uint32()

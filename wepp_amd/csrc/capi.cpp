@@ -89,6 +89,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     d.walk_eager_nodes = getenv("WEPP_WALK_EAGER_NODES") ? (uint32_t)atoll(getenv("WEPP_WALK_EAGER_NODES")) : WALK_EAGER_MAX_NODES;
     int rc;
 #define UP(dst, vec) if ((rc = upload(h, vec, &dst)) != WEPP_OK) { release(h); return rc; }
+    // (inside up_stream a failure returns the code; the caller releases the handle)
     UP(d.node_woff, f.node_woff) UP(d.words, f.words) UP(d.nstat, f.nstat) UP(d.rank2dfs, f.rank2dfs)
     UP(d.dfs2bfs, f.dfs2bfs) UP(d.rank2bfs, f.rank2bfs)
     {
@@ -100,29 +101,40 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     UP(d.maxnest, f.maxnest)
     UP(h->epp_word, f.epp_word) UP(h->epp_node, f.epp_node)
     h->epp_events = f.epp_word.size();
-    for (size_t i = 0; i < f.streams.size(); i++) {
-        const Stream& st = f.streams[i];
-        DevStream ds{};
+    auto up_stream = [&](const Stream& st, uint32_t tier, bool eager, DevStream& ds) -> int {
+        ds = DevStream{};
         ds.n = st.n;
         ds.NB = st.NB;
         ds.cp_stride = st.cp_stride;
         ds.ncp = (uint32_t)st.cp_off.size() - 1;
-        ds.eager = (i + 1 < f.streams.size()) ? 1u : 0u;
-        ds.tier = (uint32_t)i;
+        ds.eager = eager ? 1u : 0u;
+        ds.tier = tier;
         ds.e_pad = (uint32_t)st.E;
         UP(ds.nkey, st.nkey) UP(ds.nstat, st.nstat) UP(ds.blk_node0, st.blk_node0) UP(ds.blk_eoff, st.blk_eoff)
         UP(ds.ev_meta, st.ev_meta) UP(ds.cp_off, st.cp_off) UP(ds.cp_word, st.cp_word)
-        {
-            // the sweep loads two events per lane from every block start and the summaries of the next
-            // three blocks without looking at the stream's end: padding behind the last event / block
-            std::vector<uint32_t> evw(st.ev_word);
-            evw.resize(evw.size() + EV_TAIL_PAD, W_PAD);
-            std::vector<uint8_t> evl(st.ev_lb);
-            evl.resize(evl.size() + EV_TAIL_PAD, 255);
-            std::vector<BlkSum> sums(st.blk_sum);
-            sums.resize(sums.size() + SUM_TAIL_PAD, sums.empty() ? BlkSum{} : sums.back());
-            UP(ds.ev_word, evw) UP(ds.ev_lb, evl) UP(ds.blk_sum, sums)
-        }
+        if (!st.ncnt.empty()) UP(ds.ncnt, st.ncnt)
+        // the sweep loads two events per lane from every block start and the summaries of the next
+        // three blocks without looking at the stream's end: padding behind the last event / block
+        std::vector<uint32_t> evw(st.ev_word);
+        evw.resize(evw.size() + EV_TAIL_PAD, W_PAD);
+        std::vector<uint8_t> evl(st.ev_lb);
+        evl.resize(evl.size() + EV_TAIL_PAD, 255);
+        std::vector<BlkSum> sums(st.blk_sum);
+        sums.resize(sums.size() + SUM_TAIL_PAD, sums.empty() ? BlkSum{} : sums.back());
+        UP(ds.ev_word, evw) UP(ds.ev_lb, evl) UP(ds.blk_sum, sums)
+        return WEPP_OK;
+    };
+    for (size_t i = 0; i < f.wstreams.size(); i++) {
+        DevStream ds;
+        if ((rc = up_stream(f.wstreams[i], (uint32_t)(f.streams.size() - 1), false, ds)) != WEPP_OK) return rc;
+        h->wstreams.push_back(ds);
+        h->wstream_bytes.push_back(f.wstreams[i].stream_bytes());
+    }
+    d.n_windows = (uint32_t)f.wstreams.size();
+    for (size_t i = 0; i < f.streams.size(); i++) {
+        const Stream& st = f.streams[i];
+        DevStream ds;
+        if ((rc = up_stream(st, (uint32_t)i, i + 1 < f.streams.size(), ds)) != WEPP_OK) return rc;
         h->streams.push_back(ds);
         h->stream_bytes.push_back(st.stream_bytes());
         {
@@ -296,7 +308,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t* info = mat->h_info;
 
     // ---- plan the launches ---------------------------------------------------------
-    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense; size_t part_off; const uint32_t* lst; };
+    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense, window; size_t part_off; const uint32_t* lst; const DevStream* st; uint64_t sbytes; };
     Plan plans[MAX_PLANS];
     uint32_t np = 0;
     size_t part_total = 0;
@@ -304,13 +316,15 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     if (bm_bytes > 128 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
     // walk plans (device_mat.hpp): the reads of one (class, stream) that walk their own events
     WalkPlans walk[2]{}, walkc[2]{};
+    uint32_t walk_off[2][MAX_STREAMS] = {}, walkc_off[2] = {0, 0};   // list offsets of the walk plans
     uint64_t walk_reads = 0, n_jobs[2] = {0, 0};
     uint32_t walkc_reads[2] = {0, 0};
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
-        const uint32_t t = id & 15u, cls = id >> 4;
-        if (t >= ns || cls > PLAN_WALKC16) return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+        const uint32_t t = id & PLAN_IDX_MASK, cls = id >> PLAN_SHIFT;
+        if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : t >= ns))
+            return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
         if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
             // the reads with many events: their walks are cut into jobs (below); the plans of a chunked class
             // are the streams, the jobs of stream t numbered behind those of the streams before it
@@ -320,7 +334,8 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             d.tier = t;
             d.n_list = info[TI_JOBS + cc * MAX_STREAMS + t];
             d.job0 = (uint32_t)n_jobs[cc];
-            d.list = list + info[TI_OFF + (cls << 4)];
+            walkc_off[cc] = info[TI_OFF + (cls << PLAN_SHIFT)];
+            d.list = nullptr;
             d.wave_end = (wc.n ? wc.p[wc.n - 1].wave_end : 0u) + (d.n_list + 63) / 64;
             wc.n++;
             n_jobs[cc] += d.n_list;
@@ -328,19 +343,23 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             walk_reads += count;
             continue;
         }
-        if (cls != PLAN_SWEEP) {
+        if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
             WalkPlans& wp = walk[cls];
             WalkPlanDev& d = wp.p[wp.n];
             d.tier = t;
             d.n_list = count;
-            d.list = list + info[TI_OFF + id];
+            walk_off[cls][wp.n] = info[TI_OFF + id];
+            d.list = nullptr;
             d.wave_end = (wp.n ? wp.p[wp.n - 1].wave_end : 0u) + (count + 63) / 64;
             wp.n++;
             walk_reads += count;
             continue;
         }
         Plan& p = plans[np++];
-        p.t = t;
+        p.window = cls == PLAN_WIN;
+        p.t = p.window ? ns - 1 : t;                 // (a window stream is the whole tree for its reads)
+        p.st = p.window ? &mat->wstreams[t] : &mat->streams[t];
+        p.sbytes = p.window ? mat->wstream_bytes[t] : mat->stream_bytes[t];
         p.count = count;
         p.off = info[TI_OFF + id];
         // reads per tile: at most MAX_TILE_ENTRIES read words per tile (long reads share a
@@ -361,7 +380,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         p.key_cap = p.dense ? kcap : 0;
         p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, kcap, p.dense) : bm_bytes;
         // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
-        const DevStream& st = mat->streams[t];
+        const DevStream& st = *p.st;
         static const uint32_t target_waves = getenv("WEPP_TARGET_WAVES") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES")) : 4096;   // 16 resident single-wave workgroups per CU x 256 CUs; 2048 / 8192 / 16384 measured slower (WEPP_TARGET_WAVES: tuning aid)
         uint32_t nchunks = std::max<uint32_t>(1, (target_waves + p.ntiles - 1) / p.ntiles);
         // ... and chunks no longer than what stays in an XCD's L2 while the tiles sweep it: the waves of
@@ -369,7 +388,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         // resident waves walk the same ~1.5 MB of the stream together instead of drifting apart over
         // 118 MB (whole-tree sweep of 1 M reads: 432 ms with one chunk per tile, 235 ms with 80)
         static const uint64_t chunk_bytes = getenv("WEPP_CHUNK_BYTES") ? (uint64_t)atoll(getenv("WEPP_CHUNK_BYTES")) : SWEEP_CHUNK_BYTES;
-        nchunks = std::max<uint32_t>(nchunks, (uint32_t)((mat->stream_bytes[t] + chunk_bytes - 1) / chunk_bytes));
+        nchunks = std::max<uint32_t>(nchunks, (uint32_t)((p.sbytes + chunk_bytes - 1) / chunk_bytes));
         nchunks = std::min<uint32_t>(nchunks, (uint32_t)std::max<uint64_t>(1, SWEEP_MAX_PARTIAL_BYTES / ((uint64_t)count * 12)));
         // ... but a chunk's wave pays a set-up (bitmap, read words, checkpoint) worth several blocks: no chunk
         // shorter than 8 blocks, however few tiles the plan has (a plan of a few hundred reads used to be cut into
@@ -396,11 +415,21 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         }
     }
     char* part_base = (char*)mat->ws + fixed_bytes;
+    // (the workspace may have moved above: every pointer into it is taken from here on)
+    for (uint32_t cls = 0; cls < 2; cls++)
+        for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = list + walk_off[cls][k];
+    for (uint32_t cc = 0; cc < 2; cc++)
+        for (uint32_t k = 0; k < walkc[cc].n; k++) walkc[cc].p[k].list = list + walkc_off[cc];
+    static const bool debug_plans = getenv("WEPP_DEBUG_PLANS") != nullptr;
     for (uint32_t i = 0; i < np; i++) {
         Plan& p = plans[i];
         p.lst = list + p.off;
+        if (debug_plans)
+            fprintf(stderr, "[plan] %s t=%u count=%u off=%u T=%u ntiles=%u nchunks=%u bpc=%u NB=%u ncp=%u dense=%d lds=%u ent_cap=%u key_cap=%u part_off=%zu\n",
+                    p.window ? "window" : "sweep", p.t, p.count, p.off, p.T, p.ntiles, p.nchunks, p.bpc, p.st->NB, p.st->ncp, (int)p.dense,
+                    p.lds_bytes, p.ent_cap, p.key_cap, p.part_off);
         // the reads that sweep the whole tree go by first listed position (sort_reads.hip)
-        if (sort_reads && p.t + 1 == ns && p.count >= SORT_MIN_READS) {
+        if (sort_reads && !p.window && p.t + 1 == ns && p.count >= SORT_MIN_READS) {
             HIP_TRY(launch_first_pos(list + p.off, p.count, d_read_off, d_read_word, key_in, stream));
             HIP_TRY(launch_sort_reads(key_in, key_out, list + p.off, val_in, p.count, sort_tmp, sort_temp, stream));
             p.lst = val_in;
@@ -427,7 +456,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (plans[i].s_in_lds && !plans[i].dense && !unfused && n_plain < MAX_STREAMS) order[n_plain++] = i;
         else others[n_other++] = i;
         passes += plans[i].ntiles;                                   // every tile sweeps its stream once
-        bytes += (uint64_t)plans[i].ntiles * mat->stream_bytes[plans[i].t];
+        bytes += (uint64_t)plans[i].ntiles * plans[i].sbytes;
     }
     std::sort(order, order + n_plain, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
     const bool walks = walk[0].n || walk[1].n || walkc[0].n || walkc[1].n;
@@ -442,6 +471,9 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
     uint32_t joins[MAX_STREAMS], n_joins = 0;
+    // side streams of the sweeps that are launched on their own (dense / window / out-of-LDS plans); the last
+    // three belong to the walks
+    constexpr uint32_t OTHER_SIDE_STREAMS = MAX_STREAMS - 3;
     if (walks) {
         // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
         // sweeps run side by side (the walks wait on memory most of the time)
@@ -507,19 +539,19 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     }
     for (uint32_t k = 0; k < n_other; k++) {
         const Plan& p = plans[others[k]];
-        hipStream_t q = fork ? mat->side[k % (MAX_STREAMS - 3)] : stream;
+        hipStream_t q = fork ? mat->side[k % OTHER_SIDE_STREAMS] : stream;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
-        HIP_TRY(launch_sweep(mat->dev, mat->streams[p.t], d_read_off, d_read_word, root_score, p.lst, p.count, p.T,
+        HIP_TRY(launch_sweep(mat->dev, *p.st, d_read_off, d_read_word, root_score, p.lst, p.count, p.T,
                              p.ntiles,
                              p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, p.lst, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
-        if (fork && (k + (MAX_STREAMS - 3) >= n_other)) {
+        if (fork && (k + OTHER_SIDE_STREAMS >= n_other)) {
             // the last launch on every side stream joins the caller's stream
-            HIP_TRY(hipEventRecord(mat->join_ev[k % (MAX_STREAMS - 3)], q));
-            joins[n_joins++] = k % (MAX_STREAMS - 3);
+            HIP_TRY(hipEventRecord(mat->join_ev[k % OTHER_SIDE_STREAMS], q));
+            joins[n_joins++] = k % OTHER_SIDE_STREAMS;
         }
     }
     if (n_plain) {
@@ -528,7 +560,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         for (uint32_t k = 0; k < n_plain; k++) {
             const Plan& p = plans[order[k]];
             SweepPlanDev& d = pl.p[k];
-            d.st = mat->streams[p.t];
+            d.st = *p.st;
             d.list = p.lst;
             d.n_list = p.count;
             d.T = p.T;
@@ -892,7 +924,8 @@ extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_r
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tiers, mat->ws, n_reads, hipMemcpyDeviceToHost));
-    for (uint32_t r = 0; r < n_reads; r++) tiers[r] &= 15u;     // the workspace holds plan ids: (class << 4) | stream
+    for (uint32_t r = 0; r < n_reads; r++)       // the workspace holds plan ids: (class << PLAN_SHIFT) | stream or window
+        tiers[r] = (tiers[r] >> PLAN_SHIFT) == PLAN_WIN ? (uint8_t)(mat->dev.n_streams - 1) : (uint8_t)(tiers[r] & PLAN_IDX_MASK);
     return WEPP_OK;
 }
 

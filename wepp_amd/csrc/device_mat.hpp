@@ -36,6 +36,7 @@ struct DevStream {
     const uint8_t* ev_lb;
     const uint32_t* cp_off;
     const uint32_t* cp_word;
+    const uint32_t* ncnt;     // window streams: nodes an element stands for (nullptr on the others: one each)
 };
 
 // the position index and range-query structures of one stream (flatmat.hpp), for k_walk
@@ -55,6 +56,7 @@ struct DevWalk {
 // tree-wide arrays (global DFS indices)
 struct DevMAT {
     uint32_t N, bm_words, max_pos, n_streams;
+    uint32_t n_windows;           // window streams (flatmat.hpp: WIN_SIZE positions every WIN_STRIDE)
     uint32_t walk_eager_nodes;    // streams up to this many nodes: exact range query without the sparse pre-test
     int32_t root_base;
     int32_t tau[MAX_STREAMS];
@@ -70,12 +72,14 @@ struct DevMAT {
     const DevWalk* walks;         // [n_streams] device array
 };
 
-// A placement call sorts its reads into PLANS: plan id = (class << 4) | stream.  Class = how the read is
+// A placement call sorts its reads into PLANS: plan id = (class << PLAN_SHIFT) | stream (or window).  Class = how the read is
 // placed: by the per-read walk of its own events (k_walk) when it lists at most WALK8_K / WALK16_K positions and
 // the intervals it can hold open at once (sum of maxnest over its positions) fit WALK8_STACK / WALK16_STACK, by a
 // sweep of the whole stream otherwise.
-constexpr uint32_t MAX_PLANS = 128;
-constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC8 = 3, PLAN_WALKC16 = 4;
+constexpr uint32_t PLAN_SHIFT = 5, PLAN_IDX_MASK = 31, MAX_PLANS = 256;
+constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC8 = 3, PLAN_WALKC16 = 4, PLAN_WIN = 5;
+// PLAN_WIN: a read with more entries than a walk takes, all inside one genome window, sweeps that window's
+// stream (the whole tree reduced to the nodes that mutate the window + pseudo-nodes) instead of the whole tree.
 // PLAN_WALKC8 / 16: a read with many events at its positions (a frequently mutated site) walks them as several
 // independent JOBS of about WALK_JOB_EVENTS events each -- node ranges cut at quantiles of its longest list;
 // a job finds the state of a sequential walk at its first node by binary searches in the read's lists and

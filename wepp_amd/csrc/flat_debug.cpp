@@ -50,7 +50,15 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
         FIELD(f, node_woff) FIELD(f, words) FIELD(f, rank2dfs) FIELD(f, dfs2bfs) FIELD(f, bfs2id) FIELD(f, dfs2id)
         FIELD(f, parent_dfs) FIELD(f, dfs_end) FIELD(f, num_leaves) FIELD(f, epp_word) FIELD(f, epp_node) FIELD(f, maxnest) FIELD(f, rank2bfs)
     }
-    const wepp::Stream& st = f.streams[si];
+    // "w<i>:" selects window stream i
+    const bool win = name[0] == 'w' && name[1] >= '0' && name[1] <= '9' && std::strchr(name, ':');
+    if (win) {
+        si = (size_t)std::strtoul(name + 1, nullptr, 10);
+        name = std::strchr(name, ':') + 1;
+        if (si >= f.wstreams.size()) return wepp::set_error(WEPP_EINVAL, "window stream index out of range");
+    }
+    const wepp::Stream& st = win ? f.wstreams[si] : f.streams[si];
+    FIELD(st, ncnt)
     FIELD(st, nkey) FIELD(st, nstat) FIELD(st, blk_node0) FIELD(st, blk_eoff) FIELD(st, blk_sum) FIELD(st, ev_word)
     FIELD(st, ev_meta) FIELD(st, ev_lb) FIELD(st, cp_off) FIELD(st, cp_word)
     FIELD(st, ix_head) FIELD(st, ix_ent) FIELD(st, ix_nest) FIELD(st, nrec) FIELD(st, rq_pre) FIELD(st, rq_suf) FIELD(st, rq_dst) FIELD(st, sp)

@@ -28,32 +28,40 @@ inline uint32_t cost0(uint32_t x, uint32_t ref) { return (x != 0 && x != ref) ? 
 }  // namespace
 namespace {
 
-// Builds the sweep stream of the ancestor-closed node subset `sel` (sorted
-// global DFS indices, sel[0] == 0).
-int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err) {
-    const uint32_t n = (uint32_t)sel.size();
-    const uint32_t N = f.N;
+// The elements of a stream, in stream order.  A crown: the selected nodes themselves.  A window stream: the
+// nodes that mutate a position of the window plus PSEUDO-NODES, one per maximal run of skipped nodes between
+// two places where a read of the window can change its running c_S (a selected node, the end of a selected
+// node's subtree) -- a pseudo-node carries the run's best statically eligible node and how many tie it.
+struct StreamElems {
+    std::vector<uint32_t> g;         // global DFS index of a real element, IX_NONE for a pseudo-node
+    std::vector<int64_t> nkey;       // (static score << 32) | rank of the element / of the run's best node
+    std::vector<uint32_t> nstat;     // a pseudo-node: NS_ELIG0 iff its run holds an eligible node
+    std::vector<uint32_t> cnt;       // nodes the element stands for at its (score, eligible): 1 for a real one
+    std::vector<int32_t> min_all;    // min static score over ALL nodes of the element (pruning bound)
+    std::vector<uint32_t> lend;      // last element of the element's subtree
+    std::vector<uint32_t> lpar;      // innermost REAL element whose subtree holds the element (0 for the root)
+    uint32_t pos_lo = 0, pos_hi = 0xFFFFFFFFu;   // only mutations with pos_lo <= position < pos_hi become events
+    bool weighted = false;           // has pseudo-nodes: the stream carries ncnt
+    bool walk_index = true;          // build the position index / range-query tables of the walk
+};
+
+int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::string& err) {
+    const uint32_t n = (uint32_t)el.g.size();
     st.n = n;
-    // local index of a global node / number of selected nodes with global index <= g
-    std::vector<uint32_t> upto(N);
-    {
-        uint32_t c = 0, k = 0;
-        for (uint32_t g = 0; g < N; g++) {
-            if (k < n && sel[k] == g) { c++; k++; }
-            upto[g] = c;
+    st.nkey = el.nkey;
+    st.nstat = el.nstat;
+    if (el.weighted) st.ncnt = el.cnt;
+    const std::vector<uint32_t>&lend = el.lend, &lpar = el.lpar;
+    // the mutation words of an element that take part in this stream
+    auto words_of = [&](uint32_t i, auto&& fn) {
+        const uint32_t g = el.g[i];
+        if (g == IX_NONE) return;
+        for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+            const uint32_t p = f.words[w] & W_POS_MASK;
+            if (p >= el.pos_lo && p < el.pos_hi) fn(w);
         }
-    }
-    auto local_of = [&](uint32_t g) { return upto[g] - 1; };
-    st.nkey.resize(n);
-    st.nstat.resize(n);
-    std::vector<uint32_t> lend(n), lpar(n);
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t g = sel[i];
-        st.nkey[i] = f.nkey[g];
-        st.nstat[i] = f.nstat[g];
-        lend[i] = upto[f.dfs_end[g]] - 1;          // last selected node of the subtree
-        lpar[i] = i ? local_of(f.parent_dfs[g]) : 0;
-    }
+    };
+    auto n_words = [&](uint32_t i) { uint32_t c = 0; words_of(i, [&](uint32_t) { c++; }); return c; };
     // events at local position x: enter words of node x, and exit words of every
     // node a with selected descendants whose subtree ends at x-1.  A node without
     // selected descendants emits no exit; its enter is flagged W_LEAF (it changes
@@ -61,8 +69,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
     // mutations applied.
     std::vector<uint32_t> evcnt((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t g = sel[i];
-        const uint32_t nm = f.node_woff[g + 1] - f.node_woff[g];
+        const uint32_t nm = n_words(i);
         evcnt[i] += nm;
         if (lend[i] > i && lend[i] + 1 < n) evcnt[lend[i] + 1] += nm;
     }
@@ -95,12 +102,12 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
         st.ev_lb.assign(st.E, 255);
         // min static score over the (selected) subtree of every node, and over the rest of its block
         std::vector<int32_t> submin(n), sufmin(n);
-        for (uint32_t i = 0; i < n; i++) submin[i] = (int32_t)(st.nkey[i] >> 32);
+        for (uint32_t i = 0; i < n; i++) submin[i] = el.min_all[i];
         for (uint32_t i = n; i-- > 1;) submin[lpar[i]] = std::min(submin[lpar[i]], submin[i]);
         for (uint32_t b = 0; b < st.NB; b++) {
             int32_t run = SCORE_INF;
             for (uint32_t d = st.blk_node0[b + 1]; d-- > st.blk_node0[b];) {
-                run = std::min(run, (int32_t)(st.nkey[d] >> 32));
+                run = std::min(run, el.min_all[d]);
                 sufmin[d] = run;
             }
         }
@@ -118,26 +125,25 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
         }
         for (uint32_t i = 0; i < n; i++) {           // exits take the first slots of a position
             if (lend[i] > i && lend[i] + 1 < n) {
-                const uint32_t g = sel[i], x = lend[i] + 1;
+                const uint32_t x = lend[i] + 1;
                 const uint32_t xoff = x - st.blk_node0[blk_of[x]];
-                for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+                words_of(i, [&](uint32_t w) {
                     const uint32_t e = fill[x]++;
                     st.ev_word[e] = f.words[w] | W_EXIT;
                     st.ev_meta[e] = (uint8_t)xoff;
                     st.ev_lb[e] = clamp8(sufmin[x]);
-                }
+                });
             }
         }
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t g = sel[i];
             const bool leaf = (lend[i] == i) && i != 0;
             const uint32_t off = i - st.blk_node0[blk_of[i]];
-            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+            words_of(i, [&](uint32_t w) {
                 const uint32_t e = fill[i]++;
                 st.ev_word[e] = f.words[w] | (leaf ? W_LEAF : 0);
                 st.ev_meta[e] = (uint8_t)off;
                 st.ev_lb[e] = clamp8(submin[i]);
-            }
+            });
         }
     }
     st.blk_sum.assign(st.NB, BlkSum{SCORE_INF, 0xFFFFFFFFu, 0, SCORE_INF, 0, 0, 0, 0});
@@ -146,28 +152,24 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
         for (uint32_t d = st.blk_node0[b]; d < st.blk_node0[b + 1]; d++) {
             const int32_t bs = (int32_t)(st.nkey[d] >> 32);
             const uint32_t rk = (uint32_t)(st.nkey[d] & 0xFFFFFFFFll);
-            s.min_all = std::min(s.min_all, bs);
+            s.min_all = std::min(s.min_all, el.min_all[d]);
             if (!(st.nstat[d] & NS_ELIG0)) continue;
-            if (bs < s.base) { s.base = bs; s.rank = rk; s.cnt = 1; }
-            else if (bs == s.base) { s.cnt++; s.rank = std::min(s.rank, rk); }
+            if (bs < s.base) { s.base = bs; s.rank = rk; s.cnt = el.cnt[d]; }
+            else if (bs == s.base) { s.cnt += el.cnt[d]; s.rank = std::min(s.rank, rk); }
         }
         st.blk_sum[b] = s;
     }
     // ---- position index and range-query tables of the walk ------------------------------
-    {
+    if (el.walk_index) {
         const uint32_t np = f.max_pos + 1;
         std::vector<uint32_t> off((size_t)np + 1, 0);
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t g = sel[i];
-            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) off[(f.words[w] & W_POS_MASK) + 1]++;
-        }
+        for (uint32_t i = 0; i < n; i++) words_of(i, [&](uint32_t w) { off[(f.words[w] & W_POS_MASK) + 1]++; });
         for (uint32_t p = 0; p < np; p++) off[p + 1] += off[p] + 1;   // + the sentinel of list p
         const size_t total = off[np];
         st.ix_ent.assign(total, IxEnt{IX_NONE, 0, W_PAD, IX_NONE, IX_NONE, SCORE_INF, 0xFFFFFFFFu, 0});
         std::vector<uint32_t> fill(off.begin(), off.end() - 1);
-        for (uint32_t i = 0; i < n; i++) {          // ascending node index: every list ends up in stream order
-            const uint32_t g = sel[i];
-            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+        for (uint32_t i = 0; i < n; i++)            // ascending node index: every list ends up in stream order
+            words_of(i, [&](uint32_t w) {
                 IxEnt& e = st.ix_ent[fill[f.words[w] & W_POS_MASK]++];
                 e.node = i;
                 e.end = lend[i] + 1;
@@ -175,8 +177,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
                 e.base = (int32_t)(st.nkey[i] >> 32);
                 e.rank = (uint32_t)(st.nkey[i] & 0xFFFFFFFFll);
                 e.nstat = st.nstat[i];
-            }
-        }
+            });
         for (size_t e = 0; e + 1 < total; e++) st.ix_ent[e].next_node = st.ix_ent[e + 1].node;   // (a sentinel's is never read)
         st.ix_head.resize((size_t)np + 1);
         for (uint32_t p = 0; p <= np; p++) st.ix_head[p] = IxHead{off[p], p < np ? st.ix_ent[off[p]].node : IX_NONE};
@@ -277,14 +278,113 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
                 if (lend[a] > a) path.push_back(a);
                 while (a != 0) { a = lpar[a]; path.push_back(a); }
             }
-            for (size_t k = path.size(); k-- > 0;) {
-                const uint32_t g = sel[path[k]];
-                for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) st.cp_word.push_back(f.words[w]);
-            }
+            for (size_t k = path.size(); k-- > 0;) words_of(path[k], [&](uint32_t w) { st.cp_word.push_back(f.words[w]); });
         }
         st.cp_off[ncp] = (uint32_t)st.cp_word.size();
     }
     return WEPP_OK;
+}
+
+// a crown (or the whole tree): the ancestor-closed node subset `sel` (sorted global DFS indices, sel[0] == 0)
+int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err) {
+    const uint32_t n = (uint32_t)sel.size();
+    const uint32_t N = f.N;
+    // number of selected nodes with global index <= g
+    std::vector<uint32_t> upto(N);
+    {
+        uint32_t c = 0, k = 0;
+        for (uint32_t g = 0; g < N; g++) {
+            if (k < n && sel[k] == g) { c++; k++; }
+            upto[g] = c;
+        }
+    }
+    StreamElems el;
+    el.g = sel;
+    el.nkey.resize(n); el.nstat.resize(n); el.cnt.assign(n, 1); el.min_all.resize(n); el.lend.resize(n); el.lpar.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t g = sel[i];
+        el.nkey[i] = f.nkey[g];
+        el.nstat[i] = f.nstat[g];
+        el.min_all[i] = (int32_t)(f.nkey[g] >> 32);
+        el.lend[i] = upto[f.dfs_end[g]] - 1;          // last selected node of the subtree
+        el.lpar[i] = i ? upto[f.parent_dfs[g]] - 1 : 0;
+    }
+    return build_stream_core(f, el, st, err);
+}
+
+// the whole tree as the reads of one genome window [lo, hi) see it: only the nodes that mutate a position of
+// the window are elements of their own; every maximal run of other nodes between two places where such a
+// read's c_S can change becomes one pseudo-node.  20x fewer events than the whole-tree stream for a 2 K window.
+int build_window_stream(const FlatMAT& f, uint32_t lo, uint32_t hi, Stream& st, std::string& err) {
+    const uint32_t N = f.N;
+    // boundaries: a touched node starts an element of its own; behind the subtree of a touched node c_S changes back
+    std::vector<uint8_t> touched(N, 0), cut((size_t)N + 1, 0);
+    touched[0] = 1;                                          // the root is element 0 of every stream
+    for (uint32_t g = 0; g < N; g++) {
+        if (!touched[g])
+            for (uint32_t w = f.node_woff[g]; w < f.node_woff[g + 1]; w++) {
+                const uint32_t p = f.words[w] & W_POS_MASK;
+                if (p >= lo && p < hi) { touched[g] = 1; break; }
+            }
+        if (touched[g]) { cut[g] = 1; cut[g + 1] = 1; cut[f.dfs_end[g] + 1] = 1; }
+    }
+    StreamElems el;
+    el.pos_lo = lo;
+    el.pos_hi = hi;
+    el.weighted = true;
+    el.walk_index = false;
+    std::vector<uint32_t> first_of;            // global index an element starts at (for lend)
+    std::vector<uint32_t> open;                // real elements whose subtree holds the current position (local indices)
+    std::vector<uint32_t> open_end;            // their global subtree ends
+    uint32_t g = 0;
+    while (g < N) {
+        while (!open.empty() && open_end.back() < g) { open.pop_back(); open_end.pop_back(); }
+        const uint32_t local = (uint32_t)el.g.size();
+        const uint32_t par = open.empty() ? 0u : open.back();
+        if (touched[g]) {
+            el.g.push_back(g);
+            el.nkey.push_back(f.nkey[g]);
+            el.nstat.push_back(f.nstat[g]);
+            el.cnt.push_back(1);
+            el.min_all.push_back((int32_t)(f.nkey[g] >> 32));
+            el.lpar.push_back(par);
+            first_of.push_back(g);
+            if (f.dfs_end[g] > g) { open.push_back(local); open_end.push_back(f.dfs_end[g]); }
+            g++;
+            continue;
+        }
+        // a run of untouched nodes up to the next cut
+        uint32_t y = g + 1;
+        while (y < N && !cut[y]) y++;
+        int32_t best = SCORE_INF, mall = SCORE_INF;
+        uint32_t rank = 0xFFFFFFFFu, cnt = 0;
+        for (uint32_t x = g; x < y; x++) {
+            const int32_t bs = (int32_t)(f.nkey[x] >> 32);
+            mall = std::min(mall, bs);
+            if (!(f.nstat[x] & NS_ELIG0)) continue;
+            const uint32_t rk = (uint32_t)(f.nkey[x] & 0xFFFFFFFFll);
+            if (bs < best) { best = bs; rank = rk; cnt = 1; }
+            else if (bs == best) { cnt++; rank = std::min(rank, rk); }
+        }
+        el.g.push_back(IX_NONE);
+        el.nkey.push_back(((int64_t)best << 32) | (int64_t)rank);
+        el.nstat.push_back(cnt ? NS_ELIG0 : 0u);
+        el.cnt.push_back(cnt);
+        el.min_all.push_back(mall);
+        el.lpar.push_back(par);
+        first_of.push_back(g);
+        g = y;
+    }
+    // last element of every real element's subtree: the element before the first one starting behind its end
+    const uint32_t n = (uint32_t)el.g.size();
+    el.lend.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (el.g[i] == IX_NONE || f.dfs_end[el.g[i]] == el.g[i]) { el.lend[i] = i; continue; }
+        const uint32_t endg = f.dfs_end[el.g[i]];
+        el.lend[i] = (uint32_t)(std::upper_bound(first_of.begin() + i, first_of.end(), endg) - first_of.begin()) - 1;
+    }
+    st.tau = 0x7FFFFFFF;
+    return build_stream_core(f, el, st, err);
 }
 
 }  // namespace
@@ -537,6 +637,18 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
         f.streams.emplace_back();
         int rc = build_stream(f, sel, f.streams.back(), err);
         if (rc != WEPP_OK) return rc;
+    }
+
+    // ---- window streams: the whole tree per genome window, for reads with many entries (long reads) -----
+    // windows of WIN_SIZE positions every WIN_STRIDE: a read whose listed positions span less than the stride
+    // lies inside the window that starts at its first position rounded down
+    if (f.max_pos + 1 > WIN_STRIDE) {
+        const uint32_t nw = std::min<uint32_t>(MAX_WINDOWS, (f.max_pos + WIN_STRIDE) / WIN_STRIDE);
+        f.wstreams.resize(nw);
+        for (uint32_t wi = 0; wi < nw; wi++) {
+            int rc = build_window_stream(f, wi * WIN_STRIDE, wi * WIN_STRIDE + WIN_SIZE, f.wstreams[wi], err);
+            if (rc != WEPP_OK) return rc;
+        }
     }
 
     // ---- EPP event stream (see flatmat.hpp) -----------------------------------------

@@ -98,6 +98,7 @@ struct Stream {
     uint64_t E = 0;
     std::vector<int64_t> nkey;         // [n]  (base << 32) | global rank
     std::vector<uint32_t> nstat;       // [n]  (NS_ROOT only on local node 0 = the root)
+    std::vector<uint32_t> ncnt;        // [n] window streams only: nodes an element stands for (1, or the ties of a pseudo-node)
     std::vector<uint32_t> blk_node0;   // [NB+1] blocks of <=64 consecutive nodes with <=128 events
     std::vector<uint32_t> blk_eoff;    // [NB+1] (event counts padded even)
     std::vector<BlkSum> blk_sum;       // [NB]
@@ -164,6 +165,8 @@ struct FlatMAT {
                                        //             bounds the open intervals a walking read keeps on its stack
     // streams[0 .. n-2] = crowns of increasing tau, streams.back() = whole tree
     std::vector<Stream> streams;
+    // wstreams[w] = the whole tree as the reads of genome window [w * WIN_STRIDE, w * WIN_STRIDE + WIN_SIZE) see it
+    std::vector<Stream> wstreams;
     // EPP event stream (epp_kernels.hip): every non-masked mutation twice, in the order a
     // pre-order walk applies and retracts it -- enter words when its node is entered, the same
     // words with W_EXIT once the node's subtree is done.  epp_node[i] = number of nodes
@@ -175,6 +178,9 @@ struct FlatMAT {
     const Stream& full() const { return streams.back(); }
 };
 
+// window streams (flatmat.cpp): a read whose positions span at most WIN_SIZE - WIN_STRIDE = 1536 (a 1.2 kb
+// amplicon) lies inside the window that starts at its first position rounded down to the stride
+constexpr uint32_t WIN_SIZE = 2560, WIN_STRIDE = 1024, MAX_WINDOWS = 32;
 constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of wepp_mat_stats
 
 // Returns WEPP_OK or an error code; `err` receives the message.

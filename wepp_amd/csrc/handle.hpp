@@ -22,6 +22,8 @@ struct wepp_mat {
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
     unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset
     std::vector<uint64_t> stream_bytes;
+    std::vector<DevStream> wstreams;  // window streams (PLAN_WIN)
+    std::vector<uint64_t> wstream_bytes;
     wepp_mat_stats stats{};
     std::vector<uint32_t> bfs2id;
     std::vector<uint32_t> dfs2id;     // caller id of the node with pre-order (arena) index k

@@ -137,6 +137,16 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return min(min(a, b), min(c, d));
 }
 
+// wave-wide sum, returned wave-uniform (the same DPP pattern)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15) + (uint32_t)__builtin_amdgcn_readlane((int)v, 31) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // lower_bound over a position-sorted slice of read words; returns the entry
 // with exactly `pos` or NONE.
 template <typename SPtr>
@@ -244,7 +254,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
             }
         }
-        t |= cls << 4;
+        if (cls == PLAN_SWEEP && use_crowns && k > 0 && t + 1 == m.n_streams && m.n_windows) {
+            // many entries, whole tree: if they all lie inside one genome window, that window's stream will do
+            const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
+            const uint32_t wi = p_lo / WIN_STRIDE;
+            if (wi < m.n_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) { cls = PLAN_WIN; t = wi; }
+        }
+        t |= cls << PLAN_SHIFT;
         tier_of[r] = (uint8_t)t;
         slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the plan (k_scatter)
         atomicMax(&mx[t], k);
@@ -570,7 +586,7 @@ __device__ __forceinline__ void sweep_tile(
     // cnt at every point of the sweep): the evaluation is done once and its outcome taken by all
     // mm = this lane's two node offsets as loaded (byte 0: first event, byte 1: second)
     auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t mm,
-                          int64_t key, uint32_t st, int r, unsigned long long grp) {
+                          int64_t key, uint32_t st, uint32_t wt, int r, unsigned long long grp) {
         const uint32_t n0 = sum.node0;
         const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
         const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
@@ -652,7 +668,8 @@ __device__ __forceinline__ void sweep_tile(
             STAT_ADD(5, 1);
             const int smin = wave_min_i32(elig ? score : 0x7FFFFFFF);
             const bool at_min = elig && score == smin;
-            const uint32_t cntb = (uint32_t)__popcll(__ballot(at_min));
+            // (window streams: an element stands for several nodes)
+            const uint32_t cntb = m.ncnt ? wave_sum_u32(at_min ? wt : 0u) : (uint32_t)__popcll(__ballot(at_min));
             const uint32_t rmin = wave_min_u32(at_min ? rank : 0xFFFFFFFFu);
             if ((grp >> lane) & 1ull) {
                 if (smin < bs) { bs = smin; br = rmin; cnt = cntb; }
@@ -724,14 +741,18 @@ __device__ __forceinline__ void sweep_tile(
                 else { net += d; H += max(-d, 1); }
             }
         };
-        uint32_t mm = 0, st = 0;
+        uint32_t mm = 0, st = 0, wt = 1;
         int64_t key = 0;
         bool fetched = false;
         auto fetch_nodes = [&]() {
             if (e0 + 2 * lane < e1) {
                 mm = *reinterpret_cast<const uint16_t*>(m.ev_meta + e0 + 2 * lane);
             }
-            if (lane < sum.nn) { key = m.nkey[sum.node0 + lane]; st = m.nstat[sum.node0 + lane]; }
+            if (lane < sum.nn) {
+                key = m.nkey[sum.node0 + lane];
+                st = m.nstat[sum.node0 + lane];
+                if (m.ncnt) wt = m.ncnt[sum.node0 + lane];
+            }
             fetched = true;
         };
         {
@@ -867,7 +888,7 @@ __device__ __forceinline__ void sweep_tile(
                 }
                 hv &= ~grp;
                 if (!fetched) fetch_nodes();
-                heavy_eval(sum, e0, e1, w0, w1, mm, key, st, r, grp);
+                heavy_eval(sum, e0, e1, w0, w1, mm, key, st, wt, r, grp);
             }
             STAT_T(4, th_);
             c += net;
