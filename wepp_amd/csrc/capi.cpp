@@ -308,7 +308,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     const uint32_t* info = mat->h_info;
 
     // ---- plan the launches ---------------------------------------------------------
-    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense, window; size_t part_off; const uint32_t* lst; const DevStream* st; uint64_t sbytes; };
+    struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense, window, win_table; size_t part_off; const uint32_t* lst; const DevStream* st; uint64_t sbytes; };
     Plan plans[MAX_PLANS];
     uint32_t np = 0;
     size_t part_total = 0;
@@ -378,7 +378,11 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         while (kcap < need) kcap <<= 1;                        // the bitonic network wants a power of two
         p.ent_cap = p.s_in_lds ? cap : 0;
         p.key_cap = p.dense ? kcap : 0;
-        p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, kcap, p.dense) : bm_bytes;
+        // long reads inside a window: per-position read masks instead of sorted keys (the argument then
+        // carries the window's first position)
+        p.win_table = p.window && p.dense;
+        if (p.win_table) p.key_cap = t * WIN_STRIDE;
+        p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, kcap, p.dense, p.win_table) : bm_bytes;
         // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
         const DevStream& st = *p.st;
         static const uint32_t target_waves = getenv("WEPP_TARGET_WAVES") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES")) : 4096;   // 16 resident single-wave workgroups per CU x 256 CUs; 2048 / 8192 / 16384 measured slower (WEPP_TARGET_WAVES: tuning aid)
@@ -545,7 +549,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         parts(p, ps, pr, pc);
         HIP_TRY(launch_sweep(mat->dev, *p.st, d_read_off, d_read_word, root_score, p.lst, p.count, p.T,
                              p.ntiles,
-                             p.nchunks, p.bpc, p.s_in_lds, p.dense, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
+                             p.nchunks, p.bpc, p.s_in_lds, p.dense, p.win_table, p.ent_cap, p.key_cap, p.lds_bytes, ps, pr, pc, q));
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, p.lst, p.count, p.nchunks, ps, pr, pc,
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
         if (fork && (k + OTHER_SIDE_STREAMS >= n_other)) {

@@ -161,7 +161,7 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
                         const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list,
                         uint32_t n_list, uint32_t T,
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
-                        uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
+                        bool win_table, uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
                         uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream);
 #ifndef WEPP_DENSE_WAVES
 #define WEPP_DENSE_WAVES 8
@@ -175,7 +175,15 @@ constexpr uint32_t SWEEP_WAVES = WEPP_SWEEP_WAVES;            // independent swe
 constexpr uint32_t DENSE_WAVES_PER_WG = WEPP_DENSE_WAVES;     // waves sharing one tile's LDS index in the dense variant
 // LDS bytes of a k_sweep workgroup: bitmap + read words (+ dense: sorted keys + owners + accumulators)
 constexpr uint32_t DENSE_WINDOW = 4096;   // positions behind the tile's smallest one with a direct index into the sorted keys
-inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense) {
+// window plans of long reads (k_sweep<true, true, true>): table entries (window positions + a sentinel, padded so
+// that what follows stays 16-byte aligned) and the per-wave scratch (64 event records of 16 B, net[64], H[64],
+// marker[64])
+constexpr uint32_t WIN_TAB = (WIN_SIZE + 1 + 7) & ~7u;
+constexpr uint32_t WIN_WAVE_BYTES = 64 * 16 + 128 * 4 + 64 * 4;
+inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense, bool win_table = false) {
+    // window plans of long reads: read words (position-major) + per window position the mask of the tile's
+    // reads and the index of their first word + per-wave scratch + scan scratch
+    if (win_table) return ent_cap * 4 + WIN_TAB * 10 + DENSE_WAVES_PER_WG * (WIN_WAVE_BYTES + 4);
     return bm_words * 4 + ent_cap * (dense ? 5 : 4) +
            (dense ? key_cap * 4 + DENSE_WAVES_PER_WG * 3 * 64 * 4 + DENSE_WINDOW * 2 : 0);
 }

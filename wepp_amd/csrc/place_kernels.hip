@@ -147,6 +147,27 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
            (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// wave-wide inclusive scans (sum / max of unsigned values), every lane its own result: four DPP row shifts scan the
+// rows of 16 lanes, two row broadcasts (lane 15 -> next row, lane 31 -> rows 2 and 3) carry across the rows
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+
 // lower_bound over a position-sorted slice of read words; returns the entry
 // with exactly `pos` or NONE.
 template <typename SPtr>
@@ -356,7 +377,15 @@ __global__ void k_first_pos(const uint32_t* __restrict__ list, uint32_t n, const
 // so that an event whose position is in the tile's bitmap costs every read a few compares instead
 // of a binary search through LDS (99.6 % of 150 bp reads list at most four positions; longer
 // ones search the rest of their words in LDS).
-template <bool S_IN_LDS, bool DENSE>
+// WIN (with DENSE; window plans of long reads): the reads of the tile all lie inside one genome window of
+// WIN_SIZE positions from `key_cap` (= the window's first position).  Instead of the bitmap and the sorted keys
+// the workgroup keeps, per window position, the 64-bit mask of the tile's reads that list it and the index of
+// their words in a position-major copy of the tile's read words (the position bits of a copied word hold the
+// lane of its read).  A block's hit events are then resolved with lane = (event, read) pair: the events' match
+// counts are scanned, every pair finds its event through a marker array and adds its contribution to the
+// read's accumulators -- two or three rounds of 64 pairs for a block of a 1.2 kb amplicon tile, where a loop
+// over the events (lane = read) or over each event's reads (lane = event) takes tens of nearly empty rounds.
+template <bool S_IN_LDS, bool DENSE, bool WIN = false>
 __device__ __forceinline__ void sweep_tile(
     const DevStream& ms, uint32_t wg, uint32_t lds_word0, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
     uint32_t key_cap, const uint32_t* __restrict__ read_off,
@@ -365,6 +394,7 @@ __device__ __forceinline__ void sweep_tile(
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
     constexpr bool OWN = S_IN_LDS && !DENSE;
+    static_assert(!WIN || (DENSE && S_IN_LDS), "the window table lives in the dense variant's workgroup");
     STAT_DECL;
     const DevStream& m = ms;
     // Plain variant: one wave = one tile of reads and one chunk of the stream; `wg` is the wave's
@@ -390,6 +420,17 @@ __device__ __forceinline__ void sweep_tile(
     // DENSE_WINDOW positions from the tile's smallest one: reads of one amplicon (batches sorted by
     // position) fall inside, and an event then finds its reads with one LDS read instead of a binary search
     uint16_t* wtab = reinterpret_cast<uint16_t*>(reinterpret_cast<int*>(owner + ent_cap) + NW * 192);
+    // WIN (no bitmap): [ent_cap] read words, position-major | [WIN_TAB] read masks | [WIN_TAB] first word of the
+    // position (16 bit) | per wave: [64] event records (16 B), net[64], H[64], marker[64] | [NW] scan scratch.
+    // Entry WIN_SIZE of the tables is a sentinel (mask 0) for positions outside the window (padding words).
+    uint32_t* sval = lds + lds_word0;
+    unsigned long long* tmask = reinterpret_cast<unsigned long long*>(sval + ent_cap);
+    uint16_t* tstart = reinterpret_cast<uint16_t*>(tmask + WIN_TAB);
+    uint4* wrec = reinterpret_cast<uint4*>(tstart + WIN_TAB) + wv * (WIN_WAVE_BYTES / 16);
+    int* wacc = reinterpret_cast<int*>(wrec + 64);
+    uint32_t* wmark = reinterpret_cast<uint32_t*>(wacc + 128);
+    uint32_t* wscan = reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(tstart + WIN_TAB) + NW * (WIN_WAVE_BYTES / 16));
+    const uint32_t win_lo = key_cap;
 
     const uint32_t tile = wg % ntiles;
     const uint32_t chunk = (wg / ntiles) * NW + wv;
@@ -434,7 +475,8 @@ __device__ __forceinline__ void sweep_tile(
     };
     const uint32_t tid = DENSE ? threadIdx.x : lane;
 
-    for (uint32_t i = tid; i < bm_words; i += 64 * NW) bitmap[i] = 0;
+    if (!WIN)
+        for (uint32_t i = tid; i < bm_words; i += 64 * NW) bitmap[i] = 0;
     // bm_words is a power of two >= (max_pos >> 5) + 1: positions beyond the tree's
     // last mutated site (and the padding word) alias into the map; a false positive
     // only costs a failed lookup in the reads.
@@ -442,16 +484,53 @@ __device__ __forceinline__ void sweep_tile(
     const uint32_t n_ent = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);   // read words of the tile
     uint32_t n2 = 1;                                   // bitonic network size (power of two >= n_ent)
     while (n2 < n_ent) n2 <<= 1;
-    if (DENSE) {
+    if (DENSE && !WIN) {
         for (uint32_t i = threadIdx.x; i < n2; i += 64 * NW) skey[i] = 0xFFFFFFFFu;
         for (uint32_t i = lane; i < 192; i += 64) acc[i] = 0;
+    }
+    if (WIN) {
+        for (uint32_t i = threadIdx.x; i < WIN_TAB; i += 64 * NW) { tmask[i] = 0ull; tstart[i] = 0; }
+        for (uint32_t i = lane; i < 128; i += 64) wacc[i] = 0;
     }
     STAT_T(11, t0_);
     tile_sync();
     STAT_T(5, t0_);
     const unsigned long long ts1_ = STAT_NOW();
     (void)ts1_;
-    if (wv == 0) {
+    if (WIN) {
+        // every wave takes its share of the words of its lane's read
+        uint32_t* tm32 = reinterpret_cast<uint32_t*>(tmask);
+        for (uint32_t j = wv; j < my_k; j += NW) {
+            const uint32_t p = w_pos(read_word[so + j]), rel = p - win_lo;
+            if (rel < WIN_SIZE) atomicOr(&tm32[2 * rel + (lane >> 5)], 1u << (lane & 31));
+        }
+        __syncthreads();
+        // tstart = exclusive prefix sum of the masks' populations (consecutive positions per thread)
+        constexpr uint32_t PER = (WIN_SIZE + 64 * NW - 1) / (64 * NW);
+        const uint32_t i0 = threadIdx.x * PER;
+        uint32_t mine = 0;
+        for (uint32_t i = i0; i < min(i0 + PER, WIN_SIZE); i++) mine += (uint32_t)__popcll(tmask[i]);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        if (lane == 63) wscan[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine;
+        for (uint32_t w2 = 0; w2 < wv; w2++) run += wscan[w2];
+        for (uint32_t i = i0; i < min(i0 + PER, WIN_SIZE); i++) {
+            tstart[i] = (uint16_t)run;
+            run += (uint32_t)__popcll(tmask[i]);
+        }
+        __syncthreads();
+        for (uint32_t j = wv; j < my_k; j += NW) {
+            const uint32_t w = read_word[so + j], rel = w_pos(w) - win_lo;
+            // (the copy keeps the allele fields; its position bits name the read's lane)
+            if (rel < WIN_SIZE) sval[tstart[rel] + (uint32_t)__popcll(tmask[rel] & ((1ull << lane) - 1ull))] = (w & 0xFFF00000u) | lane;
+        }
+    } else if (wv == 0) {
         auto stage = [&](uint32_t j, uint32_t w) {
             const uint32_t p = w_pos(w);
             if (S_IN_LDS) S_lds[lds_off + j] = w;
@@ -468,7 +547,7 @@ __device__ __forceinline__ void sweep_tile(
     }
     tile_sync();
     // tile-wide position index: bitonic sort of the keys (once per tile, by the whole workgroup)
-    if (DENSE) {
+    if (DENSE && !WIN) {
         for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
             for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
                 for (uint32_t i = threadIdx.x; i < n2; i += 64 * NW) {
@@ -483,7 +562,7 @@ __device__ __forceinline__ void sweep_tile(
         }
     }
     uint32_t plo = 0;
-    if (DENSE) {
+    if (DENSE && !WIN) {
         for (uint32_t i = threadIdx.x; i < DENSE_WINDOW; i += 64 * NW) wtab[i] = 0xFFFFu;
         __syncthreads();
         plo = n_ent ? (skey[0] >> 13) : 0u;
@@ -516,6 +595,10 @@ __device__ __forceinline__ void sweep_tile(
         return __builtin_amdgcn_ubfe(word, pos, 1u) != 0;
     };
 
+    // the position of tree word `w` is listed by some read of the tile (WIN: its table entry, else the bitmap)
+    auto win_mask = [&](uint32_t w) -> unsigned long long { return tmask[min(w_pos(w) - win_lo, WIN_SIZE)]; };
+    auto hit = [&](uint32_t w) -> bool { return WIN ? win_mask(w) != 0ull : bit(w_pos(w)); };
+
     // OWN: the first OWN_WORDS words of this lane's read and their positions (an impossible
     // position where the read is shorter); tile_long = some read of the tile lists more
     uint32_t ow[OWN_WORDS], op[OWN_WORDS];
@@ -528,8 +611,17 @@ __device__ __forceinline__ void sweep_tile(
             if (my_k > j) { ow[j] = pre[j]; op[j] = w_pos(ow[j]); }
         tile_long = __ballot(my_k > OWN_WORDS) != 0;
     }
+    // WIN: the word of the read in lane `ln` at position P, or NONE
+    auto win_entry = [&](uint32_t P, uint32_t ln) -> uint32_t {
+        const uint32_t rel = P - win_lo;
+        if (rel >= WIN_SIZE) return NONE;
+        const unsigned long long mk = tmask[rel];
+        if (!((mk >> ln) & 1ull)) return NONE;
+        return sval[tstart[rel] + (uint32_t)__popcll(mk & ((1ull << ln) - 1ull))];
+    };
     // this lane's read word at position P (wave-uniform), or NONE
     auto own_entry = [&](uint32_t P) -> uint32_t {
+        if (WIN) return win_entry(P, lane);
         if (!OWN) return have ? find_entry(S, my_off, my_k, P) : NONE;
         uint32_t s = NONE;
 #pragma unroll
@@ -544,7 +636,7 @@ __device__ __forceinline__ void sweep_tile(
     // compared with its own reference allele (usher_mapper.cpp:302-305,342).
     int c = 0;
     for (uint32_t j = 0; j < my_k; j++) {
-        uint32_t s = S[my_off + j];
+        uint32_t s = WIN ? read_word[so + j] : S[my_off + j];   // (WIN keeps the words position-major)
         if (!rw_missing(s)) c += ((rw_mut(s) & rw_ref(s)) == 0) ? 1 : 0;
     }
 
@@ -557,7 +649,7 @@ __device__ __forceinline__ void sweep_tile(
         for (uint32_t e = e0; e < e1; e += 64) {
             const bool valid = e + lane < e1;
             const uint32_t w = e == e0 ? cp_first : (valid ? m.cp_word[e + lane] : 0);
-            unsigned long long hm = __ballot(valid && bit(w_pos(w)));
+            unsigned long long hm = __ballot(valid && hit(w));
             while (hm) {
                 const int l = __builtin_ctzll(hm);
                 hm &= hm - 1;
@@ -611,6 +703,8 @@ __device__ __forceinline__ void sweep_tile(
                 if (k_r > OWN_WORDS) {
                     if (sw == NONE && bit(p)) sw = find_entry(S, off_r + OWN_WORDS, k_r - OWN_WORDS, p);
                 }
+            } else if (WIN) {
+                sw = win_entry(w_pos(w), (uint32_t)r);
             } else {
                 sw = bit(w_pos(w)) ? find_entry(S, off_r, k_r, w_pos(w)) : NONE;
             }
@@ -684,7 +778,10 @@ __device__ __forceinline__ void sweep_tile(
     auto process_block = [&](uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t lbw, const BlkSum sum) {
         const unsigned long long tb_ = STAT_NOW();
         (void)tb_;
-        const unsigned long long hm0 = __ballot(bit(w0)), hm1 = __ballot(bit(w1));
+        unsigned long long mk0 = 0, mk1 = 0;      // WIN: the tile's reads that list the positions of this lane's events
+        if (WIN) { mk0 = win_mask(w0); mk1 = win_mask(w1); }
+        const unsigned long long hm0 = WIN ? __ballot(mk0 != 0ull) : __ballot(bit(w0));
+        const unsigned long long hm1 = WIN ? __ballot(mk1 != 0ull) : __ballot(bit(w1));
         STAT_ADD(0, 1);
         STAT_ADD(1, (hm0 | hm1) ? 1 : 0);
         STAT_ADD(2, __popcll(hm0) + __popcll(hm1));
@@ -770,7 +867,7 @@ __device__ __forceinline__ void sweep_tile(
             // (the node data is fetched when an evaluation is decided: fetched at the first hit, its loads sat
             // between the prefetched event words of the next blocks and every hit block waited for them)
             unsigned long long hm;
-            if (DENSE && __popcll(hm0) + __popcll(hm1) >= DENSE_MIN_HITS) {
+            if (DENSE && !WIN && __popcll(hm0) + __popcll(hm1) >= DENSE_MIN_HITS) {
                 // many hit events (long reads): lane = event.  Every lane looks its event up in
                 // the tile-sorted key array and adds its contribution to the owning read's
                 // accumulators in LDS; all events of the block are resolved together.
@@ -833,6 +930,62 @@ __device__ __forceinline__ void sweep_tile(
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            } else if (WIN) {
+                // lane = (event, read) pair.  Every lane counts the reads of its two events, the counts are
+                // scanned; pair i belongs to the last event whose first pair is <= i (markers + max scan).
+                const uint32_t n0 = (uint32_t)__popcll(mk0), n1 = (uint32_t)__popcll(mk1), nn = n0 + n1;
+                const uint32_t inc = wave_scan_add_u32(nn), exc = inc - nn;
+                const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                STAT_ADD(3, npairs);
+                wrec[lane] = make_uint4(w0, w1, exc | (n0 << 16),
+                                        (uint32_t)tstart[min(w_pos(w0) - win_lo, WIN_SIZE)] |
+                                            ((uint32_t)tstart[min(w_pos(w1) - win_lo, WIN_SIZE)] << 16));
+                uint32_t carry = 0;
+                for (uint32_t pb = 0; pb < npairs; pb += 64) {
+                    wmark[lane] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (nn && exc - pb < 64u) wmark[exc - pb] = lane + 1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t ev = max(wave_scan_max_u32(wmark[lane]), carry);     // event lane + 1 of this pair
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)ev, 63);
+                    const uint32_t i = pb + lane;
+                    if (i < npairs) {
+                        const uint4 rc = wrec[ev - 1];
+                        uint32_t k = i - (rc.z & 0xFFFFu);
+                        const uint32_t n0e = rc.z >> 16;
+                        const bool second = k >= n0e;
+                        if (second) k -= n0e;
+                        const uint32_t w = second ? rc.y : rc.x;
+                        const uint32_t sl = sval[(second ? rc.w >> 16 : rc.w & 0xFFFFu) + k];
+                        const int d = enter_delta(w, sl);
+                        int dn, dh;
+                        if (w & W_EXIT_DEV) { dn = -d; dh = max(d, 0); }
+                        else if (w & W_LEAF_DEV) {
+                            const uint32_t a = rw_mut(sl), par = tw_par(w);
+                            dn = 0;
+                            dh = (!rw_missing(sl) && (a & tw_mut(w)) != 0 && (a & (par ? par : rw_ref(sl))) == 0) ? 1 : 0;
+                        }
+                        else { dn = d; dh = max(-d, 1); }
+                        const uint32_t o = sl & 63u;
+                        if (dn) atomicAdd(&wacc[o], dn);
+                        atomicAdd(&wacc[64 + o], dh + 0x10000);      // high half: matches of the read (touched marker)
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const int hcnt = wacc[64 + lane];
+                if (hcnt) {
+                    touched = true;
+                    lbmin = (int)lb0;                  // (window streams carry no per-event bounds: lb0 == lb1, uniform)
+                    net = wacc[lane];
+                    H = hcnt & 0xFFFF;
+                    wacc[lane] = 0;
+                    wacc[64 + lane] = 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             } else {
                 hm = hm0;
                 while (hm) {
@@ -849,7 +1002,7 @@ __device__ __forceinline__ void sweep_tile(
             }
             for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
                 const uint32_t w = (e + lane < e1) ? m.ev_word[e + lane] : W_PAD_DEV;
-                hm = __ballot(bit(w_pos(w)));
+                hm = __ballot(hit(w));
                 while (hm) {
                     const int l = __builtin_ctzll(hm);
                     hm &= hm - 1;
@@ -941,15 +1094,15 @@ __device__ __forceinline__ void sweep_tile(
 }
 
 // one stream per launch (dense variant, reads too long for LDS)
-template <bool S_IN_LDS, bool DENSE>
+template <bool S_IN_LDS, bool DENSE, bool WIN = false>
 __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
     DevStream m, uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap, uint32_t key_cap,
     const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
     const int32_t* __restrict__ root_score, const uint32_t* __restrict__ list, uint32_t n_list, uint32_t T,
     uint32_t ntiles, uint32_t blocks_per_chunk, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
     uint32_t* __restrict__ part_cnt) {
-    sweep_tile<S_IN_LDS, DENSE>(m, blockIdx.x, 0u, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, root_score,
-                                list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+    sweep_tile<S_IN_LDS, DENSE, WIN>(m, blockIdx.x, 0u, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, root_score,
+                                     list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
 }
 
 // all the plain (short-read) plans of one placement call in ONE launch: the sweeps of the
@@ -1842,18 +1995,20 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
                         const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list,
                         uint32_t n_list, uint32_t T,
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
-                        uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
+                        bool win_table, uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
                         uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream) {
     // nchunks is a multiple of DENSE_WAVES_PER_WG for the dense variant (capi.cpp)
     const dim3 grid(dense ? ntiles * (nchunks / DENSE_WAVES_PER_WG) : ntiles * nchunks);
     const dim3 block(dense ? 64 * DENSE_WAVES_PER_WG : 64);
-#define WEPP_SWEEP(A, B, CAP, KCAP)                                                                                   \
-    hipLaunchKernelGGL((k_sweep<A, B>), grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, CAP, KCAP,          \
+#define WEPP_SWEEP(A, B, C, CAP, KCAP)                                                                                \
+    hipLaunchKernelGGL((k_sweep<A, B, C>), grid, block, lds_bytes, stream, st, m.bm_words, m.max_pos, CAP, KCAP,       \
                        d_read_off, d_read_word, root_score, list, n_list, T, ntiles, blocks_per_chunk, part_score,    \
                        part_rank, part_cnt)
-    if (s_in_lds && dense) WEPP_SWEEP(true, true, ent_cap, key_cap);
-    else if (s_in_lds) WEPP_SWEEP(true, false, ent_cap, 0u);
-    else WEPP_SWEEP(false, false, 0u, 0u);
+    // (win_table: key_cap carries the window's first position)
+    if (s_in_lds && dense && win_table) WEPP_SWEEP(true, true, true, ent_cap, key_cap);
+    else if (s_in_lds && dense) WEPP_SWEEP(true, true, false, ent_cap, key_cap);
+    else if (s_in_lds) WEPP_SWEEP(true, false, false, ent_cap, 0u);
+    else WEPP_SWEEP(false, false, false, 0u, 0u);
 #undef WEPP_SWEEP
     return hipGetLastError();
 }
@@ -1986,6 +2141,8 @@ extern "C" int wepp_debug_sweep_stats(unsigned long long* out, int reset) {
 
 hipError_t sweep_set_max_lds(uint32_t bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)k_sweep<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_sweep<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_sweep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
