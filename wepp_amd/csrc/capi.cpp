@@ -126,7 +126,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     };
     for (size_t i = 0; i < f.wstreams.size(); i++) {
         DevStream ds;
-        if ((rc = up_stream(f.wstreams[i], (uint32_t)(f.streams.size() - 1), false, ds)) != WEPP_OK) return rc;
+        if ((rc = up_stream(f.wstreams[i], (uint32_t)(f.streams.size() - 1), getenv("WEPP_WIN_EAGER") ? atoi(getenv("WEPP_WIN_EAGER")) != 0 : true, ds)) != WEPP_OK) return rc;
         h->wstreams.push_back(ds);
         h->wstream_bytes.push_back(f.wstreams[i].stream_bytes());
     }

@@ -177,9 +177,9 @@ constexpr uint32_t DENSE_WAVES_PER_WG = WEPP_DENSE_WAVES;     // waves sharing o
 constexpr uint32_t DENSE_WINDOW = 4096;   // positions behind the tile's smallest one with a direct index into the sorted keys
 // window plans of long reads (k_sweep<true, true, true>): table entries (window positions + a sentinel, padded so
 // that what follows stays 16-byte aligned) and the per-wave scratch (64 event records of 16 B, net[64], H[64],
-// marker[64])
+// bound[64], marker[64])
 constexpr uint32_t WIN_TAB = (WIN_SIZE + 1 + 7) & ~7u;
-constexpr uint32_t WIN_WAVE_BYTES = 64 * 16 + 128 * 4 + 64 * 4;
+constexpr uint32_t WIN_WAVE_BYTES = 64 * 16 + 192 * 4 + 64 * 4;
 inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense, bool win_table = false) {
     // window plans of long reads: read words (position-major) + per window position the mask of the tile's
     // reads and the index of their first word + per-wave scratch + scan scratch

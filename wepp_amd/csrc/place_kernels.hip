@@ -421,14 +421,14 @@ __device__ __forceinline__ void sweep_tile(
     // position) fall inside, and an event then finds its reads with one LDS read instead of a binary search
     uint16_t* wtab = reinterpret_cast<uint16_t*>(reinterpret_cast<int*>(owner + ent_cap) + NW * 192);
     // WIN (no bitmap): [ent_cap] read words, position-major | [WIN_TAB] read masks | [WIN_TAB] first word of the
-    // position (16 bit) | per wave: [64] event records (16 B), net[64], H[64], marker[64] | [NW] scan scratch.
+    // position (16 bit) | per wave: [64] event records (16 B), net[64], H[64], bound[64], marker[64] | [NW] scan scratch.
     // Entry WIN_SIZE of the tables is a sentinel (mask 0) for positions outside the window (padding words).
     uint32_t* sval = lds + lds_word0;
     unsigned long long* tmask = reinterpret_cast<unsigned long long*>(sval + ent_cap);
     uint16_t* tstart = reinterpret_cast<uint16_t*>(tmask + WIN_TAB);
     uint4* wrec = reinterpret_cast<uint4*>(tstart + WIN_TAB) + wv * (WIN_WAVE_BYTES / 16);
     int* wacc = reinterpret_cast<int*>(wrec + 64);
-    uint32_t* wmark = reinterpret_cast<uint32_t*>(wacc + 128);
+    uint32_t* wmark = reinterpret_cast<uint32_t*>(wacc + 192);
     uint32_t* wscan = reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(tstart + WIN_TAB) + NW * (WIN_WAVE_BYTES / 16));
     const uint32_t win_lo = key_cap;
 
@@ -490,7 +490,7 @@ __device__ __forceinline__ void sweep_tile(
     }
     if (WIN) {
         for (uint32_t i = threadIdx.x; i < WIN_TAB; i += 64 * NW) { tmask[i] = 0ull; tstart[i] = 0; }
-        for (uint32_t i = lane; i < 128; i += 64) wacc[i] = 0;
+        for (uint32_t i = lane; i < 192; i += 64) wacc[i] = 0;
     }
     STAT_T(11, t0_);
     tile_sync();
@@ -937,7 +937,8 @@ __device__ __forceinline__ void sweep_tile(
                 const uint32_t inc = wave_scan_add_u32(nn), exc = inc - nn;
                 const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 STAT_ADD(3, npairs);
-                wrec[lane] = make_uint4(w0, w1, exc | (n0 << 16),
+                // (an event record keeps the word's allele / flag bits; its position bits carry the event's bound)
+                wrec[lane] = make_uint4((w0 & 0xFFF00000u) | min(lb0, 255u), (w1 & 0xFFF00000u) | min(lb1, 255u), exc | (n0 << 16),
                                         (uint32_t)tstart[min(w_pos(w0) - win_lo, WIN_SIZE)] |
                                             ((uint32_t)tstart[min(w_pos(w1) - win_lo, WIN_SIZE)] << 16));
                 uint32_t carry = 0;
@@ -971,6 +972,7 @@ __device__ __forceinline__ void sweep_tile(
                         const uint32_t o = sl & 63u;
                         if (dn) atomicAdd(&wacc[o], dn);
                         atomicAdd(&wacc[64 + o], dh + 0x10000);      // high half: matches of the read (touched marker)
+                        atomicMax(&wacc[128 + o], 0x40000000 - (int)(w & 0xFFu));   // running min of the events' bounds
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -978,11 +980,12 @@ __device__ __forceinline__ void sweep_tile(
                 const int hcnt = wacc[64 + lane];
                 if (hcnt) {
                     touched = true;
-                    lbmin = (int)lb0;                  // (window streams carry no per-event bounds: lb0 == lb1, uniform)
+                    lbmin = 0x40000000 - wacc[128 + lane];
                     net = wacc[lane];
                     H = hcnt & 0xFFFF;
                     wacc[lane] = 0;
                     wacc[64 + lane] = 0;
+                    wacc[128 + lane] = 0;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
