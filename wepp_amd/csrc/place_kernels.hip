@@ -590,7 +590,11 @@ __device__ __forceinline__ void sweep_tile(
     const uint32_t bm_mask4 = bm_mask << 2;
     const char* bm_bytes = reinterpret_cast<const char*>(bitmap);
     auto bit = [&](uint32_t pos) -> bool {
+#ifdef WEPP_EXP_NO_CONFLICT   // timing experiment only (wrong results): every lane reads its own bank
+        const uint32_t off = (lane << 2) & bm_mask4;
+#else
         const uint32_t off = (pos >> 3) & bm_mask4;
+#endif
         const uint32_t word = BM_AT_ZERO ? *(lds_cu32*)(uintptr_t)off : *reinterpret_cast<const uint32_t*>(bm_bytes + off);
         return __builtin_amdgcn_ubfe(word, pos, 1u) != 0;
     };
