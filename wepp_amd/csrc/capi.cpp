@@ -322,7 +322,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
-        const uint32_t t = id & PLAN_IDX_MASK, cls = id >> PLAN_SHIFT;
+        const uint32_t t = plan_index(id), cls = plan_class(id);
         if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : t >= ns))
             return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
         if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
@@ -334,7 +334,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             d.tier = t;
             d.n_list = info[TI_JOBS + cc * MAX_STREAMS + t];
             d.job0 = (uint32_t)n_jobs[cc];
-            walkc_off[cc] = info[TI_OFF + (cls << PLAN_SHIFT)];
+            walkc_off[cc] = info[TI_OFF + plan_id(cls, 0)];
             d.list = nullptr;
             d.wave_end = (wc.n ? wc.p[wc.n - 1].wave_end : 0u) + (d.n_list + 63) / 64;
             wc.n++;
@@ -928,8 +928,8 @@ extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_r
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tiers, mat->ws, n_reads, hipMemcpyDeviceToHost));
-    for (uint32_t r = 0; r < n_reads; r++)       // the workspace holds plan ids: (class << PLAN_SHIFT) | stream or window
-        tiers[r] = (tiers[r] >> PLAN_SHIFT) == PLAN_WIN ? (uint8_t)(mat->dev.n_streams - 1) : (uint8_t)(tiers[r] & PLAN_IDX_MASK);
+    for (uint32_t r = 0; r < n_reads; r++)       // the workspace holds plan ids (device_mat.hpp: plan_id)
+        tiers[r] = plan_class(tiers[r]) == PLAN_WIN ? (uint8_t)(mat->dev.n_streams - 1) : (uint8_t)plan_index(tiers[r]);
     return WEPP_OK;
 }
 

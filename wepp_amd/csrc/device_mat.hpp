@@ -72,12 +72,19 @@ struct DevMAT {
     const DevWalk* walks;         // [n_streams] device array
 };
 
-// A placement call sorts its reads into PLANS: plan id = (class << PLAN_SHIFT) | stream (or window).  Class = how the read is
+// A placement call sorts its reads into PLANS: plan id = class * MAX_STREAMS + stream, the windows' plans behind
+// them (plan_id / plan_class / plan_index; k_scatter's prefix over the routing blocks costs per plan id, so the
+// ids are dense).  Class = how the read is
 // placed: by the per-read walk of its own events (k_walk) when it lists at most WALK8_K / WALK16_K positions and
 // the intervals it can hold open at once (sum of maxnest over its positions) fit WALK8_STACK / WALK16_STACK, by a
 // sweep of the whole stream otherwise.
-constexpr uint32_t PLAN_SHIFT = 5, PLAN_IDX_MASK = 31, MAX_PLANS = 256;
+constexpr uint32_t MAX_PLANS = 128;
 constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC8 = 3, PLAN_WALKC16 = 4, PLAN_WIN = 5;
+constexpr uint32_t PLAN_WIN_BASE = PLAN_WIN * MAX_STREAMS;
+static_assert(PLAN_WIN_BASE + MAX_WINDOWS <= MAX_PLANS, "plan ids");
+__host__ __device__ inline uint32_t plan_id(uint32_t cls, uint32_t idx) { return cls * MAX_STREAMS + idx; }   // (PLAN_WIN is the last class)
+__host__ __device__ inline uint32_t plan_class(uint32_t id) { return id >= PLAN_WIN_BASE ? PLAN_WIN : id / MAX_STREAMS; }
+__host__ __device__ inline uint32_t plan_index(uint32_t id) { return id >= PLAN_WIN_BASE ? id - PLAN_WIN_BASE : id % MAX_STREAMS; }
 // PLAN_WIN: a read with more entries than a walk takes, all inside one genome window, sweeps that window's
 // stream (the whole tree reduced to the nodes that mutate the window + pseudo-nodes) instead of the whole tree.
 // PLAN_WALKC8 / 16: a read with many events at its positions (a frequently mutated site) walks them as several

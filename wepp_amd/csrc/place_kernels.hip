@@ -281,7 +281,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             const uint32_t wi = p_lo / WIN_STRIDE;
             if (wi < m.n_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) { cls = PLAN_WIN; t = wi; }
         }
-        t |= cls << PLAN_SHIFT;
+        t = plan_id(cls, t);
         tier_of[r] = (uint8_t)t;
         slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the plan (k_scatter)
         atomicMax(&mx[t], k);
