@@ -279,13 +279,15 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
 
     static const uint32_t job_events = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS"))) : WALK_JOB_EVENTS;
     static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
+    static const uint32_t stack8 = getenv("WEPP_WALK_STACK8") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK8")) : WALK8_ROWS;
+    static const uint32_t stack16 = getenv("WEPP_WALK_STACK16") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK16")) : WALK16_ROWS;
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
         tier_info = mat->d_info + mat->info_idx * TI_WORDS;
         uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
-        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, job_n, tier_of, root_score, blk_counts,
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, stack8, stack16, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, stream));
         mat->info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
@@ -484,7 +486,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         hipStream_t q = fork ? mat->side[MAX_STREAMS - 1] : stream;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         for (uint32_t cls = 0; cls < 2; cls++)
-            HIP_TRY(launch_walk(mat->dev, walk[cls], cls, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
+            HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
                                 d_num_best, d_flags, mat->d_work, q));
         if (fork) {
             HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
@@ -531,7 +533,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                 const uint32_t* list3 = walkc[cc].p[0].list;
                 HIP_TRY(launch_gather_jobs(list3, R3, job_n, jcnt, q));
                 HIP_TRY(launch_exclusive_scan_u32(jcnt, joff, R3, jtmp, scan_temp[cc], q));
-                HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, jb, d_read_off, d_read_word, root_score, mat->d_work, q));
+                HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, info[TI_OPEN + 2 + cc], jb, d_read_off, d_read_word, root_score, mat->d_work, q));
                 HIP_TRY(launch_finalize_jobs(mat->dev, list3, R3, jb, d_read_off, d_read_word, d_best_bfs_j, d_score,
                                              d_num_best, d_flags, q));
                 if (fork) {

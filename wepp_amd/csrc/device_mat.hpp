@@ -92,10 +92,18 @@ __host__ __device__ inline uint32_t plan_index(uint32_t id) { return id >= PLAN_
 // a job finds the state of a sequential walk at its first node by binary searches in the read's lists and
 // the chains of enclosing entries (ix_up) -- whose (score, rank, count) partials k_finalize_jobs combines.
 constexpr uint32_t WALK_JOB_EVENTS = 32;
+// most stack rows a walk workgroup gets (<= WALK8_STACK / WALK16_STACK, what the kernels take; WEPP_WALK_STACK8 /
+// WEPP_WALK_STACK16 lower them): a read that could hold more intervals open at once (sum of ix_nest over its
+// positions) is left to the sweeps.  A launch asks LDS for the deepest stack its reads can need (k_route's maximum
+// per class), which on the synthetic SARS-CoV-2-like MAT is 17 (up to 8 entries) / 25 (9-16) of 200 K reads.
+// Measured (16 M nodes, 1 M reads with 5 % N): rows 16/32 -> 12/20 (2 -> 3.5 waves per SIMD for the 16-entry
+// class) 21.5 -> 19.9 ms, nothing on the other legs: the walks are not short of waves.
+constexpr uint32_t WALK_WAVES = 2;         // waves per workgroup of k_walk (their LDS regions are private)
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
 constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
+constexpr uint32_t WALK8_ROWS = WALK8_STACK, WALK16_ROWS = WALK16_STACK;   // (default stack rows: see WALK_WAVES above)
 struct WalkPlanDev {
     uint32_t tier, n_list, wave_end, job0;   // wave_end = first wave (of the launch) after this plan;
     const uint32_t* list;                    // chunked: n_list jobs numbered from job0, list = the class's whole list
@@ -114,12 +122,12 @@ struct WalkPlans {
     WalkPlanDev p[MAX_STREAMS];
 };
 // cls = 0 / 1: the plans of one class in ONE launch, a wave = 64 reads; writes the final per-read results
-hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const uint32_t* d_read_off,
+hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
                        const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
                        uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
-hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const WalkJobs& jb, const uint32_t* d_read_off,
+hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
                             hipStream_t stream);
 hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t n_list, const WalkJobs& jb,
@@ -151,7 +159,8 @@ constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chain
 // route: tier of every read + per-(block, tier) counts and per-tier max entries; also clears tier_info_next,
 // the counters the next call will use (they must be zero before its k_route)
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
+                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
+                        uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
                         uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
@@ -235,6 +244,7 @@ hipError_t sweep_set_max_lds(uint32_t bytes);
 // layout of tier_info (uint32), indexed by plan id: counts, max entries of one read, offsets into the list
 // then, per chunked class and stream, the jobs of its chunked walks
 constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
-                   TI_WORDS = TI_JOBS + 2 * MAX_STREAMS;
+                   TI_OPEN = TI_JOBS + 2 * MAX_STREAMS,      // [4] deepest stack of the walk classes (WALK8, WALK16, WALKC8, WALKC16)
+                   TI_WORDS = TI_OPEN + 4;
 
 }  // namespace wepp

@@ -195,17 +195,19 @@ __device__ __forceinline__ uint32_t find_entry(SPtr S, uint32_t off, uint32_t k,
 __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_t* __restrict__ read_off,
                                                           const uint32_t* __restrict__ read_word, uint32_t n_reads,
                                                           int use_crowns, uint32_t walk_max_events, uint32_t job_events,
+                                                          uint32_t stack8, uint32_t stack16,
                                                           uint32_t* __restrict__ job_n, uint8_t* __restrict__ tier_of,
                                                           int32_t* __restrict__ root_score,
                                                           uint32_t* __restrict__ blk_counts,
                                                           uint32_t* __restrict__ tier_info,
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next) {
-    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS];
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
     if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
+    if (threadIdx.x < 4) open_of[threadIdx.x] = 0;
     if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
@@ -263,16 +265,21 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                     longest = max(longest, len);
                 }
             }
+            // (stack8 <= WALK8_STACK, stack16 <= WALK16_STACK: the stack rows the walks' workgroups get; the few
+            // reads that could hold more intervals open are left to the sweeps)
             if (events <= walk_max_events) {
-                if (k <= WALK8_K && open_max <= WALK8_STACK) cls = PLAN_WALK8;
-                else if (open_max <= WALK16_STACK) cls = PLAN_WALK16;
-            } else if (open_max <= WALK16_STACK) {
+                if (k <= WALK8_K && open_max <= stack8) cls = PLAN_WALK8;
+                else if (open_max <= stack16) cls = PLAN_WALK16;
+                // the deepest stack a walk of the class can need in this call: its kernel's LDS request
+                if (cls != PLAN_SWEEP) atomicMax(&open_of[cls], open_max);
+            } else if (open_max <= stack16) {
                 // many events: jobs of about `job_events`, cut at quantiles of the longest list
-                const uint32_t small = (k <= WALK8_K && open_max <= WALK8_STACK) ? 1u : 0u;
+                const uint32_t small = (k <= WALK8_K && open_max <= stack8) ? 1u : 0u;
                 cls = small ? PLAN_WALKC8 : PLAN_WALKC16;
                 const uint32_t nj = min((events + job_events - 1) / job_events, longest);
                 job_n[r] = nj;
                 atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
+                atomicMax(&open_of[small ? 2 : 3], open_max);
             }
         }
         if (cls == PLAN_SWEEP && use_crowns && k > 0 && t + 1 == m.n_streams && m.n_windows) {
@@ -296,6 +303,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         }
     }
     if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
+    if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
 }
 
 // -----------------------------------------------------------------------------
@@ -1272,19 +1280,25 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
 // whole tree for a read with three entries.  Same results (tests/walk_model.py is the CPU model).
 // -----------------------------------------------------------------------------
 template <int KW, int SD, bool CHUNKED>
-__global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, const uint32_t* __restrict__ read_off,
+__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, uint32_t sd_rows,
+                                              const uint32_t* __restrict__ read_off,
                                               const uint32_t* __restrict__ read_word,
                                               const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
                                               int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best,
                                               uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter) {
-    // wave-private LDS: the read words [KW][64], the list cursors [KW][64], the interval stack [SD][64]
-    __shared__ uint32_t lds_all[4 * (2 * KW + SD) * 64];
+    // wave-private LDS: the allele fields of the read words, 16 bits each [KW / 2][64]; the list cursors [KW][64];
+    // the interval stack [sd_rows][64] -- sd_rows = the deepest stack a read of this launch can need (k_route's
+    // maximum of open_max over the class, <= SD).  The walk waits on memory: what it gains from a wave more
+    // per SIMD is nearly proportional, and its LDS request is what limits them.
+    extern __shared__ uint32_t lds_all[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t* S_l = lds_all + wv * (2 * KW + SD) * 64;
-    uint32_t* cur_l = S_l + KW * 64;
+    uint32_t* S16 = lds_all + wv * (KW / 2 + KW + sd_rows) * 64;
+    uint32_t* cur_l = S16 + (KW / 2) * 64;
     uint32_t* stk = cur_l + KW * 64;
-    const uint32_t unit = blockIdx.x * 4 + wv;
+    // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
+    auto sword = [&](int j) -> uint32_t { return ((S16[(j >> 1) * 64 + lane] >> ((j & 1) * 16)) & 0x1FFu) << 20; };
+    const uint32_t unit = blockIdx.x * WALK_WAVES + wv;
     if (unit >= pl.p[pl.n - 1].wave_end) return;
 #ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
     unsigned long long ts_[6];
@@ -1343,9 +1357,11 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
     uint32_t head[KW];
     int c = 0;
     uint32_t long_off = 0, long_len = 0;     // CHUNKED: the read's longest list (the chunks are its quantiles)
+    uint32_t s_pair = 0;
 #pragma unroll
     for (int j = 0; j < KW; j++) {
         head[j] = NONE;
+        uint32_t s9 = 0;
         if ((uint32_t)j < k) {
             const uint32_t w = read_word[so + j];
             const uint32_t p = w_pos(w);
@@ -1353,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
             IxHead h{ix.last_ent, NONE};
             if (p <= m.max_pos) h = ix.ix_head[p];
             const uint32_t e = h.off;
-            S_l[j * 64 + lane] = w;
+            s9 = (w >> 20) & 0x1FFu;
             cur_l[j * 64 + lane] = e;
             if (CHUNKED) {
                 const uint32_t len = p <= m.max_pos ? ix.ix_head[p + 1].off - e - 1u : 0u;
@@ -1363,6 +1379,8 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
             }
             if (!rw_missing(w)) c += ((rw_mut(w) & rw_ref(w)) == 0) ? 1 : 0;
         }
+        if (j & 1) S16[(j >> 1) * 64 + lane] = s_pair | (s9 << 16);
+        else s_pair = s9;
     }
     WALK_STAMP(2);          // words and list heads staged
     uint32_t n = ix.n;              // one past the last node this lane looks at
@@ -1387,7 +1405,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
             for (uint32_t u = 0; u < 4; u++) {
                 lo[u] = 0; hi[u] = 0;
                 if (j0 + u < k && mid_stream) {
-                    const uint32_t p = w_pos(S_l[(j0 + u) * 64 + lane]);
+                    const uint32_t p = w_pos(read_word[so + j0 + u]);
                     lo[u] = cur_l[(j0 + u) * 64 + lane];
                     hi[u] = p <= m.max_pos ? ix.ix_head[p + 1].off - 1u : lo[u];       // (the sentinel stays out)
                 }
@@ -1415,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
             for (uint32_t u = 0; u < 4; u++) {
                 if (j0 + u < k && mid_stream) {
                     const uint32_t first = u == 0 ? first0 : u == 1 ? first1 : u == 2 ? first2 : first3;
-                    const uint32_t sw = S_l[(j0 + u) * 64 + lane];
+                    const uint32_t sw = sword((int)(j0 + u));
                     cur_l[(j0 + u) * 64 + lane] = lo[u];
                     uint32_t e = lo[u] > first ? lo[u] - 1u : NONE;
                     IxEnt ent{};
@@ -1493,7 +1511,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
         if (at_node) {
 #pragma unroll
             for (int j = KW - 1; j >= 0; j--) js = head[j] == i_next ? j : js;
-            sw = S_l[js * 64 + lane];
+            sw = sword(js);
             ecur = cur_l[js * 64 + lane];
             ent = ix.ix_ent[ecur];             // 32 bytes: the mutation, the list's next node and the node's own record
         }
@@ -1580,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_walk(DevMAT m, WalkPlans pl, WalkJobs j
                     }
                     if (more) {
                         js = jn;
-                        sw = S_l[js * 64 + lane];
+                        sw = sword(js);
                         ecur = cur_l[js * 64 + lane];
                         ent = ix.ix_ent[ecur];
                     }
@@ -1976,11 +1994,13 @@ __global__ void k_excess(DevMAT m, const uint32_t* __restrict__ read_off, const 
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
-                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t* job_n, uint8_t* tier_of,
+                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
+                        uint32_t* job_n, uint8_t* tier_of,
                         int32_t* root_score, uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk,
                         uint32_t* tier_info_next, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
-                       n_reads, use_crowns, walk_max_events, job_events, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
+                       n_reads, use_crowns, walk_max_events, job_events, std::min(stack8, WALK8_STACK), std::min(stack16, WALK16_STACK),
+                       job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
     return hipGetLastError();
 }
 
@@ -2057,19 +2077,29 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
     return hipGetLastError();
 }
 
-hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const uint32_t* d_read_off,
+// LDS of a walk workgroup: WALK_WAVES waves, each KW / 2 rows of read alleles + KW rows of cursors + sd_rows of
+// stack (64 lanes x 4 bytes a row)
+static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVES * (kw / 2 + kw + sd_rows) * 256; }
+// stack rows of a launch: the deepest stack its reads can need (k_route), at least one row for the job decode's
+// scratch, never more than the class admits
+static uint32_t walk_stack_rows(uint32_t open_max, uint32_t sd) { return std::min(sd, std::max(open_max, 2u)); }
+
+hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
                        const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
                        uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
     const uint32_t waves = pl.p[pl.n - 1].wave_end;
-    const dim3 grid((waves + 3) / 4), block(256);
+    const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
     const WalkJobs none{};
-    if (cls == PLAN_WALK8)
-        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, 0, stream, m, pl, none, d_read_off,
-                           d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
-    else
-        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, 0, stream, m, pl, none, d_read_off,
-                           d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+    if (cls == PLAN_WALK8) {
+        const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl,
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+    } else {
+        const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl,
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+    }
     return hipGetLastError();
 }
 
@@ -2079,20 +2109,23 @@ hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint3
     return hipGetLastError();
 }
 
-hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, const WalkJobs& jb, const uint32_t* d_read_off,
-                            const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
-                            hipStream_t stream) {
+hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb,
+                            const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score,
+                            unsigned long long* work_counter, hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
     const uint32_t waves = pl.p[pl.n - 1].wave_end;
-    const dim3 grid((waves + 3) / 4), block(256);
-    if (cls == PLAN_WALKC8)
-        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, 0, stream, m, pl, jb, d_read_off,
-                           d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+    const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
+    if (cls == PLAN_WALKC8) {
+        const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, work_counter);
-    else
-        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, 0, stream, m, pl, jb, d_read_off,
-                           d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+    } else {
+        const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, work_counter);
+    }
     return hipGetLastError();
 }
 
