@@ -327,7 +327,7 @@ def test_device_pointer_entry_point(oracle):
 
 def test_full_size_parity_and_properties(oracle):
     """BASELINE.json configs[2] at full size -- 16 M nodes, the whole 1 M-read batch, work skipping on --
-    and configs[4]'s read shape on the same MAT.
+    configs[4]'s read shape and configs[3]'s per-GPU shard (1.25 M reads) on the same MAT.
       1. the incremental CPU checker (oracle/incremental_oracle.c, proven equal to the faithful
          restatement by tests/test_incremental.py) on >= 10 000 of the 150-bp reads, drawn so that EVERY
          non-empty sweep stream (crown tier) is covered, and on >= 500 1.2-kb reads;
@@ -344,7 +344,7 @@ def test_full_size_parity_and_properties(oracle):
     ot = oracle.OracleTree(g.tree)
     inc = ot.incremental()
 
-    def gather(idx):
+    def gather(idx, reads=reads):
         lists_off = np.zeros(len(idx) + 1, np.uint32)
         words = []
         for i, q in enumerate(idx):
@@ -379,8 +379,21 @@ def test_full_size_parity_and_properties(oracle):
     all_long = np.arange(long_reads.n_reads)
     same(rl, all_long, inc.place_batch(long_reads, nthreads=nthr))
     same(rl, np.arange(4), ot.place_batch(long_reads.slice(0, 4), nthr, node_parallel=True))
-    inc.close()
     ot.close()
+
+    # configs[3] shape: the 1.25 M-read shard one of eight GPUs places (rank 3's reads of a 10 M-read run);
+    # every 2441st read against the incremental checker, and two half batches = the whole
+    shard = g.reads(22 + 3, 1_250_000)
+    rs = mat.place_batch(shard)
+    every = np.arange(0, shard.n_reads, 2441)[:512]
+    got = inc.place_batch(gather(every, shard), nthreads=nthr)
+    assert (rs.score[every] == got["score"]).all() and (rs.best_bfs_j[every] == got["best_j"]).all()
+    assert (rs.num_best[every] == got["num_best"]).all() and (rs.has_unique[every] == got["has_unique"]).all()
+    half = shard.n_reads // 2
+    ra, rb = mat.place_batch(shard.slice(0, half)), mat.place_batch(shard.slice(half, shard.n_reads))
+    for f in ("score", "best_bfs_j", "num_best", "flags"):
+        assert (np.concatenate([getattr(ra, f), getattr(rb, f)]) == getattr(rs, f)).all(), f
+    inc.close()
 
     # 3. properties
     mat.set_tile_reads(16)
