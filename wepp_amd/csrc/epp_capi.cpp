@@ -22,14 +22,40 @@
 
 namespace {
 
-struct DevPool {                       // device allocations of one call
-    std::vector<void*> ptrs;
-    ~DevPool() { for (void* p : ptrs) (void)hipFree(p); }
+struct DevPool {                       // device allocations of one call, taken from / returned to the handle's cache
+    wepp_mat_t* mat;
+    std::vector<std::pair<void*, size_t>> used;
+    explicit DevPool(wepp_mat_t* m) : mat(m) {}
+    ~DevPool() {
+        // (a call that fails half-way may still have kernels in flight on these blocks)
+        (void)hipDeviceSynchronize();
+        for (auto& b : used) mat->epp_cache.blocks.push_back(b);
+    }
     template <typename T>
     hipError_t get(T** out, size_t n) {
+        const size_t bytes = (std::max<size_t>(n * sizeof(T), 64) + 255) & ~(size_t)255;
+        // the smallest cached block that holds the request without wasting more than half of itself
+        size_t best = SIZE_MAX;
+        auto& cache = mat->epp_cache.blocks;
+        for (size_t i = 0; i < cache.size(); i++) {
+            const size_t sz = cache[i].second;
+            if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && (best == SIZE_MAX || sz < cache[best].second)) best = i;
+        }
+        if (best != SIZE_MAX) {
+            used.push_back(cache[best]);
+            cache.erase(cache.begin() + (std::ptrdiff_t)best);
+            *out = (T*)used.back().first;
+            return hipSuccess;
+        }
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n * sizeof(T), 64));
-        if (e == hipSuccess) ptrs.push_back(p);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess && !cache.empty()) {
+            // out of memory with blocks of other sizes parked in the cache: release them and try again
+            for (auto& b : cache) (void)hipFree(b.first);
+            cache.clear();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e == hipSuccess) used.emplace_back(p, bytes);
         *out = (T*)p;
         return e;
     }
@@ -181,7 +207,7 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
                                           " bytes of LDS (window bitmap + allele table): reads too long");
 
     // ---- device copies of the reads ------------------------------------------------------
-    DevPool pool;
+    DevPool pool(mat);
     uint32_t *d_off, *d_word, *d_order, *d_wemax;
     int32_t *d_start, *d_end, *d_degree;
     EppGroup* d_groups;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/wepp_place.h"
@@ -31,8 +32,15 @@ struct wepp_mat {
     const uint32_t* epp_word = nullptr;
     const uint32_t* epp_node = nullptr;
     uint64_t epp_events = 0;
-    void* epp_ws = nullptr;           // grow-only workspace of wepp_epp_map
+    void* epp_ws = nullptr;           // (unused)
     size_t epp_ws_bytes = 0;
+    // device buffers of wepp_epp_map kept between calls (gigabytes at 16 M nodes: a hipMalloc of that size costs
+    // tens of milliseconds); a call takes the blocks that fit and hands everything back when it returns.  Freed
+    // with the handle (release() has selected the device by then).
+    struct DevBlockCache {
+        std::vector<std::pair<void*, size_t>> blocks;
+        ~DevBlockCache() { for (auto& b : blocks) (void)hipFree(b.first); }
+    } epp_cache;
     std::vector<void*> allocs;
     uint32_t tile_reads = 64;
     int use_crowns = 1;
