@@ -277,6 +277,65 @@ def test_mixed_batch_short_long_and_huge_reads(oracle):
     mat.close()
 
 
+def _window_edge_case():
+    """Tree and reads of test_window_plans_at_their_edges (also built by its child process)."""
+    g = w.generate_tree(91, 60000, p_ambiguous=0.002, p_back_mutation=0.05)
+    tree = g.tree
+    L = 29903
+    ref_at = np.full(L + 1, 1, np.uint8)                      # reference allele by position (A where nothing mutates)
+    ref_at[tree.mut_pos] = tree.mut_ref
+    rng = np.random.default_rng(5)
+    lists = []
+    for start, span in [(0, 2560), (0, 2561), (1023, 1537), (1023, 1538), (1024, 2560), (2047, 1536), (2047, 1537),
+                        (5000, 1536), (5000, 1200), (5119, 2561), (29696, 207), (29000, 903), (27136, 2560),
+                        (27136, 2767), (28671, 1232), (12287, 1538)]:
+        for k in (17, 24, 60, 140):
+            inner = rng.choice(np.arange(start + 1, start + span - 1), size=k - 2, replace=False)
+            pos = sorted(set([start, start + span - 1]) | set(int(x) for x in inner))
+            ents = []
+            for q in pos:
+                rf = int(ref_at[q])
+                if rng.random() < 0.3:
+                    ents.append((q, rf, 15, 1))                                   # N
+                else:
+                    ents.append((q, rf, int(1 << rng.integers(0, 4)), 0))         # any allele, the reference's too
+            lists.append(ents)
+    order = rng.permutation(len(lists))
+    return g, Reads.from_lists([lists[i] for i in order])
+
+
+def test_window_plans_at_their_edges(oracle):
+    """Reads with more entries than a walk takes are swept on the stream of the genome window (2560 positions
+    every 1024) their first position falls in -- if their last position fits, on the whole tree otherwise.  Reads
+    built to sit exactly on both sides of that rule, at window starts, at the genome's end and across the
+    tree's last mutated position; long (table variant of the window sweep) and 17..24 entries, with walks on
+    and off (plain sweeps of window streams) and without work skipping (no window plans at all).  A child
+    process with WEPP_DEBUG_PLANS=1 shows that the batch really takes window plans and whole-tree plans."""
+    import subprocess, sys
+    g, reads = _window_edge_case()
+    tree = g.tree
+    want = oracle.OracleTree(tree).place_batch(reads, os.cpu_count())
+    mat = w.Mat(tree)
+    for walk in (True, False):
+        mat.set_use_walk(walk)
+        assert_same(mat.place_batch(reads), want, f"window edges, walk={walk}")
+    mat.set_use_walk(True)
+    mat.set_use_crowns(False)
+    assert_same(mat.place_batch(reads), want, "window edges, no work skipping")
+    mat.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import wepp_amd as w; "
+            "from test_gpu_parity import _window_edge_case; g, r = _window_edge_case(); m = w.Mat(g.tree); m.place_batch(r); m.close()"
+            % (os.path.dirname(here), here))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WEPP_DEBUG_PLANS="1"), capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plans = [l for l in out.stderr.splitlines() if l.startswith("[plan]")]
+    win = [l for l in plans if l.startswith("[plan] window")]
+    assert len(win) >= 6 and any("dense=1" in l for l in win), plans          # several windows, the table variant among them
+    assert any(l.startswith("[plan] sweep") and "dense=1" in l for l in plans), plans   # reads that fit no window
+
+
 def test_rejects_unsorted_or_duplicate_read_positions():
     g = w.generate_tree(47, 1000)
     mat = w.Mat(g.tree)
