@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "handle.hpp"
+#include "host_pool.hpp"
 
 namespace {
 
@@ -40,6 +42,8 @@ void release(wepp_mat* h) {
         if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    for (int i = 0; i < 4; i++)
+        if (h->out_ev[i]) (void)hipEventDestroy(h->out_ev[i]);
     delete h;
 }
 
@@ -645,6 +649,17 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     const uint64_t nw = read_off[n_reads];
     if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
     HIP_TRY(hipSetDevice(mat->device));
+    // WEPP_DEBUG_TIMING=1: wall time of the call's phases to stderr
+    static const bool dbg_time = getenv("WEPP_DEBUG_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
+    double t_phase[5] = {0, 0, 0, 0, 0};
+    auto lap = [&](int i) {
+        if (!dbg_time) return;
+        const auto now = std::chrono::steady_clock::now();
+        t_phase[i] = std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+    };
     uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
     int32_t* d_pns = nullptr;
     int rc = WEPP_OK;
@@ -679,13 +694,14 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         }
     }
     // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.
-    // Checked by a few host threads on large batches, each of which also moves its reads into the pinned
-    // staging buffer (one pass over the input instead of a check and two memcpys); the first offending
-    // read (lowest index) is reported.
+    // Checked by the handle's host workers on large batches, each task moving its reads into the pinned staging
+    // buffer as it goes (one pass over the input instead of a check and two memcpys); the first offending read
+    // (lowest index) is reported.
     {
         uint32_t* pin_off = (uint32_t*)mat->pin;
         uint32_t* pin_word = (uint32_t*)((char*)mat->pin + off_bytes);
-        auto check = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
+        // exact, read by read: only run on a range the fast pass below found something in
+        auto check_exact = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
             for (uint32_t r = lo; r < hi; r++) {
                 if (read_off[r + 1] < read_off[r] || read_off[r + 1] > nw) { bad = r; what = 0; return; }
                 for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
@@ -693,22 +709,46 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
                 for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
                     if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0) { bad = r; what = 2; return; }
             }
-            // this range is well-formed (offsets monotone, within the word array): stage it
-            std::memcpy(pin_off + lo, read_off + lo, (size_t)(hi - lo + (hi == n_reads ? 1 : 0)) * 4);
-            if (read_off[hi] > read_off[lo])
-                std::memcpy(pin_word + read_off[lo], read_word + read_off[lo], (size_t)(read_off[hi] - read_off[lo]) * 4);
         };
-        const uint32_t nt = n_reads >= (1u << 16) ? std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        // fast pass over a range of reads: branch-free loops the compiler vectorises.  Offsets: monotone and inside
+        // the word array.  Words: no zero mask; positions ascend from one word to the next except where a read
+        // starts -- the descents are counted over all words and over the read starts, and must be the same number.
+        auto check = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
+            uint32_t off_bad = (read_off[lo] > nw) ? 1u : 0u;
+            for (uint32_t r = lo; r < hi; r++) {
+                const uint32_t a = read_off[r], b = read_off[r + 1];
+                off_bad |= (uint32_t)(b < a) | (uint32_t)(b > nw);
+                pin_off[r] = a;
+            }
+            if (hi == n_reads) pin_off[hi] = read_off[hi];
+            if (off_bad) { check_exact(lo, hi, bad, what); return; }
+            const uint32_t a0 = read_off[lo], b0 = read_off[hi];
+            uint32_t zero = 0, descents = 0, at_starts = 0;
+            for (uint32_t k = a0; k < b0; k++) {
+                const uint32_t w = read_word[k];
+                zero |= (uint32_t)(((w >> 24) & 15u) == 0) | (uint32_t)(((w >> 20) & 15u) == 0);
+                pin_word[k] = w;
+            }
+            for (uint32_t k = a0 + 1; k < b0; k++) descents += (uint32_t)((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu));
+            for (uint32_t r = lo + 1; r < hi; r++) {
+                const uint32_t s0 = read_off[r];
+                if (read_off[r + 1] > s0 && s0 > a0) at_starts += (uint32_t)((read_word[s0] & 0xFFFFFu) <= (read_word[s0 - 1] & 0xFFFFFu));
+            }
+            if (zero || descents != at_starts) check_exact(lo, hi, bad, what);
+        };
+        const bool big = n_reads >= (1u << 16);
+        if (big && !mat->pool) {
+            const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+            mat->pool.reset(new HostPool(std::min<uint32_t>(15, hw > 1 ? hw - 1 : 1)));
+        }
+        const uint32_t nt = big ? 4 * (mat->pool->workers() + 1) : 1;
         std::vector<uint32_t> bad(nt, 0xFFFFFFFFu);
         std::vector<int> what(nt, 0);
-        if (nt == 1) check(0, n_reads, bad[0], what[0]);
-        else {
-            std::vector<std::thread> th;
-            for (uint32_t i = 0; i < nt; i++)
-                th.emplace_back(check, (uint32_t)((uint64_t)n_reads * i / nt), (uint32_t)((uint64_t)n_reads * (i + 1) / nt),
-                                std::ref(bad[i]), std::ref(what[i]));
-            for (auto& t : th) t.join();
-        }
+        auto task = [&](uint32_t i) {
+            check((uint32_t)((uint64_t)n_reads * i / nt), (uint32_t)((uint64_t)n_reads * (i + 1) / nt), bad[i], what[i]);
+        };
+        if (nt == 1) task(0);
+        else mat->pool->run(nt, task);
         for (uint32_t i = 0; i < nt; i++) {
             if (bad[i] == 0xFFFFFFFFu) continue;
             if (what[i] == 0) return set_error(WEPP_EINVAL, "read_off not monotone");
@@ -717,7 +757,11 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
             return set_error(WEPP_EINVAL, "read " + std::to_string(bad[i]) + ": zero nucleotide mask");
         }
     }
-    e = hipMemcpy(d_off, mat->pin, off_bytes + nw * 4, hipMemcpyHostToDevice);     // offsets and words in one DMA
+    lap(0);
+    // offsets and words in one DMA, stream-ordered before the kernels (the staging buffer is pinned: the call returns at once)
+    e = hipMemcpyAsync(d_off, mat->pin, off_bytes + nw * 4, hipMemcpyHostToDevice, nullptr);
+    if (dbg_time) (void)hipDeviceSynchronize();
+    lap(1);
     if (e != hipSuccess) { rc = hip_fail(e, "H2D copy of the reads"); goto done; }
     rc = wepp_place_batch_device(mat, d_off, d_word, n_reads, nw, d_out, (int32_t*)(d_out + n_reads),
                                  d_out + 2 * (size_t)n_reads, d_out + 3 * (size_t)n_reads, nullptr);
@@ -730,20 +774,44 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         if (e == hipSuccess) e = hipMemcpy(per_node_scores, d_pns, nb, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { rc = hip_fail(e, "per-node score kernel"); goto done; }
     }
-    e = hipMemcpy(mat->pin, d_out, (size_t)n_reads * 16, hipMemcpyDeviceToHost);   // synchronises with the kernels
-    if (e != hipSuccess) { rc = hip_fail(e, "placement kernels / D2H copy of the results"); goto done; }
+    if (dbg_time) { (void)hipDeviceSynchronize(); lap(2); }
     {
-        const uint32_t* po = (const uint32_t*)mat->pin;
+        // the four result arrays come back one after the other; an array is moved out to the caller's buffer (four
+        // tasks, a quarter each) while the next one is still on the bus
+        uint32_t* po = (uint32_t*)mat->pin;
         void* dst[4] = {best_bfs_j, score, num_best, flags};
-        auto move = [&](int i) { if (dst[i]) std::memcpy(dst[i], po + (size_t)i * n_reads, (size_t)n_reads * 4); };
-        if (n_reads >= (1u << 16) && std::thread::hardware_concurrency() >= 4) {   // one host thread per output array
-            std::thread t1(move, 1), t2(move, 2), t3(move, 3);
-            move(0);
-            t1.join(); t2.join(); t3.join();
-        } else {
-            for (int i = 0; i < 4; i++) move(i);
+        const bool pooled = n_reads >= (1u << 16) && mat->pool;
+        for (int i = 0; i < 4 && e == hipSuccess; i++) {
+            if (!dst[i]) continue;
+            if (!mat->out_ev[i]) e = hipEventCreateWithFlags(&mat->out_ev[i], hipEventDisableTiming);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(po + (size_t)i * n_reads, d_out + (size_t)i * n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(mat->out_ev[i], nullptr);
         }
+        if (e != hipSuccess) { (void)hipDeviceSynchronize(); rc = hip_fail(e, "placement kernels / D2H copy of the results"); goto done; }
+        constexpr uint32_t PARTS = 4, NT = 4 * PARTS;       // an array moves out in four parts
+        hipError_t task_err[NT];
+        for (uint32_t t = 0; t < NT; t++) task_err[t] = hipSuccess;
+        auto move = [&](uint32_t t) {
+            const int i = (int)(t / PARTS);
+            if (!dst[i]) return;
+            (void)hipSetDevice(mat->device);                              // (a worker thread starts on device 0)
+            task_err[t] = hipEventSynchronize(mat->out_ev[i]);             // synchronises with the kernels
+            if (task_err[t] != hipSuccess) return;
+            const size_t lo = (size_t)n_reads * (t % PARTS) / PARTS, hi = (size_t)n_reads * (t % PARTS + 1) / PARTS;
+            std::memcpy((uint32_t*)dst[i] + lo, po + (size_t)i * n_reads + lo, (hi - lo) * 4);
+        };
+        if (pooled) mat->pool->run(NT, move);
+        else for (uint32_t t = 0; t < NT; t++) move(t);
+        for (uint32_t t = 0; t < NT; t++)
+            if (task_err[t] != hipSuccess) { rc = hip_fail(task_err[t], "placement kernels / D2H copy of the results"); goto done; }
     }
+    lap(3);
+    lap(4);
+    if (dbg_time)
+        fprintf(stderr, "[place_batch] %u reads: check+stage %.3f  H2D %.3f  kernels %.3f  D2H+copy-out %.3f  total %.3f ms (H2D and kernels synchronised for this print)\n",
+                n_reads, t_phase[0], t_phase[1], t_phase[2], t_phase[3],
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 done:
     if (d_pns) (void)hipFree(d_pns);
     return rc;

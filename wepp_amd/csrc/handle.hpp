@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "device_mat.hpp"
 #include "errors.hpp"
 #include "flatmat.hpp"
+#include "host_pool.hpp"
 
 using namespace wepp;
 
@@ -50,6 +52,8 @@ struct wepp_mat {
     size_t io_in_bytes = 0, io_out_bytes = 0;
     void* pin = nullptr;              // pinned staging of the same (pageable caller buffers go through it)
     size_t pin_bytes = 0;
+    std::unique_ptr<HostPool> pool;   // host workers of wepp_place_batch (started by the first large batch)
+    hipEvent_t out_ev[4] = {};        // one per result array: its D2H copy has landed in the staging buffer
     // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;

@@ -1,0 +1,94 @@
+// host_pool.hpp -- a handle's host worker threads: they check and stage the reads of wepp_place_batch and move its
+// results out.  Starting and joining eight std::threads costs more than the work they share on a 1 M-read batch;
+// these sleep on a condition variable between calls.  run() is called by one thread at a time (a handle is not
+// re-entrant); the caller works along.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace wepp {
+
+class HostPool {
+  public:
+    explicit HostPool(uint32_t n_workers) {
+        for (uint32_t i = 0; i < n_workers; i++) threads_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    HostPool(const HostPool&) = delete;
+    HostPool& operator=(const HostPool&) = delete;
+    uint32_t workers() const { return (uint32_t)threads_.size(); }
+
+    // fn(i) for i in [0, n), shared between the workers and the caller; returns when all are done
+    void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
+        if (n == 0) return;
+        {
+            // (a worker that woke up late for the previous round may still be looking at its counters)
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [this] { return active_ == 0; });
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            done_ = 0;
+            gen_++;
+        }
+        cv_.notify_all();
+        const uint32_t mine = work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_ += mine;
+        cv_done_.wait(lk, [this] { return done_ == n_ && active_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    uint32_t work() {
+        uint32_t mine = 0;
+        for (;;) {
+            const uint32_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_) break;
+            (*fn_)(i);
+            mine++;
+        }
+        return mine;
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                active_++;          // n_, fn_ and next_ stay put while a worker is active
+            }
+            const uint32_t mine = work();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                done_ += mine;
+                active_--;
+                if (active_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(uint32_t)>* fn_ = nullptr;
+    uint32_t n_ = 0, done_ = 0, active_ = 0;
+    std::atomic<uint32_t> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace wepp
