@@ -347,6 +347,55 @@ def test_rejects_unsorted_or_duplicate_read_positions():
     mat.close()
 
 
+def test_large_batches_are_checked_by_the_host_workers():
+    """Batches of 65 536 reads and more are checked and staged by the handle's host workers with a fast pass
+    (descents of the positions counted over all words and over the read starts) that falls back to the exact
+    read-by-read check: a broken read is reported by its index, the lowest one when there are several; a read
+    that starts below its predecessor's last position is fine."""
+    g = w.generate_tree(48, 3000)
+    reads = g.reads(49, 90_000, p_n=0.03)
+    k = np.diff(reads.read_off)
+    multi = np.flatnonzero(k >= 2)
+    assert len(multi) > 200
+    mat = w.Mat(g.tree)
+    good = mat.place_batch(reads)
+    # sorted batches make many reads start below the previous read's last position: must not be flagged
+    starts = reads.read_off[1:-1][(k[1:] > 0) & (k[:-1] > 0)]
+    prev_last = reads.read_word[starts - 1] & 0xFFFFF
+    first = reads.read_word[starts] & 0xFFFFF
+    assert (first <= prev_last).any()
+
+    def broken(fn):
+        rw = reads.read_word.copy()
+        ro = reads.read_off.copy()
+        fn(ro, rw)
+        return Reads(ro, rw)
+
+    r1, r2 = int(multi[len(multi) // 2]), int(multi[-3])
+    def swap(ro, rw, r):
+        a = int(ro[r]); rw[a], rw[a + 1] = rw[a + 1], rw[a]
+    with pytest.raises(w.WeppError, match=f"read {r1}:") as ei:
+        mat.place_batch(broken(lambda ro, rw: (swap(ro, rw, r1), swap(ro, rw, r2))))
+    assert ei.value.code == 1
+    with pytest.raises(w.WeppError, match=f"read {r2}:"):
+        mat.place_batch(broken(lambda ro, rw: swap(ro, rw, r2)))
+    def dup(ro, rw):
+        a = int(ro[r1]); rw[a + 1] = (rw[a + 1] & ~np.uint32(0xFFFFF)) | (rw[a] & np.uint32(0xFFFFF))
+    with pytest.raises(w.WeppError, match=f"read {r1}:"):
+        mat.place_batch(broken(dup))
+    def zero_mask(ro, rw):
+        rw[int(ro[r2])] &= ~np.uint32(0xF << 24)
+    with pytest.raises(w.WeppError, match=f"read {r2}: zero nucleotide mask"):
+        mat.place_batch(broken(zero_mask))
+    def bad_off(ro, rw):
+        ro[r1 + 1] = ro[r1] - 1 if ro[r1] else ro[r1 + 2] + 1
+    with pytest.raises(w.WeppError, match="read_off"):
+        mat.place_batch(broken(bad_off))
+    again = mat.place_batch(reads)                       # the handle is fine after the rejections
+    assert (again.score == good.score).all() and (again.best_bfs_j == good.best_bfs_j).all()
+    mat.close()
+
+
 def test_device_pointer_entry_point(oracle):
     import torch
     g = w.generate_tree(49, 40000)
