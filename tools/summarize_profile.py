@@ -36,7 +36,9 @@ def main(src, name, mode):
             assert b["config"]["kernel_hash"] == summ["kernel_hash"], "profile taken on other kernel sources"
         except Exception as e:  # noqa: BLE001
             summ["bench_under_trace_error"] = repr(e)
-    ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    # (a directory merged back by several gpurun calls holds one file per run: the newest is this run's)
+    newest = lambda fs: sorted(fs, key=os.path.getmtime, reverse=True)
+    ks = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
     if ks:
         rows = list(csv.DictReader(open(ks[0])))
         summ["kernel_stats"] = [{"name": r["Name"].split("(")[0][-48:], "calls": int(r["Calls"]),
@@ -46,7 +48,7 @@ def main(src, name, mode):
         summ["placement_kernels_ms_per_step_sum_of_durations"] = tot / 1e6 / steps
     counters = {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        fs = newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")))
         if not fs:
             continue
         shutil.copy(fs[0], os.path.join(out_dir, os.path.basename(d) + "_counter_collection.csv"))
