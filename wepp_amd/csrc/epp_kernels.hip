@@ -314,42 +314,6 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
         }
     }
 
-    // Pass 2, one read per lane: prefix sums over the lanes of the reads' score deltas and degrees.  The reads
-    // of a tile are consecutive in window order, so the reads whose window holds a position -- what a flip
-    // usually concerns -- are a RANGE of lanes [a, b]; its sums are then incl(b) - excl(a), four readlanes
-    // instead of two 64-bit wave reductions and the bin loop.  bin_end = first lane behind the lane's bin
-    // (buckets ascend with the window start; fast_ok is false for a tile where they do not).
-    long long px_fx = 0, pi_fx = 0;          // exclusive / inclusive prefix of dfx[0]
-    int px_deg = 0, pi_deg = 0;              // of deg[0]
-    uint32_t bin_end = 64;
-    bool fast_ok = false;
-    if (PASS == 2 && RPL == 1) {
-        long long inc = dfx[0];
-        int incd = deg[0];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const long long o = __shfl_up(inc, d, 64);
-            const int od = __shfl_up(incd, d, 64);
-            if (lane >= (uint32_t)d) { inc += o; incd += od; }
-        }
-        pi_fx = inc; px_fx = inc - dfx[0];
-        pi_deg = incd; px_deg = incd - deg[0];
-        const uint32_t prev_b = (uint32_t)__shfl_up((int)bucket[0], 1, 64);
-        const unsigned long long hv = __ballot(have[0]);
-        const bool tail_only = (hv & (hv + 1ull)) == 0ull;                       // the reads fill the low lanes
-        fast_ok = tail_only && __ballot(have[0] && lane > 0 && bucket[0] < prev_b) == 0ull;
-        if (fast_ok) {
-            // lanes of my bin: a contiguous range (buckets ascend); its last lane + 1
-            unsigned long long pending = hv;
-            while (pending) {
-                const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)bucket[0], __builtin_ctzll(pending));
-                const unsigned long long m = __ballot(have[0] && bucket[0] == bb);
-                if (have[0] && bucket[0] == bb) bin_end = 64u - (uint32_t)__builtin_clzll(m);
-                pending &= ~m;
-            }
-        }
-    }
-
     // flips of pass 2: the reads in `tmask` start (those also in `onmask`) or stop matching at node p
     auto flip = [&](const unsigned long long (&tmask)[RPL], const unsigned long long (&onmask)[RPL], uint32_t p) {
         // A mutation's enter and exit events usually flip the same reads in opposite directions
@@ -361,47 +325,7 @@ __global__ __launch_bounds__(64) void k_epp_sweep(EppSweepArgs a) {
             same_dir = same_dir && onmask[q] == c_on[q];
             opp_dir = opp_dir && onmask[q] == (c_t[q] & ~c_on[q]);
         }
-        bool by_range = false;
-        if (RPL == 1 && fast_ok && !(same_t && (same_dir || opp_dir) && c_nb <= 2)) {
-            const unsigned long long t = tmask[0], on = onmask[0];
-            const uint32_t lo = (uint32_t)__builtin_ctzll(t | (1ull << 63)), len = (uint32_t)__popcll(t);
-            const bool contiguous = t != 0ull && (t >> lo) == (len == 64u ? ~0ull : (1ull << len) - 1ull);
-            if (contiguous && (on == t || on == 0ull)) {
-                const int la = (int)lo, lb = (int)(lo + len - 1u);
-                auto rl64 = [&](long long v, int l) -> long long {
-                    return ((long long)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
-                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-                };
-                long long vs = rl64(pi_fx, lb) - rl64(px_fx, la);
-                const int sign = on ? 1 : -1;
-                int nb = 0, cs2[2] = {0, 0};
-                uint32_t b2[2] = {0, 0};
-                bool fits = true;
-                if (a.diff_cnt) {
-                    // the bins of lanes [la, lb]: consecutive sub-ranges (at most two, else the general path)
-                    int at = la;
-                    while (at <= lb) {
-                        if (nb == 2) { fits = false; break; }
-                        const int e = min((int)__builtin_amdgcn_readlane((int)bin_end, at), lb + 1);
-                        b2[nb] = (uint32_t)__builtin_amdgcn_readlane((int)bucket[0], at);
-                        cs2[nb] = __builtin_amdgcn_readlane(pi_deg, e - 1) - __builtin_amdgcn_readlane(px_deg, at);
-                        nb++;
-                        at = e;
-                    }
-                }
-                if (fits) {
-                    c_vs = sign > 0 ? vs : -vs;
-                    c_nb = nb;
-                    c_b[0] = b2[0]; c_b[1] = b2[1];
-                    c_cs[0] = sign * cs2[0]; c_cs[1] = sign * cs2[1];
-                    c_t[0] = t; c_on[0] = on;
-                    by_range = true;
-                }
-            }
-        }
-        if (by_range) {
-            // (sums taken from the prefix registers)
-        } else if (!(same_t && (same_dir || opp_dir)) || c_nb > 2) {
+        if (!(same_t && (same_dir || opp_dir)) || c_nb > 2) {
             long long v = 0;
             bool t_l[RPL], on_l[RPL];
 #pragma unroll
