@@ -61,6 +61,8 @@ struct DevPool {                       // device allocations of one call, taken 
     }
 };
 
+// jobs (tile, stream chunk) a call aims at (WEPP_EPP_TARGET_JOBS): see wepp_epp_map
+constexpr uint32_t EPP_TARGET_JOBS = 262144;   // measured at 16 M nodes, 1 M reads: 8192 (one chunk per tile, 15.6 K jobs) 576 ms, 32 K 440, 64 K 402, 128 K 382, 256 K 370, 1 M 362, 4 M 379 ms on the device
 struct EppTiming { float select_ms = 0, sweep1_ms = 0, sweep2_ms = 0, finish_ms = 0; uint64_t events_swept = 0, stream_events = 0; uint32_t groups = 0, jobs = 0; };
 thread_local EppTiming g_last;
 
@@ -251,7 +253,8 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
         swept += (uint64_t)totals[g] * groups[g].ntiles;
     }
     // enough jobs to fill the machine when there are few tiles
-    const uint32_t want_chunks = std::max<uint32_t>(1, (8192 + ntiles - 1) / ntiles);
+    static const uint32_t target_jobs = getenv("WEPP_EPP_TARGET_JOBS") ? (uint32_t)std::max(1, atoi(getenv("WEPP_EPP_TARGET_JOBS"))) : EPP_TARGET_JOBS;
+    const uint32_t want_chunks = std::max<uint32_t>(1, (target_jobs + ntiles - 1) / ntiles);
     uint32_t chunk_events = std::max<uint32_t>(1024, (n_max + want_chunks - 1) / want_chunks);
     chunk_events = (chunk_events + 63) & ~63u;
     uint64_t n_jobs64 = 0;
