@@ -392,7 +392,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
         const DevStream& st = *p.st;
         static const uint32_t target_waves = getenv("WEPP_TARGET_WAVES") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES")) : 4096;   // 16 resident single-wave workgroups per CU x 256 CUs; 2048 / 8192 / 16384 measured slower (WEPP_TARGET_WAVES: tuning aid)
-        uint32_t nchunks = std::max<uint32_t>(1, (target_waves + p.ntiles - 1) / p.ntiles);
+        // (the 8-wave workgroups of the dense / window variant run for milliseconds: four times as many of them
+        // balance the chip better -- 1.2 kb reads 132 -> 120 ms per 200 K at 16384, the same at 32768)
+        static const uint32_t target_waves_dense = getenv("WEPP_TARGET_WAVES_DENSE") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES_DENSE")) : 16384;
+        uint32_t nchunks = std::max<uint32_t>(1, ((p.dense ? target_waves_dense : target_waves) + p.ntiles - 1) / p.ntiles);
         // ... and chunks no longer than what stays in an XCD's L2 while the tiles sweep it: the waves of
         // a launch are ordered chunk-major (all tiles of chunk 0, then of chunk 1, ...), so the ~4 K
         // resident waves walk the same ~1.5 MB of the stream together instead of drifting apart over
