@@ -18,7 +18,7 @@ def _root_score(fv, S):
 
 def test_walk_model_matches_oracle_fuzz(oracle):
     rng = np.random.default_rng(12)
-    n = exact = segs = 0
+    n = exact = segs = by_entry = 0
     deepest = 0
     for it in range(300):
         if it % 3 == 2:
@@ -41,8 +41,10 @@ def test_walk_model_matches_oracle_fuzz(oracle):
                 deepest = max(deepest, m.max_stack)
                 exact += m.n_exact
                 segs += m.n_segments
+                by_entry += m.n_by_entry
             n += 1
     assert n == 1200 and segs > exact > 0 and deepest >= 2
+    assert by_entry > 0          # ranges decided by the entry's own pre-test byte (tests/conftest.py builds it for every stream)
 
 
 def test_chunked_walk_matches_oracle(oracle):
@@ -110,6 +112,18 @@ def test_index_layout_invariants():
         brk[off[:-1]] = True
         d = np.diff(node.astype(np.int64))
         assert (d[~brk[1:]] > 0).all()
+        # pre-test byte of an entry (top byte of its rank): the minimum static score (sp encoding) of the eligible
+        # nodes between the list's previous entry and the entry's node
+        assert fv.get("ix_pre", s)[0] == 1
+        nk, ns_ = fv.get("nkey", s), fv.get("nstat", s)
+        val = np.where((ns_ & sm.NS_ELIG0) != 0, np.clip(nk >> 32, 0, wm.SP_CLAMP), wm.SP_NONE).astype(np.int64)
+        rng = np.random.default_rng(3)
+        for p in rng.choice(len(off) - 1, size=min(60, len(off) - 1), replace=False):
+            prev = 0
+            for e in range(int(off[p]), int(off[p + 1]) - 1):
+                want = int(val[prev:int(node[e])].min()) if int(node[e]) > prev else wm.SP_NONE
+                assert int(ent[e, 6]) >> 24 == want, (s, p, e)
+                prev = int(node[e]) + 1
         sp, pre, suf, dst = fv.get("sp", s), fv.get("rq_pre", s), fv.get("rq_suf", s), fv.get("rq_dst", s)
         assert len(sp) % n == 0 and len(pre) == len(suf) == n and len(dst) % ((n + 15) // 16) == 0
         elig = (fv.get("nstat", s) & sm.NS_ELIG0) != 0

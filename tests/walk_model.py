@@ -27,7 +27,12 @@ class WalkModel:
         real = ent[:, 0] != IX_NONE
         assert (ent[:-1, 4][real[:-1]] == ent[1:, 0][real[:-1]]).all()  # IxEnt::next_node
         assert (ent[real, 5].astype(np.int32).astype(np.int64) == (self.nkey[ent[real, 0]] >> 32)).all()
-        assert (ent[real, 6].astype(np.int64) == (self.nkey[ent[real, 0]] & 0xFFFFFFFF)).all()
+        pre = flat.get("ix_pre", self.stream)
+        self.has_pre = bool(len(pre) and pre[0])          # top byte of IxEnt::rank = pre-test of the range the entry ends
+        rank_of = ent[:, 6] & (0xFFFFFF if self.has_pre else 0xFFFFFFFF)
+        self.ix_pre_byte = ent[:, 6] >> 24
+        self.n_by_entry = 0
+        assert (rank_of[real].astype(np.int64) == (self.nkey[ent[real, 0]] & 0xFFFFFFFF)).all()
         assert (ent[real, 7] == self.nstat[ent[real, 0]]).all()
         assert (nrec[:, 0].astype(np.int64) == (self.nkey >> 32)).all() and (nrec[:, 2] == self.nstat).all()
         assert (nrec[:, 1].astype(np.int64) == (self.nkey & 0xFFFFFFFF)).all()
@@ -173,8 +178,14 @@ class WalkModel:
                 if rank < br:
                     br, bhu = rank, hu
 
-        def segment(a, b):
+        def segment(a, b, entry=None):
             self.n_segments += 1
+            if self.has_pre and entry is not None:
+                # the range ends at the node of list entry `entry`: its byte stands for a superset of [a, b)
+                pb = int(self.ix_pre_byte[entry])
+                if pb == SP_NONE or (pb < SP_CLAMP and pb + c > bs):
+                    self.n_by_entry += 1
+                    return
             m = self.range_min(a, b)
             if m != SP_NONE and (m >= SP_CLAMP or m + c <= bs):
                 self.n_exact += 1
@@ -187,7 +198,8 @@ class WalkModel:
             e_next = stack[-1][0] if stack else IX_NONE
             stop = min(i_next, e_next, n_end)
             if stop > pos:
-                segment(pos, stop)
+                at_node = i_next < e_next and i_next < n_end
+                segment(pos, stop, cur[head.index(i_next)] if at_node else None)
                 pos = stop
             if pos >= n_end:
                 break

@@ -147,6 +147,7 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
             dw.rq_blocks = st.rq_blocks;
             dw.last_ent = (uint32_t)st.ix_ent.size() - 1;
             dw.whole = st.whole;
+            dw.has_pre = st.ix_pre.empty() ? 0u : st.ix_pre[0];
             UP(dw.ix_head, st.ix_head) UP(dw.ix_ent, st.ix_ent) UP(dw.ix_nest, st.ix_nest) UP(dw.nrec, st.nrec)
             UP(dw.rq_pre, st.rq_pre) UP(dw.rq_suf, st.rq_suf) UP(dw.rq_dst, st.rq_dst) UP(dw.sp, st.sp)
             h->walks.push_back(dw);

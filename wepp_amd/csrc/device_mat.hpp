@@ -41,7 +41,8 @@ struct DevStream {
 
 // the position index and range-query structures of one stream (flatmat.hpp), for k_walk
 struct DevWalk {
-    uint32_t n, rq_blocks, last_ent, pad;   // nodes, blocks of the exact range query, index of the last (sentinel) entry
+    uint32_t n, rq_blocks, last_ent, has_pre;   // nodes, blocks of the exact range query, index of the last (sentinel) entry,
+                                                // 1: the top byte of an entry's rank is the pre-test of the range it ends (flatmat.hpp: ix_pre)
     SegNode whole;                          // aggregate of the whole stream
     const IxHead* ix_head;
     const IxEnt* ix_ent;

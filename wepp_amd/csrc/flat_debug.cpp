@@ -61,7 +61,7 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
     FIELD(st, ncnt)
     FIELD(st, nkey) FIELD(st, nstat) FIELD(st, blk_node0) FIELD(st, blk_eoff) FIELD(st, blk_sum) FIELD(st, ev_word)
     FIELD(st, ev_meta) FIELD(st, ev_lb) FIELD(st, cp_off) FIELD(st, cp_word)
-    FIELD(st, ix_head) FIELD(st, ix_ent) FIELD(st, ix_nest) FIELD(st, nrec) FIELD(st, rq_pre) FIELD(st, rq_suf) FIELD(st, rq_dst) FIELD(st, sp)
+    FIELD(st, ix_head) FIELD(st, ix_ent) FIELD(st, ix_nest) FIELD(st, ix_pre) FIELD(st, nrec) FIELD(st, rq_pre) FIELD(st, rq_suf) FIELD(st, rq_dst) FIELD(st, sp)
 #undef FIELD
     return wepp::set_error(WEPP_EINVAL, std::string("unknown flat field: ") + name);
 }

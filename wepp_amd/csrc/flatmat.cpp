@@ -19,6 +19,7 @@
 #include "flatmat.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace wepp {
@@ -256,6 +257,27 @@ int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::
             const uint8_t* lo = st.sp.data() + (size_t)(l - 1) * n;
             uint8_t* hi = st.sp.data() + (size_t)l * n;
             for (uint32_t i = 0; i < n; i++) hi[i] = i + half < n ? std::min(lo[i], lo[i + half]) : lo[i];
+        }
+        // pre-test byte of the nodes between consecutive entries of a list, in the entry that ends the range
+        st.ix_pre.assign(1, 0);
+        static const uint32_t pre_min_nodes = getenv("WEPP_IX_PRE_MIN_NODES") ? (uint32_t)atoll(getenv("WEPP_IX_PRE_MIN_NODES")) : IX_PRE_MIN_NODES;
+        if (f.N <= (1u << IX_RANK_BITS) && n >= pre_min_nodes) {
+            st.ix_pre[0] = 1;
+            auto range_min = [&](uint32_t a, uint32_t b) -> uint32_t {     // [a, b), a < b: exact minimum (two overlapping spans)
+                uint32_t l = 0;
+                while ((2u << l) <= b - a) l++;
+                const uint8_t* row = st.sp.data() + (size_t)l * n;
+                return std::min<uint32_t>(row[a], row[b - (1u << l)]);
+            };
+            for (uint32_t p = 0; p < np; p++) {
+                uint32_t prev = 0;
+                for (uint32_t e = off[p]; e + 1 < off[p + 1]; e++) {
+                    IxEnt& x = st.ix_ent[e];
+                    const uint32_t v = x.node > prev ? range_min(prev, x.node) : (uint32_t)SP_NONE;
+                    x.rank = (x.rank & IX_RANK_MASK) | (v << IX_RANK_BITS);
+                    prev = x.node + 1;
+                }
+            }
         }
     }
     // checkpoints

@@ -84,7 +84,8 @@ struct NodeRec {           // per stream node: static score, tie-break rank, fla
     int32_t base;
     uint32_t rank, nstat, pad;
 };
-constexpr uint32_t RQ_BLK = 16;              // nodes per block of the exact range query
+constexpr uint32_t RQ_BLK = 16;
+constexpr uint32_t IX_PRE_MIN_NODES = 8192, IX_PRE_MIN_LISTS = 3, IX_RANK_BITS = 24, IX_RANK_MASK = (1u << IX_RANK_BITS) - 1;              // nodes per block of the exact range query
 constexpr uint32_t IX_NONE = 0xFFFFFFFFu;    // sentinel node index closing every position's list
 constexpr uint8_t SP_NONE = 255, SP_CLAMP = 254;   // sparse table: no eligible node in the range / score >= 254
 
@@ -117,6 +118,12 @@ struct Stream {
     std::vector<IxEnt> ix_ent;
     std::vector<uint8_t> ix_nest;      // [max_pos + 1] most entries of a position's list open at once (nested subtrees
                                        // INSIDE this stream), clamped to 255: bounds the stack of a walking read
+    // ix_pre[0] = 1: the top byte of IxEnt::rank holds the pre-test value (sp encoding) of the nodes between the
+    // list's previous entry and this one -- a superset of any range a walk finishes at this entry's node, so the
+    // walk needs no sparse-table byte for it.  Only for trees of at most 2^24 nodes (ranks then fit 24 bits) and
+    // streams of at least IX_PRE_MIN_NODES nodes (WEPP_IX_PRE_MIN_NODES; smaller ones stay in the caches and pass
+    // the pre-test so often that the table byte fetched alongside the entry is the better deal).
+    std::vector<uint32_t> ix_pre;
     std::vector<NodeRec> nrec;         // [n]
     // range queries over the statically eligible nodes.
     // (1) "can anything in [a, b) matter": a sparse table of the minimum score, sp[l * n + i] = min over

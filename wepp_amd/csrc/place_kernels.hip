@@ -1515,17 +1515,37 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             ecur = cur_l[js * 64 + lane];
             ent = ix.ix_ent[ecur];             // 32 bytes: the mutation, the list's next node and the node's own record
         }
+        // the sparse-table byte of [pos, stop): the minimum over [pos, pos + 2^lvl), the first level that reaches
+        // `stop`.  A lane whose range ends at the fetched entry's node asks that entry's byte first (use_pre);
+        // every other lane's table byte is requested here, with the entry, not behind it
+        const bool ranged = live && stop > pos;
+        const bool use_pre = ranged && !eager && ix.has_pre && at_node && k >= IX_PRE_MIN_LISTS;
+        size_t sp_at = 0;
+        uint32_t mn_early = SP_NONE;
+        if (ranged && !eager) {
+            const uint32_t len = stop - pos;
+            const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
+            sp_at = (size_t)lvl * ix.n + pos;
+            if (!use_pre) mn_early = ix.sp[sp_at];
+        }
         // ---- the nodes [pos, stop): none of them carries a listed position, c is constant ----
         if (live && stop > pos) {
             const uint32_t last = stop - 1;
             const uint32_t ba = pos / RQ_BLK, bl = last / RQ_BLK;
             bool pass = true;
             if (!eager) {
-                // one byte: the minimum over [pos, pos + 2^lvl), the first level that reaches `stop`
-                const uint32_t len = stop - pos;
-                const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
-                const uint32_t mn = ix.sp[(size_t)lvl * ix.n + pos];
-                pass = mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
+                // the range ends at the node of the entry fetched above: that entry's byte is the minimum of a
+                // superset (everything since its list's previous entry), no table byte needed unless it passes
+                // (a read with one or two lists gains nothing: its ranges ARE the ranges between its list's entries, and
+                // when such a range cannot be skipped the table byte would be fetched after the entry instead of with it)
+                bool by_entry = false;
+                uint32_t mn = mn_early;
+                if (use_pre) {
+                    const uint32_t pb = ent.rank >> IX_RANK_BITS;
+                    by_entry = pb == SP_NONE || (pb < SP_CLAMP && (int)pb + c > bs);
+                    if (!by_entry) mn = ix.sp[sp_at];          // (rare on the large streams: the byte of the table after all)
+                }
+                pass = !by_entry && mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
             }
             if (__ballot(pass)) {
                 if (pass) {
@@ -1617,7 +1637,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                     elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
                     hu = ncom < (int)nmut ? 1u : 0u;                                // :184,199,262
                 }
-                if (elig && sc <= bs) take(sc, ent.rank, 1u, hu);
+                if (elig && sc <= bs) take(sc, ix.has_pre ? ent.rank & IX_RANK_MASK : ent.rank, 1u, hu);
                 if (dsum != 0 && end > node + 1) {
                     // k_route admits a read only if its open intervals always fit (sum of ix_nest <= SD)
                     stk[sp * 64 + lane] = (end << 7) | (uint32_t)(dsum + 64);
