@@ -126,8 +126,11 @@ int wepp_mat_bfs_order(const wepp_mat_t *mat, uint32_t *bfs_ids);
  *     best_set_difference  -> score[r]
  *     num_best             -> num_best[r]
  *     best_node_has_unique -> flags[r] & WEPP_FLAG_HAS_UNIQUE
- * Host buffers in, host buffers out (H2D / D2H inside).  Any output pointer
- * may be NULL.  per_node_scores, when non-NULL, receives n_reads * n_nodes
+ * Host buffers in, host buffers out (H2D / D2H inside); synchronous: the
+ * results are in the caller's buffers on return.  Batches of 65 536 reads and
+ * more are checked, staged and moved out by host worker threads the handle
+ * starts at the first such call and keeps (wepp_amd/csrc/host_pool.hpp).  Any
+ * output pointer may be NULL.  per_node_scores, when non-NULL, receives n_reads * n_nodes
  * int32 values: the -p mode's node_set_difference[k] in BFS order
  * (src/usher_common.cpp:403-409, +1 for ineligible nodes src/usher_mapper.cpp:500-505). */
 int wepp_place_batch(wepp_mat_t *mat, const uint32_t *read_off, const uint32_t *read_word,
