@@ -205,11 +205,19 @@ Tree create_tree_from_newick_string(std::string const& nw) {
     std::vector<Node*> open;   // internal nodes whose child list is still being read
     size_t i = 0;
     const size_t n = nw.size();
+    // (strchr finds the terminator of its pattern for a NUL byte: a damaged file must not pass for a delimiter)
+    auto one_of = [](const char* set, char c) { return c != '\0' && strchr(set, c) != nullptr; };
     auto read_length = [&](float& len) {   // optional ":<number>"
         if (i < n && nw[i] == ':') {
             size_t j = ++i;
-            while (i < n && (isdigit((unsigned char)nw[i]) || strchr(".eE+-", nw[i]))) i++;
-            if (i > j) len = std::stof(nw.substr(j, i - j));
+            while (i < n && (isdigit((unsigned char)nw[i]) || one_of(".eE+-", nw[i]))) i++;
+            if (i > j) {
+                const std::string num = nw.substr(j, i - j);
+                char* endp = nullptr;
+                const float v = std::strtof(num.c_str(), &endp);
+                if (endp == num.c_str() || *endp != '\0') throw mat_error("ERROR: incorrect Newick format (branch length '" + num + "')!");
+                len = v;
+            }
         }
     };
     bool any = false;
@@ -227,13 +235,14 @@ Tree create_tree_from_newick_string(std::string const& nw) {
             open.pop_back();
             i++;
             // the label of an internal node is discarded (upstream keeps node_<k>)
-            while (i < n && !strchr(",:();", nw[i])) i++;
+            while (i < n && !one_of(",:();", nw[i])) i++;
             read_length(nd->branch_length);
         } else if (ch == ',' || ch == ';' || isspace((unsigned char)ch)) {
             i++;
         } else {
             size_t j = i;
-            while (i < n && !strchr(",:();", nw[i])) i++;
+            while (i < n && !one_of(",:();", nw[i])) i++;
+            if (i == j) throw mat_error("ERROR: incorrect Newick format!");    // (a ':' without a label)
             std::string name = nw.substr(j, i - j);
             Node* leaf = open.empty() ? T.create_node(name) : T.create_node(name, open.back());
             any = true;
