@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -403,6 +404,15 @@ void save_mutation_annotated_tree(const Tree& tree, std::string const& filename)
 void read_vcf(Tree* T, std::string const& vcf_filename, std::vector<Missing_Sample>& missing_samples) {
     fprintf(stderr, "Loading VCF file\n");
     std::string raw = slurp(vcf_filename, "VCF");
+    // a number of a VCF field, or mat_error (std::stoi would throw std::invalid_argument / std::out_of_range)
+    auto field_int = [](const std::string& w, const char* what) -> int {
+        char* endp = nullptr;
+        errno = 0;
+        const long v = std::strtol(w.c_str(), &endp, 10);
+        if (w.empty() || endp == w.c_str() || errno == ERANGE || v < 0 || v > 0x7FFFFFFFL)
+            throw mat_error(std::string("ERROR! Incorrect VCF format: ") + what + " '" + w + "'.");
+        return (int)v;
+    };
     std::istringstream in(raw);
     std::string line;
     bool header_found = false;
@@ -422,6 +432,8 @@ void read_vcf(Tree* T, std::string const& vcf_filename, std::vector<Missing_Samp
                         fprintf(stderr, "WARNING: Ignoring sample %s as it is already in the tree.\n", words[j].c_str());
                     }
                 }
+                if (words.size() < 9)
+                    throw mat_error("ERROR! Incorrect VCF format. The header names " + std::to_string(words.size()) + " columns, at least 9 expected.");
                 n_columns = words.size();
                 header_found = true;
             }
@@ -436,12 +448,15 @@ void read_vcf(Tree* T, std::string const& vcf_filename, std::vector<Missing_Samp
             const std::string& gt = words[sample_column[k]];
             Mutation m;
             m.chrom = words[0];
-            m.position = std::stoi(words[1]);
+            m.position = field_int(words[1], "position");
             m.ref_nuc = get_nuc_id(words[3][0]);
             m.par_nuc = m.ref_nuc;
             bool emit = true;
             if (!gt.empty() && isdigit((unsigned char)gt[0])) {
-                int allele_id = std::stoi(gt);
+                // (the leading run of digits: "1", "1/1", "1|0" all name allele 1, as std::stoi read them)
+                size_t nd = 0;
+                while (nd < gt.size() && isdigit((unsigned char)gt[nd])) nd++;
+                int allele_id = field_int(gt.substr(0, nd), "genotype");
                 if (allele_id > 0) {
                     if ((size_t)allele_id > alleles.size()) throw mat_error("ERROR! VCF genotype refers to a missing ALT allele.");
                     m.mut_nuc = get_nuc_id(alleles[(size_t)allele_id - 1][0]);
