@@ -91,3 +91,14 @@ def test_vcf_and_reads_loaders_survive_damaged_files(tmp_path, mode):
     assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout[-300:], run.stderr[-3000:])
     loaded, rejected = int(run.stdout.split()[1]), int(run.stdout.split()[3])
     assert loaded + rejected == 2000
+
+
+def test_tree_description_check_survives_damage(tmp_path):
+    """wepp_tree_desc through the flattener's validation (the same code wepp_mat_create runs), ASan + UBSan."""
+    cs = os.path.join(ROOT, "wepp_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "cxx", "tree_desc_fuzz.cpp")] + [os.path.join(cs, f) for f in ("flatmat.cpp", "gen.cpp", "flat_debug.cpp", "errors.cpp")]
+    exe = _build(tmp_path, "tree_desc_fuzz", srcs)
+    run = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=4096"))
+    assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout[-300:], run.stderr[-3000:])
+    assert int(run.stdout.split()[3]) > 50          # most damage is caught
