@@ -68,6 +68,8 @@ def parse():
                          "results inside); 0 disables it")
     ap.add_argument("--no-sensitivity", action="store_true",
                     help="skip the sensitivity ladder (reads/s against the N rate and the entries per read)")
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct read batches (all resident in HBM) the timed loop rotates over")
     ap.add_argument("--p-n", type=float, default=None, help="per-base N rate of the synthetic reads (default 0.005 "
                     "for 150 bp reads, SURVEY 8(d) config 2/3; 0.02 for long reads, config 5)")
     return ap.parse_args()
@@ -118,22 +120,23 @@ def cpu_baseline(tree, reads, gpu_res, target_s):
         "unit": "reads/s",
         "cores": cores,
         "kind": "port",
+        "kind_note": "the oracle's C restatement of mapper2_body / the usher_common loop (oracle/mapper2_oracle.c), NOT the "
+                     "reference's TBB build: the reference needs TBB / Boost / protobuf headers this image lacks (DESIGN.md 6)",
         "sample": f"first {n} reads of the step batch on the same MAT, node range split over {cores} threads "
                   f"(like tbb::parallel_for over nodes), {dt:.1f} s; probe read {t1:.2f} s",
         "sample_matches_gpu": ok,
     }
 
 
-def pmc_profile(mode):
-    """Counters per step of k_sweep from the committed rocprofv3 --pmc profile of THIS workload
-    (`mode`: short_reads / whole_tree / long_reads) and THIS build of the kernels
-    (profiles/pmc_counters.json, written by tools/summarize_profile.py from tools/profile.sh runs):
-    HBM-side bytes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE,
-    x 1024) and vector / scalar instruction counts.  None unless the profile's kernel hash is the hash
-    of the sources this process was built from."""
+def pmc_profile(mode, reads_per_step):
+    """Counters per step of the placement kernels from the committed rocprofv3 --pmc profile of THIS workload
+    (`mode`: short_reads / whole_tree / long_reads), THIS number of reads per step and THIS build of the kernels
+    (profiles/pmc_counters.json, written by tools/summarize_profile.py from tools/profile.sh runs; key
+    "<mode>:<reads per step>", kernel hash inside).  None when no such profile is committed: bench.py never prices
+    one workload with another's counters."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as fh:
-            t = json.load(fh)[mode]
+            t = json.load(fh)[f"{mode}:{reads_per_step}"]
     except (OSError, KeyError, ValueError):
         return None
     if t.get("kernel_hash") != kernel_hash():
@@ -141,60 +144,60 @@ def pmc_profile(mode):
     return t
 
 
-def sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch):
-    """The roofline objects of one measurement.  `hbm`: algorithmic and counter traffic against the 8 TB/s
-    peak.  The other candidates come from the committed rocprofv3 --pmc profile of this workload and this
-    build: vector instruction issue (256 CUs x one wave-instruction per cycle) and the vector memory address
-    units (TA busy cycles: a gather whose 64 lanes touch 64 cache lines keeps its CU's unit busy for 64+
-    cycles -- what bounds the per-read walks).  `binding` = the candidate with the largest utilisation."""
-    prof = pmc_profile(mode)
+def sweep_roofline(mode, reads_per_step, sweep_ms, alg_bytes, passes, n_launch):
+    """The roofline object of one measurement (contract shape: bound / achieved / peak / unit / frac / traffic) and the
+    other utilisation views.
+    achieved = ALGORITHMIC bytes per step -- what the kernels ask memory for, counted by the library: a sweep reads
+    its stream once per 64-read tile (SURVEY 8(d) B_pass), a walk's lanes count their own requests (a 32-byte index
+    entry per node event, sparse-table bytes, range-query aggregates, list heads, read words, results: DESIGN.md 4.2)
+    -- over the kernel time of a step measured live with HIP events on the launch stream.
+    traffic = HBM-side bytes per step from the committed rocprofv3 --pmc profile of the same workload and build:
+    (FETCH_SIZE + WRITE_SIZE) x 1024 for the walks, whose 32-byte gathers the counter tallies as they are (cross-check:
+    TCC_MISS x 64 B agrees); MI355X_MICROARCH.md's doubling of FETCH_SIZE applies to wide coalesced streams (the
+    whole-tree sweep) and is reported beside it as traffic_x2.  Infinity-Cache hits are counted by both."""
+    prof = pmc_profile(mode, reads_per_step)
     secs = sweep_ms * 1e-3
     alg = alg_bytes / secs / 1e9
-    hbm = {"bound": "hbm", "kernel": "placement kernels (k_walk / k_sweep / k_finalize)", "achieved": alg, "peak": HBM_PEAK_GBS,
-           "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
-           "achieved_note": "ALGORITHMIC bytes over the live kernel time: a sweep reads its stream once per 64-read tile, "
-                            "a walk 26 bytes per loop iteration (DESIGN.md 4.1, 4.2).  Streams and index are shared between "
-                            "reads and largely served by the L2s / Infinity Cache: see traffic / traffic_gbs for what left the L2s",
-           "algorithmic_bytes_per_step": alg_bytes, "passes_per_step": passes, "kernel_ms_per_step": sweep_ms,
-           "steps_timed": n_launch, "traffic": None, "traffic_gbs": None, "traffic_frac": None}
+    roof = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "placement kernels of one step (k_walk plain + chunked, k_sweep, k_finalize*), concurrent on side streams",
+            "algorithmic_bytes_per_step": alg_bytes, "passes_per_step": passes, "kernel_ms_per_step": sweep_ms,
+            "steps_timed": n_launch,
+            "achieved_note": "algorithmic bytes counted by the kernels' own lanes / tiles over the live kernel time; the index "
+                             "and the streams are shared between reads, so part of it is served by L2 / Infinity Cache"}
     cands = []
     if prof is None:
-        binding = {"bound": "unknown", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                   "kernel_ms_per_step": sweep_ms, "steps_timed": n_launch,
-                   "provenance": "no rocprofv3 --pmc profile of this workload for this build of the kernels is committed "
-                                 "(profiles/pmc_counters.json, tools/profile.sh + tools/summarize_profile.py)"}
-        return binding, hbm, cands
-    prov = (f"counters per step from {prof['profile']} (rocprofv3 --pmc runs of this workload, kernel hash "
-            f"{prof['kernel_hash']}); duration measured live with HIP events; the profiled run's kernel time was "
-            f"{prof.get('kernel_ms_per_step_trace')} ms per step")
-    if prof.get("traffic_bytes_per_step") is not None:
-        hbm.update({"traffic": prof["traffic_bytes_per_step"], "traffic_gbs": prof["traffic_bytes_per_step"] / secs / 1e9,
-                    "traffic_frac": prof["traffic_bytes_per_step"] / secs / 1e9 / HBM_PEAK_GBS,
-                    "l2_hit_rate": prof.get("l2_hit_rate"),
-                    "traffic_note": "bytes per step leaving the L2s, (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes; "
-                                    "Infinity-Cache hits are counted, so true HBM traffic is lower still"})
-        cands.append({"bound": "hbm", "achieved": hbm["traffic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s (counter traffic)",
-                      "frac": hbm["traffic_frac"]})
+        roof["provenance"] = (f"no rocprofv3 --pmc profile of {mode}:{reads_per_step} for kernel hash {kernel_hash()} is committed "
+                              "(profiles/pmc_counters.json, tools/profile.sh + tools/summarize_profile.py): traffic null")
+        return roof, cands
+    roof["provenance"] = (f"traffic and the other counters per step from {prof['profile']} (rocprofv3 --pmc passes of this "
+                          f"workload, {reads_per_step} reads per step, kernel hash {prof['kernel_hash']}; its kernel time was "
+                          f"{prof.get('kernel_ms_per_step_trace')} ms per step); achieved and kernel_ms measured live")
+    raw, x2 = prof.get("raw_bytes_per_step"), prof.get("traffic_bytes_per_step")
+    streaming = mode == "whole_tree"
+    if raw is not None:
+        t = x2 if streaming else raw
+        roof.update({"traffic": t, "traffic_gbs": t / secs / 1e9, "traffic_frac": t / secs / 1e9 / HBM_PEAK_GBS,
+                     "traffic_raw": raw, "traffic_x2": x2, "tcc_miss_bytes": prof.get("tcc_miss_bytes_per_step"),
+                     "l2_hit_rate": prof.get("l2_hit_rate"),
+                     "traffic_note": ("(2*FETCH_SIZE + WRITE_SIZE)*1024: wide coalesced stream" if streaming else
+                                      "(FETCH_SIZE + WRITE_SIZE)*1024: 32-byte gathers are tallied as they are (TCC_MISS x 64 B "
+                                      "agrees); traffic_x2 is the figure with MI355X_MICROARCH.md's doubling") +
+                                     "; Infinity-Cache hits are counted, true HBM traffic is lower"})
+        cands.append({"bound": "hbm_traffic", "achieved": roof["traffic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["traffic_frac"]})
     if prof.get("valu_insts_per_step") is not None:
         a = prof["valu_insts_per_step"] / secs / 1e9
         cands.append({"bound": "valu_issue", "achieved": a, "peak": VALU_ISSUE_PEAK, "unit": "G wave-instructions/s",
                       "frac": a / VALU_ISSUE_PEAK, "valu_insts_per_step": prof["valu_insts_per_step"],
-                      "salu_insts_per_step": prof.get("salu_insts_per_step"),
-                      "peak_note": "256 CUs x one vector instruction per cycle x 2.4 GHz max clock (the clock held under load is "
-                                   "lower: frac is a lower bound)"})
+                      "salu_insts_per_step": prof.get("salu_insts_per_step")})
     if prof.get("ta_busy_cycles_per_step") is not None:
         a = prof["ta_busy_cycles_per_step"] / secs / 1e9
         cands.append({"bound": "vmem_address", "achieved": a, "peak": VALU_ISSUE_PEAK, "unit": "G busy cycles/s over the 256 address units",
-                      "frac": a / VALU_ISSUE_PEAK, "ta_busy_cycles_per_step": prof["ta_busy_cycles_per_step"],
-                      "vmem_read_insts_per_step": prof.get("vmem_rd_insts_per_step"),
-                      "tcp_cache_accesses_per_step": prof.get("tcp_cache_accesses_per_step"),
-                      "peak_note": "TA_TA_BUSY summed over the 256 vector-memory address units / (256 x 2.4 GHz x kernel time): the "
-                                   "share of the time the units were busy splitting gathers into cache-line requests"})
-    best = max(cands, key=lambda c: c["frac"]) if cands else None
-    binding = dict(best) if best else {"bound": "unknown", "achieved": None, "peak": None, "unit": None, "frac": None}
-    binding.update({"kernel": "placement kernels (k_walk / k_sweep / k_finalize)", "traffic": prof.get("traffic_bytes_per_step"),
-                    "kernel_ms_per_step": sweep_ms, "steps_timed": n_launch, "provenance": prov})
-    return binding, hbm, cands
+                      "frac": a / VALU_ISSUE_PEAK, "vmem_read_insts_per_step": prof.get("vmem_rd_insts_per_step"),
+                      "tcp_cache_accesses_per_step": prof.get("tcp_cache_accesses_per_step")})
+    if prof.get("sq_wait_any_frac") is not None:
+        roof["sq_wait_any_over_wave_cycles"] = prof["sq_wait_any_frac"]
+    return roof, cands
 
 
 class DeviceBatch:
@@ -256,7 +259,11 @@ def main():
         return g.reads(seed, n, read_len=args.read_len, amplicon_len=amp_len, amplicon_step=amp_step,
                        p_substitution=p_sub, p_n=pn)
 
-    reads = gen_reads((24 if long_reads else 22) + rank, args.reads)
+    # the timed loop rotates over N_BATCHES distinct batches, all resident in HBM (seeds 22 + 8 * rank + i: rank 0 places
+    # seeds 22 .. 29): no step finds the index lines and the routing of the step before it in the caches
+    seed0 = (24 if long_reads else 22) + args.batches * rank
+    batches_host = [gen_reads(seed0 + i, args.reads) for i in range(args.batches)]
+    reads = batches_host[0]
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     mat = w.Mat(g.tree, device=local_rank)
@@ -265,7 +272,8 @@ def main():
     mat.set_use_walk(not args.no_walk)
     t_flat = time.perf_counter() - t0
     st = mat.stats
-    batch = DeviceBatch(torch, reads, dev)
+    batches = [DeviceBatch(torch, rd, dev) for rd in batches_host]
+    batch = batches[0]
     R, nw = batch.R, batch.nw
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -283,18 +291,22 @@ def main():
         return float(tt.item())
 
     # ---- the timed region: K steps, inputs resident in HBM ----------------------------------
-    for _ in range(args.warmup):
-        batch.place(mat, stream)
+    for i in range(args.warmup):
+        batches[i % len(batches)].place(mat, stream)
     fence()
     mat.timing_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.place(mat, stream)
+    for i in range(args.steps):
+        batches[i % len(batches)].place(mat, stream)
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     sweep_ms, n_launch, passes, alg_bytes = mat.last_timing()
     walk_reads, walk_iters = mat.last_walk()
+    reads_timed = sum(batches[i % len(batches)].R for i in range(args.steps))
+    batch.place(mat, stream)                  # (batch 0 once more: its routing is what `streams` reports)
+    fence()
     tiers = mat.last_tiers(R)
+    pcls, _ = mat.last_plans(R)
     ref_out = [t.clone() for t in batch.out]
 
     # ---- SURVEY 8(d)'s metric as defined: wall clock of wepp_place_batch with HOST buffers (validation of the
@@ -302,18 +314,22 @@ def main():
     pcie = None
     if args.pcie_steps > 0:
         hres = mat.place_batch(reads)                 # grows the handle's staging buffers once
+        same = bool((hres.score == ref_out[1].cpu().numpy()).all() and
+                    (hres.best_bfs_j == ref_out[0].cpu().numpy().view(np.uint32)).all() and
+                    (hres.num_best == ref_out[2].cpu().numpy().view(np.uint32)).all())
         fence()
         t0 = time.perf_counter()
         per_call = []
-        for _ in range(args.pcie_steps):
+        n_placed = 0
+        for i in range(args.pcie_steps):
+            rd = batches_host[(i + 1) % len(batches_host)]     # distinct host batches in rotation, like the timed loop
             t1 = time.perf_counter()
-            hres = mat.place_batch(reads, out=hres)           # synchronous: the results are in host memory on return
+            hres = mat.place_batch(rd, out=hres)               # synchronous: the results are in host memory on return
             per_call.append(time.perf_counter() - t1)
+            n_placed += rd.n_reads
         fence()
         el = max_over_ranks(time.perf_counter() - t0)
-        same = bool((hres.score == ref_out[1].cpu().numpy()).all() and
-                    (hres.best_bfs_j == ref_out[0].cpu().numpy().view(np.uint32)).all())
-        pcie = {"value": R * world * args.pcie_steps / el, "ms_per_step": el / args.pcie_steps * 1e3,
+        pcie = {"value": n_placed * world / el, "ms_per_step": el / args.pcie_steps * 1e3,
                 "ms_per_step_median": float(np.median(per_call)) * 1e3, "ms_per_step_min": float(np.min(per_call)) * 1e3,
                 "steps": args.pcie_steps, "bytes_in_per_step": 4 * (R + 1) + 4 * nw, "bytes_out_per_step": 16 * R,
                 "results_identical_to_timed_run": same}
@@ -370,14 +386,14 @@ def main():
     if rank == 0:
         gpu_res = {"score": ref_out[1].cpu().numpy(), "best": ref_out[0].cpu().numpy().view(np.uint32),
                    "num_best": ref_out[2].cpu().numpy().view(np.uint32), "flags": ref_out[3].cpu().numpy().view(np.uint32)}
-        total_reads = R * world * args.steps
+        total_reads = reads_timed * world          # (every rank places batches of the same sizes)
         value = total_reads / elapsed
         mode = "long_reads" if long_reads else ("whole_tree" if (args.no_crowns and args.no_walk) else "short_reads")
-        issue, hbm, cands = sweep_roofline(mode, sweep_ms, alg_bytes, passes, n_launch)
+        roof, cands = sweep_roofline(mode, R, sweep_ms, alg_bytes, passes, n_launch)
         shape = (f"{R} synthetic midnight-amplicon-like {args.read_len} bp reads per GPU per step (3 % substitutions, "
-                 f"N rate {p_n}; seed 24+rank); BASELINE.json configs[4] shape on one GPU" if long_reads else
+                 f"N rate {p_n}; {args.batches} batches in rotation from seed {seed0}); BASELINE.json configs[4] shape on one GPU" if long_reads else
                  f"{R} synthetic ARTIC-like {args.read_len} bp reads per GPU per step (0.1 % substitutions, N rate {p_n}; "
-                 f"seed 22+rank); BASELINE.json configs[2]")
+                 f"{args.batches} distinct batches in rotation, seeds {seed0}..{seed0 + args.batches - 1}); BASELINE.json configs[2]")
         counts = np.bincount(tiers, minlength=st.n_streams)
         out = {
             "metric": "reads placed/sec on SARS-CoV-2 MAT (~16M nodes)",
@@ -392,12 +408,16 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "value_note": "inputs and outputs resident in HBM (wepp_place_batch_device); value_pcie_inclusive is SURVEY 8(d)'s "
-                          "wall clock of wepp_place_batch with host buffers.  Both are a best case of the synthetic "
-                          "generator (reads of reference-like genotypes with ~1 entry): see `sensitivity`",
             "value_pcie_inclusive": pcie["value"] if pcie else None,
+            "value_note": "inputs and outputs resident in HBM (wepp_place_batch_device); value_pcie_inclusive (also under "
+                          "config.pcie_inclusive_reads_per_s) is SURVEY 8(d)'s wall clock of wepp_place_batch with host buffers.  "
+                          "Both are a best case of the synthetic generator (reads of reference-like genotypes with ~1 entry): "
+                          "see `sensitivity`",
             "pcie_inclusive": pcie,
             "config": {
+                "pcie_inclusive_reads_per_s": pcie["value"] if pcie else None,
+                "pcie_inclusive_ms_per_step": pcie["ms_per_step"] if pcie else None,
+                "distinct_batches_in_rotation": args.batches,
                 "workload": f"synthetic SARS-CoV-2-like MAT N={st.n_nodes} nodes M={st.n_mutations} mutations "
                             f"(seed 21, L=29903), {shape}",
                 "reads_per_gpu": R,
@@ -408,28 +428,33 @@ def main():
                 "mat": {"nodes": int(st.n_nodes), "mutations": int(st.n_mutations), "events": int(st.n_events),
                         "blocks": int(st.n_blocks), "leaves": int(st.n_leaves), "max_depth": int(st.max_depth),
                         "device_bytes": int(st.device_bytes)},
-                "setup_s": {"generate": round(t_gen, 1), "flatten_upload": round(t_flat, 1)},
+                "setup_s": {"generate_tree_and_batches": round(t_gen, 1), "flatten_upload": round(t_flat, 1)},
                 "kernel_hash": kernel_hash(),
             },
-            "roofline": issue,
-            "roofline_hbm": hbm,
+            "roofline": roof,
             "roofline_candidates": cands,
             "walk": {"reads_walked_per_step": int(walk_reads), "wave_iterations_per_step": int(walk_iters // max(1, args.steps)),
-                     "enabled": not args.no_walk},
+                     "enabled": not args.no_walk,
+                     "reads_by_plan_class": {w.PLAN_NAMES[c]: int(n) for c, n in enumerate(np.bincount(pcls, minlength=6)) if n}},
             "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]), "bytes": int(st.stream_bytes_of[i]),
                          "reads_routed": int(counts[i])} for i in range(st.n_streams)],
         }
         if whole is not None:
-            wi, wh, wc = sweep_roofline("whole_tree", whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],
-                                        whole["stream_sweeps_per_step"], whole["steps_timed"])
+            wr, wc = sweep_roofline("whole_tree", R, whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],
+                                    whole["stream_sweeps_per_step"], whole["steps_timed"])
+            valu = next((c for c in wc if c["bound"] == "valu_issue"), None)
             out["roofline_whole_tree"] = {
-                "what": "same batch with work skipping off: every 64-read tile streams the whole-tree event "
+                "what": "same batch with work skipping and walks off: every 64-read tile streams the whole-tree event "
                         "stream once (BASELINE.json configs[2] 'HBM-roofline run'); not part of `value`",
                 "reads_per_s": R / (whole["kernel_ms_per_step"] * 1e-3),
                 "results_identical_to_timed_run": whole["results_identical_to_timed_run"],
-                "binding": wi, "hbm": wh, "candidates": wc,
-                "served_from": "L2 (chunk-major 1 MB chunks)", "l2_peak": L2_PEAK_GBS,
-                "algorithmic_frac_of_l2_peak": wh["achieved"] / L2_PEAK_GBS}
+                "served_from": "L2: the tiles of a launch sweep the same 1 MB chunk together (chunk-major order), so the "
+                               "algorithmic rate is an L2 rate, not an HBM rate -- it is priced against the L2 peak, and the "
+                               "kernel's binding unit is vector issue",
+                "algorithmic_gbs": wr["achieved"], "l2_peak_gbs": L2_PEAK_GBS, "frac_of_l2_peak": wr["achieved"] / L2_PEAK_GBS,
+                "algorithmic_bytes_per_step": wr["algorithmic_bytes_per_step"], "kernel_ms_per_step": wr["kernel_ms_per_step"],
+                "hbm_side_traffic_gbs": wr.get("traffic_gbs"), "hbm_side_traffic_frac_of_8TBs": wr.get("traffic_frac"),
+                "l2_hit_rate": wr.get("l2_hit_rate"), "valu_issue": valu, "provenance": wr.get("provenance")}
         out["sensitivity"] = sens
         if world == 1 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(g.tree, reads, gpu_res, args.cpu_baseline_seconds)

@@ -192,7 +192,8 @@ int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
 /* Per-read walks on (default) / off: when on, a read that lists at most 16 positions visits only the
  * events of those positions (position index + range queries over the stream) instead of sweeping the
  * whole stream with 63 other reads; when off every read is placed by a sweep.  Affects speed only,
- * never results. */
+ * never results.  WEPP_ELIMIT when enabling on a tree with a stream of 2^25 nodes or more (the walk's interval
+ * stack packs a subtree end into 25 bits; such a tree is placed by sweeps). */
 int wepp_mat_set_use_walk(wepp_mat_t *mat, int enable);
 
 /* Timing of the dominant kernel (k_sweep), measured with HIP events recorded on
@@ -202,9 +203,11 @@ int wepp_mat_set_use_walk(wepp_mat_t *mat, int enable);
  * handle was created or wepp_mat_timing_reset() was called (the most recent 64
  * calls are kept).  Blocks until those launches have finished.
  * mean_sweep_ms = mean duration of the sweep / walk launches of one call; passes =
- * event-stream sweeps of the last call (one per tile) plus the 64-read waves of its walks;
- * algorithmic_bytes = bytes the sweeps read (sum over tiles of their stream's size) plus 26 bytes
- * per loop iteration of the walks (index entry, node key and flags, two sparse-table bytes). */
+ * event-stream sweeps of a call (one per tile) plus the 64-read waves of its walks, averaged like the bytes;
+ * algorithmic_bytes = bytes the sweeps read (sum over tiles of their stream's size) plus what the walks' lanes
+ * asked memory for, counted by the kernel (a 32-byte index entry per node event, the sparse-table bytes and
+ * range-query aggregates actually requested, list heads, read words, the start states of the jobs, results),
+ * averaged over the calls since the reset. */
 int wepp_mat_timing_reset(wepp_mat_t *mat);
 int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_calls, uint64_t *passes,
                          uint64_t *algorithmic_bytes);
@@ -213,6 +216,18 @@ int wepp_mat_last_timing(wepp_mat_t *mat, float *mean_sweep_ms, uint32_t *n_call
  * the handle's most recent placement call was routed to; n_reads must be that call's.
  * Synchronises the device.  Lets a test reach every stream with the oracle. */
 int wepp_mat_last_tiers(wepp_mat_t *mat, uint8_t *tiers, uint32_t n_reads);
+
+/* Diagnostic: the full plan of every read of the handle's most recent placement call: plan_class[r] = how it was
+ * placed (WEPP_PLAN_*), plan_stream[r] = on which stream (index into wepp_mat_stats::stream_tau; for
+ * WEPP_PLAN_WIN the index of the genome window).  n_reads must be that call's.  Synchronises the device.  Lets a
+ * test reach every (class, stream) pair with the oracle. */
+#define WEPP_PLAN_WALK8   0   /* per-read walk, up to 8 listed positions                  */
+#define WEPP_PLAN_WALK16  1   /* per-read walk, up to 16                                   */
+#define WEPP_PLAN_SWEEP   2   /* sweep of the stream with up to 63 other reads             */
+#define WEPP_PLAN_WALKC8  3   /* walk cut into jobs (many events), up to 8 positions       */
+#define WEPP_PLAN_WALKC16 4   /* walk cut into jobs, up to 16 positions                    */
+#define WEPP_PLAN_WIN     5   /* sweep of a genome window's stream (long reads)            */
+int wepp_mat_last_plans(wepp_mat_t *mat, uint8_t *plan_class, uint8_t *plan_stream, uint32_t n_reads);
 
 /* Diagnostic: reads of the handle's most recent placement call that walked their own events (k_walk;
  * the others were placed by sweeps of their stream), and the loop iterations (one per event, interval end or

@@ -5,6 +5,8 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
 #include <vector>
 
 int main(int argc, char** argv) {
@@ -24,6 +26,21 @@ int main(int argc, char** argv) {
         for (uint32_t i = 0; i < 64; i++)
             if (hit[i] != (i < n ? 1 : 0)) { std::printf("BAD round %d task %u ran %d times\n", round, i, (int)hit[i]); return 1; }
         total += n;
+        // every 97th round: some tasks throw.  All tasks of the round still run (they reference this frame), the
+        // first exception comes out of run() on this thread, and the pool works on afterwards.
+        if (round % 97 == 0) {
+            for (auto& h : hit) h = 0;
+            bool caught = false;
+            try {
+                pool.run(n, [&](uint32_t i) {
+                    hit[i]++;
+                    if (i % 3 == 0) throw std::runtime_error("task failed");
+                });
+            } catch (const std::runtime_error&) { caught = true; }
+            if (!caught) { std::printf("BAD round %d: the exception was lost\n", round); return 1; }
+            for (uint32_t i = 0; i < 64; i++)
+                if (hit[i] != (i < n ? 1 : 0)) { std::printf("BAD throwing round %d task %u ran %d times\n", round, i, (int)hit[i]); return 1; }
+        }
     }
     std::printf("ok %ld tasks\n", total);
     return 0;

@@ -467,16 +467,27 @@ def test_full_size_parity_and_properties(oracle):
         assert (got.num_best[idx] == want["num_best"]).all()
         assert (got.has_unique[idx] == want["has_unique"]).all()
 
-    # 1. up to 900 reads of every non-empty tier, then the head of the batch up to 10 240 reads
+    # 1. up to 900 reads of every non-empty PLAN -- (class, stream): plain walks of both sizes, chunked walks, sweeps,
+    # each on every stream the batch reaches --, then the head of the batch up to 10 240 reads
+    pcls, pst = mat.last_plans(reads.n_reads)
+    assert (np.where(pcls == w.PLAN_WIN, mat.stats.n_streams - 1, pst) == tiers).all()
     present = [int(t) for t in np.unique(tiers)]
     assert len(present) >= 6, present                      # the batch reaches many crown streams
+    plan_key = pcls.astype(np.int32) * 64 + pst
     pick = []
-    for t in present:
-        pick.extend(np.nonzero(tiers == t)[0][:900].tolist())
+    for key in np.unique(plan_key):
+        pick.extend(np.nonzero(plan_key == key)[0][:900].tolist())
     rest = np.setdiff1d(np.arange(20000), np.array(pick))
     pick = np.array(sorted(set(pick) | set(rest[: max(0, 10240 - len(pick))].tolist())))
     assert len(pick) >= 10000
     same(res, pick, inc.place_batch(gather(pick), nthreads=nthr))
+    # every non-empty plan has at least 200 of its reads (or all of them) among the checked ones
+    checked = np.zeros(reads.n_reads, bool)
+    checked[pick] = True
+    for key in np.unique(plan_key):
+        members = plan_key == key
+        assert (checked & members).sum() >= min(200, members.sum()), (w.PLAN_NAMES[key // 64], key % 64)
+    assert {w.PLAN_WALK8, w.PLAN_WALKC8} <= set(np.unique(pcls).tolist())
     # 2. the faithful oracle: 2 reads per tier
     few = np.array([q for t in present for q in np.nonzero(tiers == t)[0][:2].tolist()])
     same(res, few, ot.place_batch(gather(few), nthr, node_parallel=True))
@@ -526,6 +537,26 @@ def test_full_size_parity_and_properties(oracle):
     k_nm = cs[reads.read_off[1:].astype(np.int64)] - cs[reads.read_off[:-1].astype(np.int64)]
     assert (res.score <= k_nm).all() and (res.score >= 0).all() and (res.num_best >= 1).all()
     mat.close()
+
+
+def test_full_size_nrich_and_long_shard():
+    """What bench.py's sensitivity ladder times, oracle-checked at the size it is timed at: the N rate 5 % batch and
+    the exactly-8-entries batch on the 16 M-node MAT (chunked walks of both classes, start states by bisection,
+    per-entry pre-test bytes at the PRODUCT's threshold: the child process does not inherit this suite's
+    WEPP_IX_PRE_MIN_NODES=0), >= 5 000 reads of each against the incremental checker with every (class, stream)
+    plan covered; then configs[4] at its per-GPU shard size, 125 000 reads of 1.2 kb: every 250th read against the
+    checker, two half batches = the whole, tile-size invariance.  tests/nrich_full_size.py does the work."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "WEPP_IX_PRE_MIN_NODES"}
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nrich_full_size.py")
+    run = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    rep = json.loads(run.stdout.strip().splitlines()[-1])
+    assert rep["nodes"] == 16_000_000 and {"walkc8", "walkc16"} <= set(rep["classes_seen"])
+    assert all(b["checked"] >= 5000 for b in rep["batches"]) and rep["long_reads"]["checked"] >= 500
+    assert rep["long_reads"]["window_plan_share"] > 0.9
+    print("full-size N-rich / long-shard report:", json.dumps(rep))
 
 
 def test_two_handles_two_host_threads(oracle):

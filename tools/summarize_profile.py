@@ -5,6 +5,9 @@ its roofline objects (keyed by workload mode and by the hash of the kernel sourc
 
     python tools/summarize_profile.py gpurun_out/prof_<tag> <name> <mode: short_reads|whole_tree|long_reads>
 
+profiles/pmc_counters.json is keyed "<mode>:<reads per step>" (+ the kernel hash inside the entry): bench.py quotes a
+profile only for the workload, the batch size and the build it was taken on.
+
 HBM-side bytes follow MI355X_MICROARCH.md (HBM section): bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, with
 FETCH_SIZE doubled because on gfx950 it reports half of the bytes of a coalesced streaming read.
 Infinity-Cache hits are counted by FETCH_SIZE, so this is the traffic leaving the L2s, an upper bound on
@@ -30,9 +33,11 @@ def main(src, name, mode):
     if os.path.exists(bt):
         try:
             b = json.load(open(bt))
-            steps = b["steps"] + b["warmup"]
+            steps = b["steps"] + b["warmup"] + 1      # (+ the untimed step that reports batch 0's routing)
+            summ["reads_per_step"] = b["config"]["reads_per_gpu"]
             summ["bench_under_trace"] = {k: b[k] for k in ("value", "ms_per_step")}
             summ["bench_under_trace"]["kernel_ms_per_step"] = b["roofline"]["kernel_ms_per_step"]
+            summ["bench_under_trace"]["algorithmic_bytes_per_step"] = b["roofline"].get("algorithmic_bytes_per_step")
             assert b["config"]["kernel_hash"] == summ["kernel_hash"], "profile taken on other kernel sources"
         except Exception as e:  # noqa: BLE001
             summ["bench_under_trace_error"] = repr(e)
@@ -76,11 +81,16 @@ def main(src, name, mode):
             entry[dst] = c[src_name]
     if "TCC_HIT_sum" in c and c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0) > 0:
         entry["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        entry["tcc_miss_bytes_per_step"] = c["TCC_MISS_sum"] * 64
+    if c.get("SQ_WAVE_CYCLES"):
+        entry["sq_wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_INSTS_VMEM_RD") and c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        entry["cache_lines_per_vmem_read_inst"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"]
     summ["entry"] = entry
     json.dump(summ, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
     tp = os.path.join("profiles", "pmc_counters.json")
     t = json.load(open(tp)) if os.path.exists(tp) else {}
-    t[mode] = entry
+    t[f"{mode}:{summ.get('reads_per_step', 0)}"] = entry
     json.dump(t, open(tp, "w"), indent=1)
     print(json.dumps(entry, indent=1))
 

@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import lib, check
 
 A, C, G, T, N = 1, 2, 4, 8, 15  # nucleotide masks, src/mutation_annotated_tree.cpp:19-74
+# how a read was placed (include/wepp_place.h WEPP_PLAN_*, Mat.last_plans)
+PLAN_WALK8, PLAN_WALK16, PLAN_SWEEP, PLAN_WALKC8, PLAN_WALKC16, PLAN_WIN = range(6)
+PLAN_NAMES = ("walk8", "walk16", "sweep", "walkc8", "walkc16", "window")
 
 
 def pack_read_word(position, ref_nuc, mut_nuc, is_missing=0):
@@ -459,6 +462,14 @@ class Mat:
         out = np.zeros(int(n_reads), np.uint8)
         check(lib.wepp_mat_last_tiers(self._h, _ptr(out), int(n_reads)))
         return out
+
+    def last_plans(self, n_reads):
+        """(class, stream) of every read of the last placement call: class = PLAN_* (how it was placed), stream =
+        index of the sweep stream (or of the genome window for PLAN_WIN)."""
+        cls = np.zeros(int(n_reads), np.uint8)
+        st = np.zeros(int(n_reads), np.uint8)
+        check(lib.wepp_mat_last_plans(self._h, _ptr(cls), _ptr(st), int(n_reads)))
+        return cls, st
 
     def last_walk(self):
         """(reads of the last call placed by the per-read walk, walk loop iterations since timing_reset)."""

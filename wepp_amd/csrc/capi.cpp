@@ -161,10 +161,16 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
 #undef UP
     {
         static const bool walk_on = !(getenv("WEPP_WALK") && getenv("WEPP_WALK")[0] == '0');
-        h->use_walk = walk_on ? 1 : 0;
+        // k_walk keeps an open interval as (subtree end << WALK_DELTA_BITS) | delta in one dword: a stream of
+        // 2^(32 - WALK_DELTA_BITS) nodes or more is left to the sweeps (device_mat.hpp)
+        h->walk_ok = 1;
+        for (const Stream& st : f.streams)
+            if ((uint64_t)st.n >= (1ull << (32 - WALK_DELTA_BITS))) h->walk_ok = 0;
+        h->use_walk = (walk_on && h->walk_ok) ? 1 : 0;
     }
-    e = hipMalloc((void**)&h->d_work, WALK_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->d_work, 0, WALK_COUNTERS * sizeof(unsigned long long));
+    // (two arrays of WALK_COUNTERS slots: loop iterations of the walks' waves, bytes their lanes asked memory for)
+    e = hipMalloc((void**)&h->d_work, 2 * WALK_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_work, 0, 2 * WALK_COUNTERS * sizeof(unsigned long long));
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     e = hipMalloc((void**)&h->d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_PLANS) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(h->d_info, 0, 2 * TI_WORDS * sizeof(uint32_t));
@@ -216,6 +222,8 @@ extern "C" int wepp_mat_set_use_crowns(wepp_mat_t* mat, int enable) {
 
 extern "C" int wepp_mat_set_use_walk(wepp_mat_t* mat, int enable) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    if (enable && !mat->walk_ok)
+        return set_error(WEPP_ELIMIT, "per-read walks need streams of fewer than 2^25 nodes; this tree is placed by sweeps");
     mat->use_walk = enable ? 1 : 0;
     return WEPP_OK;
 }
@@ -539,6 +547,9 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                 jb.part_rank = (uint32_t*)w2; w2 += b_job;
                 jb.part_cnt = (uint32_t*)w2;
                 const uint32_t* list3 = walkc[cc].p[0].list;
+                // gather (list, count in, count out), scan (in, out), combination (list, offset, count, three partial
+                // arrays, four results): what the chain's small kernels move
+                bytes += (uint64_t)R3 * (12 + 8 + 12 + 16) + (uint64_t)J * 12;
                 HIP_TRY(launch_gather_jobs(list3, R3, job_n, jcnt, q));
                 HIP_TRY(launch_exclusive_scan_u32(jcnt, joff, R3, jtmp, scan_temp[cc], q));
                 HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, info[TI_OPEN + 2 + cc], jb, d_read_off, d_read_word, root_score, mat->d_work, q));
@@ -599,6 +610,8 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     mat->n_timed++;
     mat->last_passes = passes;
     mat->last_bytes = bytes;
+    mat->acc_passes += passes;
+    mat->acc_bytes += bytes;
     mat->last_n_reads = n_reads;
     mat->last_walk_reads = walk_reads;
     return WEPP_OK;
@@ -607,9 +620,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
 extern "C" int wepp_mat_timing_reset(wepp_mat_t* mat) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
     mat->n_timed = 0;
+    mat->acc_passes = mat->acc_bytes = 0;
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(mat->d_work, 0, WALK_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(mat->d_work, 0, 2 * WALK_COUNTERS * sizeof(unsigned long long)));
     return WEPP_OK;
 }
 
@@ -627,18 +641,19 @@ extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint3
         HIP_TRY(hipEventElapsedTime(&ms, mat->ev0[slot], mat->ev1[slot]));
         sum += ms;
     }
-    // what the walks read: per loop iteration one index entry (12 B), one node key + flags (12 B) and two
-    // sparse-table bytes; averaged over the calls since the reset
-    unsigned long long it = 0;
+    // what the walks asked memory for: counted by their lanes (k_walk: a 32-byte index entry per node event, the
+    // sparse-table bytes and range-query aggregates actually requested, list heads, read words, start states of
+    // the jobs, results); averaged over the calls since the reset
+    unsigned long long wb = 0;
     {
         std::vector<unsigned long long> slots(WALK_COUNTERS);
-        HIP_TRY(hipMemcpy(slots.data(), mat->d_work, WALK_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        for (unsigned long long v : slots) it += v;
+        HIP_TRY(hipMemcpy(slots.data(), mat->d_work + WALK_COUNTERS, WALK_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (unsigned long long v : slots) wb += v;
     }
     if (mean_sweep_ms) *mean_sweep_ms = (float)(sum / n);
     if (n_calls) *n_calls = n;
-    if (passes) *passes = mat->last_passes;
-    if (algorithmic_bytes) *algorithmic_bytes = mat->last_bytes + (uint64_t)(it / std::max<uint64_t>(1, mat->n_timed)) * 26u;
+    if (passes) *passes = mat->acc_passes / std::max<uint64_t>(1, mat->n_timed);
+    if (algorithmic_bytes) *algorithmic_bytes = (mat->acc_bytes + wb) / std::max<uint64_t>(1, mat->n_timed);
     return WEPP_OK;
 }
 
@@ -1007,6 +1022,22 @@ extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_r
     return WEPP_OK;
 }
 
+// diagnostic: the full plan id (class and stream) of every read of the handle's most recent placement call
+extern "C" int wepp_mat_last_plans(wepp_mat_t* mat, uint8_t* plan_class_out, uint8_t* plan_stream_out, uint32_t n_reads) {
+    if (!mat || !plan_class_out || !plan_stream_out) return set_error(WEPP_EINVAL, "null argument");
+    if (n_reads != mat->last_n_reads || !mat->ws)
+        return set_error(WEPP_EINVAL, "n_reads differs from the handle's last placement call");
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(plan_stream_out, mat->ws, n_reads, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const uint32_t id = plan_stream_out[r];
+        plan_class_out[r] = (uint8_t)plan_class(id);
+        plan_stream_out[r] = (uint8_t)plan_index(id);
+    }
+    return WEPP_OK;
+}
+
 // diagnostic: how the most recent placement call placed its reads
 extern "C" int wepp_mat_last_walk(wepp_mat_t* mat, uint64_t* reads_walked, uint64_t* walk_iterations) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
@@ -1033,6 +1064,10 @@ extern "C" int wepp_mat_last_walk(wepp_mat_t* mat, uint64_t* reads_walked, uint6
                 fprintf(stderr, "[walk stats] %s: waves %llu iterations/wave %.1f cycles/wave: decode %.0f stage %.0f start-state %.0f walk %.0f write %.0f\n",
                         c ? "chunked" : "plain", v[5], (double)v[6] / v[5], (double)v[0] / v[5], (double)v[1] / v[5], (double)v[2] / v[5],
                         (double)v[3] / v[5], (double)v[4] / v[5]);
+            if (v[5] && v[5] < (1ull << 40))
+                fprintf(stderr, "[walk stats] %s: lanes with work %llu  lane-iterations %llu (%.1f per lane, %.1f%% of wave-iterations x 64)  node events %llu  "
+                        "table bytes %llu  exact range queries %llu\n", c ? "chunked" : "plain", v[11], v[7], (double)v[7] / std::max(1ull, v[11]),
+                        100.0 * v[7] / std::max(1.0, 64.0 * v[6]), v[8], v[9], v[10]);
         }
     }
     return WEPP_OK;

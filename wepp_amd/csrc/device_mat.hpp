@@ -104,6 +104,11 @@ constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would 
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
 constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
+// an open interval on a walk's stack is one dword: (subtree end << WALK_DELTA_BITS) | (delta + WALK_DELTA_BIAS).  The
+// delta of one node is a sum over at most WALK16_K listed positions of values in [-2, 2]; the end keeps 25 bits, so
+// streams of 2^25 nodes or more cannot be walked (capi.cpp leaves such a tree to the sweeps)
+constexpr uint32_t WALK_DELTA_BITS = 7, WALK_DELTA_BIAS = 64;
+static_assert(2 * WALK16_K < WALK_DELTA_BIAS, "a node's delta must fit the stack entry's delta field");
 constexpr uint32_t WALK8_ROWS = WALK8_STACK, WALK16_ROWS = WALK16_STACK;   // (default stack rows: see WALK_WAVES above)
 struct WalkPlanDev {
     uint32_t tier, n_list, wave_end, job0;   // wave_end = first wave (of the launch) after this plan;

@@ -29,7 +29,11 @@ int hipf(hipError_t e, const char* what) {
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 16)); }
+    // (a buffer that is allocated again -- a retry after a failed upload -- gives its old block back first)
+    hipError_t alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        return hipMalloc(&p, std::max<size_t>(n, 16));
+    }
     template <typename T> T* as() { return (T*)p; }
 };
 }  // namespace
@@ -215,7 +219,9 @@ extern "C" int wepp_fitch_plan_run(wepp_fitch_plan_t* plan, uint32_t n_sites, co
     // per batch of 64 rows: the decision tables and the two partial-sum scratch arrays
     const size_t part_bytes = levels ? 0 : (size_t)C * D * 64 * 16;
     const size_t per_batch = (size_t)N * rows_per_batch + 2 * part_bytes;
-    const size_t budget = free_b / 2;
+    // (the decision tables the plan already holds are part of what a run may use: without them in the sum every run
+    // after the first saw half the memory and cut its rows into twice as many groups)
+    const size_t budget = (free_b + plan->tables_bytes) / 2;
     const uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nbatches, budget / std::max<size_t>(per_batch, 1)));
     // per-call buffers; the decision tables (tens of GB at 16 M nodes) and the topology stay with the plan
     const size_t tables_need = (size_t)N * rows_per_batch * group;

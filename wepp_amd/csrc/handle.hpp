@@ -23,6 +23,7 @@ struct wepp_mat {
     std::vector<DevStream> streams;
     std::vector<DevWalk> walks;       // position index + range-query structures of every stream (k_walk)
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
+    int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
     unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset
     std::vector<uint64_t> stream_bytes;
     std::vector<DevStream> wstreams;  // window streams (PLAN_WIN)
@@ -69,6 +70,7 @@ struct wepp_mat {
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_timed = 0;             // placement calls since the last timing reset
     uint64_t last_passes = 0, last_bytes = 0;
+    uint64_t acc_passes = 0, acc_bytes = 0;   // the same summed over the calls since the last timing reset
     uint64_t last_walk_reads = 0;     // reads of the most recent call that walked their own events (k_walk)
     uint32_t last_n_reads = 0;        // reads of the most recent placement call (wepp_mat_last_tiers)
 };

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -30,7 +31,9 @@ class HostPool {
     HostPool& operator=(const HostPool&) = delete;
     uint32_t workers() const { return (uint32_t)threads_.size(); }
 
-    // fn(i) for i in [0, n), shared between the workers and the caller; returns when all are done
+    // fn(i) for i in [0, n), shared between the workers and the caller; returns when all are done.  An exception
+    // thrown by fn (on any thread) is kept -- the first one --, the remaining tasks still run to the end (they may
+    // reference the caller's locals, which must outlive them), and run() rethrows it on the calling thread.
     void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
         if (n == 0) return;
         {
@@ -41,14 +44,21 @@ class HostPool {
             n_ = n;
             next_.store(0, std::memory_order_relaxed);
             done_ = 0;
+            error_ = nullptr;
             gen_++;
         }
         cv_.notify_all();
         const uint32_t mine = work();
-        std::unique_lock<std::mutex> lk(m_);
-        done_ += mine;
-        cv_done_.wait(lk, [this] { return done_ == n_ && active_ == 0; });
-        fn_ = nullptr;
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            done_ += mine;
+            cv_done_.wait(lk, [this] { return done_ == n_ && active_ == 0; });
+            fn_ = nullptr;
+            err = error_;
+            error_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 
   private:
@@ -57,7 +67,12 @@ class HostPool {
         for (;;) {
             const uint32_t i = next_.fetch_add(1, std::memory_order_relaxed);
             if (i >= n_) break;
-            (*fn_)(i);
+            try {
+                (*fn_)(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!error_) error_ = std::current_exception();
+            }
             mine++;
         }
         return mine;
@@ -89,6 +104,7 @@ class HostPool {
     std::atomic<uint32_t> next_{0};
     uint64_t gen_ = 0;
     bool stop_ = false;
+    std::exception_ptr error_;    // first exception of the current round (guarded by m_)
 };
 
 }  // namespace wepp

@@ -1307,6 +1307,10 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
 #else
 #define WALK_STAMP(i)
 #endif
+    // what the walk asks memory for, in bytes (DESIGN.md 4.2 "algorithmic bytes"): the rare requests are added per
+    // lane (lane_bytes), the two of the loop body -- a 32-byte index entry per node event, a sparse-table byte per
+    // range pre-test -- are counted per wave with a population count of the lanes that issue them
+    uint32_t lane_bytes = 0, n_ent = 0, n_spb = 0;
     uint32_t pi = 0;
     while (pi + 1 < pl.n && unit >= pl.p[pi].wave_end) pi++;
     const WalkPlanDev& q = pl.p[pi];
@@ -1342,6 +1346,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             rd = q.list[lp];
             chunk = job - (a ? stk[a - 1] : jb.job_off[lp0]);
             n_chunks = jb.job_n[rd];
+            lane_bytes += 4 + 4 + 4;                  // its job offset, list entry and job count
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1352,6 +1357,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     const uint32_t so = have ? read_off[rd] : 0u;
     const uint32_t k = have ? read_off[rd + 1] - so : 0u;
     const int root_sc = have ? root_score[rd] : 0;
+    // list entry, two offsets, root score; per listed position its word and list head (chunked: also the next head)
+    if (have) lane_bytes += (CHUNKED ? 0u : 4u) + 8u + 4u + k * (CHUNKED ? 20u : 12u);
 
     // ---- set-up: the read's words, the start of every position's list, its first node ----
     uint32_t head[KW];
@@ -1391,8 +1398,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     if (CHUNKED) {
         // this job's nodes [pos, n): cut at the quantiles of the longest list (k_route made sure it has at
         // least n_chunks entries)
-        if (chunk + 1 < n_chunks) n = ix.ix_ent[long_off + (uint32_t)(((uint64_t)(chunk + 1) * long_len) / n_chunks)].node;
-        if (chunk) pos = ix.ix_ent[long_off + (uint32_t)(((uint64_t)chunk * long_len) / n_chunks)].node;
+        if (chunk + 1 < n_chunks) { n = ix.ix_ent[long_off + (uint32_t)(((uint64_t)(chunk + 1) * long_len) / n_chunks)].node; lane_bytes += 4; }
+        if (chunk) { pos = ix.ix_ent[long_off + (uint32_t)(((uint64_t)chunk * long_len) / n_chunks)].node; lane_bytes += 4; }
         // ---- the state of a sequential walk when it reaches `pos` ----
         // every list's cursor at its first entry >= pos: binary searches, four lists side by side (their
         // loads in flight together); cursors and words live in LDS, so the loops over the lists stay rolled
@@ -1408,6 +1415,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                     const uint32_t p = w_pos(read_word[so + j0 + u]);
                     lo[u] = cur_l[(j0 + u) * 64 + lane];
                     hi[u] = p <= m.max_pos ? ix.ix_head[p + 1].off - 1u : lo[u];       // (the sentinel stays out)
+                    lane_bytes += 4 + 4;
                 }
             }
             // first entry of the list goes to the stack region for a moment: the predecessor test below needs it
@@ -1421,6 +1429,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     if (lo[u] < hi[u]) {
+                        lane_bytes += 4;
                         const uint32_t mid = (lo[u] + hi[u]) >> 1;
                         if (probe[u] < pos) lo[u] = mid + 1; else hi[u] = mid;
                         searching = searching || lo[u] < hi[u];
@@ -1439,6 +1448,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                     IxEnt ent{};
                     while (e != NONE) {
                         ent = ix.ix_ent[e];
+                        lane_bytes += 32;
                         if (ent.end > pos) break;
                         e = ent.up;
                     }
@@ -1449,24 +1459,25 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                             // insertion by subtree end, outermost at the bottom (the intervals are nested)
                             const uint32_t end = ent.end;
                             uint32_t at = sp;
-                            while (at > 0 && (stk[(at - 1) * 64 + lane] >> 7) < end) { stk[at * 64 + lane] = stk[(at - 1) * 64 + lane]; at--; }
-                            stk[at * 64 + lane] = (end << 7) | (uint32_t)(d + 64);
+                            while (at > 0 && (stk[(at - 1) * 64 + lane] >> WALK_DELTA_BITS) < end) { stk[at * 64 + lane] = stk[(at - 1) * 64 + lane]; at--; }
+                            stk[at * 64 + lane] = (end << WALK_DELTA_BITS) | (uint32_t)(d + (int)WALK_DELTA_BIAS);
                             sp++;
                         }
                         e = ent.up;
-                        if (e != NONE) ent = ix.ix_ent[e];
+                        if (e != NONE) { ent = ix.ix_ent[e]; lane_bytes += 32; }
                     }
                 }
             }
         }
         if (sp) {
             const uint32_t e = stk[(sp - 1) * 64 + lane];
-            top_end = e >> 7;
-            top_d = (int)(e & 127u) - 64;
+            top_end = e >> WALK_DELTA_BITS;
+            top_d = (int)(e & ((1u << WALK_DELTA_BITS) - 1u)) - (int)WALK_DELTA_BIAS;
         }
 #pragma unroll
         for (int j = 0; j < KW; j++)
             if ((uint32_t)j < k) head[j] = ix.ix_ent[cur_l[j * 64 + lane]].node;
+        lane_bytes += 4 * k;
     }
     if (!have) pos = n;
     WALK_STAMP(3);          // (chunked) start state found
@@ -1495,14 +1506,22 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     // made of low-score nodes), so the exact query is issued at once, with the other loads of the iteration;
     // large ones ask the sparse table first (there nearly every range fails it)
     const bool eager = ix.n <= m.walk_eager_nodes;
+#ifdef WEPP_WALK_STATS
+    uint32_t st_live = 0, st_pass = 0;
+#endif
     while (__ballot(pos < n)) {
         iters++;
+#ifdef WEPP_WALK_STATS
+        st_live += (uint32_t)__popcll(__ballot(pos < n));
+#endif
         uint32_t i_next = head[0];
 #pragma unroll
         for (int j = 1; j < KW; j++) i_next = min(i_next, head[j]);
         const bool live = pos < n;
         const uint32_t stop = min(min(i_next, top_end), n);
         const bool at_node = live && i_next < top_end && i_next < n;
+        const unsigned long long b_at = __ballot(at_node);
+        n_ent += (uint32_t)__popcll(b_at);
         // ---- everything this iteration reads from memory is requested here, together ----
         // the node of the next event: its record, the list entry that carries it and that list's next node
         IxEnt ent{};
@@ -1528,6 +1547,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             sp_at = (size_t)lvl * ix.n + pos;
             if (!use_pre) mn_early = ix.sp[sp_at];
         }
+        n_spb += (uint32_t)__popcll(__ballot(ranged && !eager && !use_pre));
         // ---- the nodes [pos, stop): none of them carries a listed position, c is constant ----
         if (live && stop > pos) {
             const uint32_t last = stop - 1;
@@ -1543,10 +1563,13 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                 if (use_pre) {
                     const uint32_t pb = ent.rank >> IX_RANK_BITS;
                     by_entry = pb == SP_NONE || (pb < SP_CLAMP && (int)pb + c > bs);
-                    if (!by_entry) mn = ix.sp[sp_at];          // (rare on the large streams: the byte of the table after all)
+                    if (!by_entry) { mn = ix.sp[sp_at]; lane_bytes += 1; }   // (rare on the large streams: the byte of the table after all)
                 }
                 pass = !by_entry && mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
             }
+#ifdef WEPP_WALK_STATS
+            st_pass += (uint32_t)__popcll(__ballot(pass));
+#endif
             if (__ballot(pass)) {
                 if (pass) {
                     // exact aggregate of the statically eligible nodes of [pos, stop): suffix of the first node's
@@ -1560,10 +1583,12 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                     if (ba == bl) {
                         // inside one block: its prefix up to the last node, unless the range starts behind the
                         // block's first node -- then node by node
+                        lane_bytes += 16;
                         if (pos == ba * RQ_BLK) join(ix.rq_pre[last]);
                         else if (last + 1 == min(ix.n, (ba + 1) * RQ_BLK)) join(ix.rq_suf[pos]);
                         else
                             for (uint32_t i = pos; i < stop; i++) {
+                                if (i > pos) lane_bytes += 16;
                                 const NodeRec x = ix.nrec[i];
                                 if (x.nstat & NS_ELIG0_DEV) {
                                     const uint32_t hu = (x.nstat & NS_ROOT_DEV) ? 0u : (x.nstat & NS_MASKED_DEV) ? 1u :
@@ -1579,6 +1604,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                         const SegNode s1 = ix.rq_suf[pos], s2 = ix.rq_pre[last];
                         const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
                         join(s1); join(s2); join(s3); join(s4);
+                        lane_bytes += 32 + (lo <= hi ? 16 : 0) + (lo < hi ? 16 : 0);
                     }
                     if (ag.cnt && ag.base + c <= bs) take(ag.base + c, ag.rank, ag.cnt, ag.hu);
                 }
@@ -1592,12 +1618,12 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                 sp--;
                 if (sp) {
                     const uint32_t e = stk[(sp - 1) * 64 + lane];
-                    top_end = e >> 7;
-                    top_d = (int)(e & 127u) - 64;
+                    top_end = e >> WALK_DELTA_BITS;
+                    top_d = (int)(e & ((1u << WALK_DELTA_BITS) - 1u)) - (int)WALK_DELTA_BIAS;
                 } else { top_end = NONE; top_d = 0; }
             }
         }
-        if (__ballot(at_node)) {
+        if (b_at) {
             if (at_node) {
                 // every listed mutation the node carries (nearly always one: the entry fetched above)
                 const uint32_t node = i_next;
@@ -1621,6 +1647,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                         sw = sword(js);
                         ecur = cur_l[js * 64 + lane];
                         ent = ix.ix_ent[ecur];
+                        lane_bytes += 32;
                     }
                 }
                 const uint32_t nst = ent.nstat;
@@ -1640,7 +1667,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                 if (elig && sc <= bs) take(sc, ix.has_pre ? ent.rank & IX_RANK_MASK : ent.rank, 1u, hu);
                 if (dsum != 0 && end > node + 1) {
                     // k_route admits a read only if its open intervals always fit (sum of ix_nest <= SD)
-                    stk[sp * 64 + lane] = (end << 7) | (uint32_t)(dsum + 64);
+                    stk[sp * 64 + lane] = (end << WALK_DELTA_BITS) | (uint32_t)(dsum + (int)WALK_DELTA_BIAS);
                     sp++;
                     top_end = end;
                     top_d = dsum;
@@ -1656,7 +1683,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             jb.part_score[job] = bs;
             jb.part_rank[job] = br;
             jb.part_cnt[job] = (cnt << 1) | bhu;     // (the job's has_unique rides in bit 0)
+            lane_bytes += 12;
         } else {
+            lane_bytes += 4 + 16;                    // rank -> BFS index, the four results
             // the root always competes, so br is a rank; the clamp only keeps a broken invariant in bounds
             if (best_bfs_j) best_bfs_j[rd] = m.rank2bfs[br < m.N ? br : 0u];
             if (score_out) score_out[rd] = bs;
@@ -1672,11 +1701,24 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
         for (int i = 0; i < 5; i++) atomicAdd(wc + i, ts_[i + 1] - ts_[i]);
         atomicAdd(wc + 5, 1ull);
         atomicAdd(wc + 6, (unsigned long long)iters);
+        // lane-level counts: live lanes summed over the iterations, node events, table bytes, exact queries, lanes with work
+        atomicAdd(wc + 7, (unsigned long long)st_live);
+        atomicAdd(wc + 8, (unsigned long long)n_ent);
+        atomicAdd(wc + 9, (unsigned long long)n_spb);
+        atomicAdd(wc + 10, (unsigned long long)st_pass);
+        atomicAdd(wc + 11, (unsigned long long)__popcll(__ballot(have)));
     }
 #else
-    // plain walks count in the first half of the slots, chunked ones in the second
-    if (work_counter && lane == 0)
-        atomicAdd(work_counter + (CHUNKED ? WALK_COUNTERS / 2 : 0) + (unit & (WALK_COUNTERS / 2 - 1)), (unsigned long long)iters);
+    // plain walks count in the first half of the slots, chunked ones in the second; the bytes in a second array of
+    // WALK_COUNTERS slots behind the iterations
+    {
+        const uint32_t wave_bytes = wave_sum_u32(lane_bytes);
+        if (work_counter && lane == 0) {
+            const uint32_t at = (CHUNKED ? WALK_COUNTERS / 2 : 0) + (unit & (WALK_COUNTERS / 2 - 1));
+            atomicAdd(work_counter + at, (unsigned long long)iters);
+            atomicAdd(work_counter + WALK_COUNTERS + at, (unsigned long long)wave_bytes + 32ull * n_ent + n_spb);
+        }
+    }
 #endif
 }
 
