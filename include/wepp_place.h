@@ -381,6 +381,14 @@ int wepp_flat_get(const wepp_flat_t *flat, const char *name, const void **data, 
                   uint32_t *elem_bytes);
 int wepp_flat_scalars(const wepp_flat_t *flat, wepp_mat_stats *stats, uint32_t *cp_stride);
 int wepp_flat_destroy(wepp_flat_t *flat);
+/* The device half of wepp_mat_create on its own: uploads an image built by wepp_flat_create to HIP device `device`.
+ * The image is only read, so ONE flatten serves every GPU of a node (and several handles on one GPU): the
+ * multi-GPU host loop calls wepp_flat_create once and wepp_mat_upload from each device's host thread, where the
+ * reference re-expands the tree per sample (src/usher_common.cpp:339).  wepp_mat_create == flatten + upload.
+ * The image may be destroyed as soon as the uploads have returned. */
+int wepp_mat_upload(const wepp_flat_t *flat, int device, wepp_mat_t **out);
+/* Diagnostic: full flattens (wepp_mat_create, wepp_flat_create) this process has run. */
+uint64_t wepp_debug_flatten_count(void);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ for step in "$@"; do
     parity)   timeout -k 10 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -s > "$OUT/pytest_parity.log" 2>&1; rc=$?; tail -4 "$OUT/pytest_parity.log";;
     alltests) timeout -k 10 1700 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; rc=$?; tail -4 "$OUT/pytest_gpu.log";;
     bench)    timeout -k 10 600 python bench.py ${BENCH_ARGS:-} > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; rc=$?; cut -c1-600 "$OUT/bench_default.json"; tail -3 "$OUT/bench_default.err";;
-    probe)    timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe.log" 2>&1; rc=$?; cut -c1-400 "$OUT/probe.log";;
+    probe)    timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe${PROBE_TAG:-}.log" 2>&1; rc=$?; cut -c1-330 "$OUT/probe${PROBE_TAG:-}.log";;
+    probe0)   WEPP_WALK_SORT=0 timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe_nosort.log" 2>&1; rc=$?; cut -c1-330 "$OUT/probe_nosort.log";;
     probestats) WEPP_PLACE_LIB=$REPO/variants/walkstats/libwepp_place.so WEPP_WALK_DEBUG=1 timeout -k 10 900 python tools/walk_probe.py > "$OUT/probestats.log" 2>&1; rc=$?; cut -c1-400 "$OUT/probestats.log";;
     *) echo "unknown step $step"; rc=1;;
   esac

@@ -163,6 +163,8 @@ _SIGS = {
     ),
     "wepp_flat_scalars": (ctypes.c_int, [_V, ctypes.POINTER(MatStats), ctypes.POINTER(ctypes.c_uint32)]),
     "wepp_flat_destroy": (ctypes.c_int, [_V]),
+    "wepp_mat_upload": (ctypes.c_int, [_V, ctypes.c_int, ctypes.POINTER(_V)]),
+    "wepp_debug_flatten_count": (ctypes.c_uint64, []),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so is stale

@@ -257,6 +257,11 @@ class FlatView:
             pass
 
 
+def flatten_count():
+    """Full flattens (Mat(tree), FlatView(tree)) this process has run."""
+    return int(lib.wepp_debug_flatten_count())
+
+
 def fitch_last_timing():
     """Wall time by phase (ms) of this thread's last Fitch-Sankoff run: rows prepared on the host, uploads,
     kernels, sort + decode + copy-out."""
@@ -338,11 +343,16 @@ class PlacementResult:
 class Mat:
     """Flattened MAT resident in one GPU's HBM (wepp_mat_t)."""
 
-    def __init__(self, tree, device=0):
+    def __init__(self, tree, device=0, flat=None):
+        """flat = a FlatView of the same tree: upload that image (wepp_mat_upload) instead of flattening again
+        (one flatten per host, one upload per device)."""
         self._h = ctypes.c_void_p()
-        d = tree.desc()
         self._keep = tree
-        check(lib.wepp_mat_create(ctypes.byref(d), int(device), ctypes.byref(self._h)))
+        if flat is not None:
+            check(lib.wepp_mat_upload(flat._h, int(device), ctypes.byref(self._h)))
+        else:
+            d = tree.desc()
+            check(lib.wepp_mat_create(ctypes.byref(d), int(device), ctypes.byref(self._h)))
         self.device = int(device)
         st = _lib.MatStats()
         check(lib.wepp_mat_get_stats(self._h, ctypes.byref(st)))

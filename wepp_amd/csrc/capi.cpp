@@ -49,17 +49,11 @@ void release(wepp_mat* h) {
 
 }  // namespace
 
-extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_t** out) {
-    if (!tree || !out) return set_error(WEPP_EINVAL, "null argument");
+namespace {
+// the device half of wepp_mat_create: the flat image `f` (flatmat.hpp) copied into HBM of `device`, plus the handle's
+// streams, events and counters.  The image is only read: one image serves any number of devices / handles.
+int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
     *out = nullptr;
-    FlatMAT f;
-    std::string err;
-    try {
-        int rc = flatten_tree(*tree, f, err);
-        if (rc != WEPP_OK) return set_error(rc, err);
-    } catch (const std::bad_alloc&) {
-        return set_error(WEPP_ENOMEM, "out of host memory while flattening the tree");
-    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -189,6 +183,29 @@ extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_
     *out = h;
     return WEPP_OK;
 }
+}  // namespace
+
+extern "C" int wepp_mat_create(const wepp_tree_desc* tree, int device, wepp_mat_t** out) {
+    if (!tree || !out) return set_error(WEPP_EINVAL, "null argument");
+    *out = nullptr;
+    FlatMAT f;
+    std::string err;
+    try {
+        int rc = flatten_tree(*tree, f, err);
+        if (rc != WEPP_OK) return set_error(rc, err);
+    } catch (const std::bad_alloc&) {
+        return set_error(WEPP_ENOMEM, "out of host memory while flattening the tree");
+    }
+    return upload_flat(f, device, out);
+}
+
+// One flatten per host, one upload per device: the multi-GPU host loop flattens once (wepp_flat_create) and every
+// device thread uploads the same image.
+extern "C" int wepp_mat_upload(const wepp_flat_t* flat, int device, wepp_mat_t** out) {
+    if (!flat || !out) return set_error(WEPP_EINVAL, "null argument");
+    if (flat->f.streams.empty()) return set_error(WEPP_EINVAL, "the flat image holds no sweep streams");
+    return upload_flat(flat->f, device, out);
+}
 
 extern "C" int wepp_mat_destroy(wepp_mat_t* mat) {
     release(mat);
@@ -260,8 +277,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     size_t sort_temp = 0;
     if (sort_reads) HIP_TRY(sort_reads_temp_bytes(n_reads, &sort_temp));
     sort_temp = (sort_temp + 255) & ~(size_t)255;
-    // fixed part of the workspace: tier | list | root_score | slot in block | sort keys in/out | sort values | sort temp
-    const size_t fixed_bytes = tier_bytes + 4 * list_bytes + (sort_reads ? 3 * list_bytes + sort_temp : 0);
+    // fixed part of the workspace: tier | list | root_score | slot in block | jobs | sort keys in/out | sorted lists |
+    // sort temp of the whole-tree plan and of the four walk classes (their sorts run on different side streams)
+    constexpr uint32_t N_SORTS = 5;
+    const size_t fixed_bytes = tier_bytes + 4 * list_bytes + (sort_reads ? 3 * list_bytes + N_SORTS * sort_temp : 0);
     {
         // before routing only the fixed regions are needed; reserve a typical partial size too
         int rc = grow(fixed_bytes + (size_t)n_reads * 12 * 2);
@@ -282,8 +301,8 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (sort_reads) {
             key_in = (uint32_t*)p; p += list_bytes;
             key_out = (uint32_t*)p; p += list_bytes;
-            val_in = (uint32_t*)p; p += list_bytes;   // the sorted list of the whole-tree stream
-            sort_tmp = p;
+            val_in = (uint32_t*)p; p += list_bytes;   // the sorted lists (same offsets as in `list`)
+            sort_tmp = p;                             // N_SORTS regions of sort_temp bytes
         }
     };
     carve();
@@ -452,9 +471,9 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                     p.lds_bytes, p.ent_cap, p.key_cap, p.part_off);
         // the reads that sweep the whole tree go by first listed position (sort_reads.hip)
         if (sort_reads && !p.window && p.t + 1 == ns && p.count >= SORT_MIN_READS) {
-            HIP_TRY(launch_first_pos(list + p.off, p.count, d_read_off, d_read_word, key_in, stream));
-            HIP_TRY(launch_sort_reads(key_in, key_out, list + p.off, val_in, p.count, sort_tmp, sort_temp, stream));
-            p.lst = val_in;
+            HIP_TRY(launch_first_pos(list + p.off, p.count, d_read_off, d_read_word, key_in + p.off, stream));
+            HIP_TRY(launch_sort_reads(key_in + p.off, key_out + p.off, list + p.off, val_in + p.off, p.count, sort_tmp, sort_temp, stream));
+            p.lst = val_in + p.off;
         }
     }
 
@@ -496,14 +515,37 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     // side streams of the sweeps that are launched on their own (dense / window / out-of-LDS plans); the last
     // three belong to the walks
     constexpr uint32_t OTHER_SIDE_STREAMS = MAX_STREAMS - 3;
+    // A walk class's reads go by (stream, first listed position) when there are enough of them (device_mat.hpp:
+    // WALK_SORT_MIN_READS; WEPP_WALK_SORT=0: A/B aid): sorted on the class's own stream, right before its launch.
+    // `region` = which of the sort temp regions (1..4; 0 is the whole-tree plan's).
+    static const bool walk_sort = sort_reads && !(getenv("WEPP_WALK_SORT") && getenv("WEPP_WALK_SORT")[0] == '0');
+    auto sort_class = [&](uint32_t cls, uint32_t region, hipStream_t q, bool& sorted) -> int {
+        sorted = false;
+        if (!walk_sort) return WEPP_OK;
+        const uint32_t off = info[TI_OFF + plan_id(cls, 0)];
+        const uint32_t cnt = info[TI_OFF + plan_id(cls, 0) + MAX_STREAMS] - off;      // (plan ids of a class are consecutive)
+        if (cnt < WALK_SORT_MIN_READS) return WEPP_OK;
+        HIP_TRY(launch_walk_keys(list + off, cnt, tier_of, d_read_off, d_read_word, key_in + off, q));
+        HIP_TRY(launch_sort_reads(key_in + off, key_out + off, list + off, val_in + off, cnt, (char*)sort_tmp + region * sort_temp,
+                                  sort_temp, q, WALK_SORT_KEY_BITS));
+        sorted = true;
+        return WEPP_OK;
+    };
     if (walks) {
         // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
         // sweeps run side by side (the walks wait on memory most of the time)
         hipStream_t q = fork ? mat->side[MAX_STREAMS - 1] : stream;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
-        for (uint32_t cls = 0; cls < 2; cls++)
+        for (uint32_t cls = 0; cls < 2; cls++) {
+            if (!walk[cls].n) continue;
+            bool sorted = false;
+            int rc = sort_class(cls, 1 + cls, q, sorted);
+            if (rc != WEPP_OK) return rc;
+            if (sorted)
+                for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = val_in + walk_off[cls][k];
             HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
                                 d_num_best, d_flags, mat->d_work, q));
+        }
         if (fork) {
             HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
             joins[n_joins++] = MAX_STREAMS - 1;
@@ -546,6 +588,13 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
                 jb.part_score = (int32_t*)w2; w2 += b_job;
                 jb.part_rank = (uint32_t*)w2; w2 += b_job;
                 jb.part_cnt = (uint32_t*)w2;
+                {
+                    bool sorted = false;
+                    int rc = sort_class(PLAN_WALKC8 + cc, 3 + cc, q, sorted);
+                    if (rc != WEPP_OK) return rc;
+                    if (sorted)
+                        for (uint32_t k = 0; k < walkc[cc].n; k++) walkc[cc].p[k].list = val_in + walkc_off[cc];
+                }
                 const uint32_t* list3 = walkc[cc].p[0].list;
                 // gather (list, count in, count out), scan (in, out), combination (list, offset, count, three partial
                 // arrays, four results): what the chain's small kernels move

@@ -100,6 +100,7 @@ constexpr uint32_t WALK_JOB_EVENTS = 32;
 // Measured (16 M nodes, 1 M reads with 5 % N): rows 16/32 -> 12/20 (2 -> 3.5 waves per SIMD for the 16-entry
 // class) 21.5 -> 19.9 ms, nothing on the other legs: the walks are not short of waves.
 constexpr uint32_t WALK_WAVES = 2;         // waves per workgroup of k_walk (their LDS regions are private)
+constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of a launch runs on XCD b % 8
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
@@ -171,11 +172,19 @@ hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint3
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
 constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less than the sort
+// the walks' lists go by (stream, first listed position): reads of one amplicon -- the same few hundred position lists
+// of the index -- then sit in neighbouring lanes and waves, and a wave's gathers hit lines its neighbours have just
+// brought into the L2 instead of opening a DRAM row each.  Key = stream << SORT_KEY_BITS | position + 1.
+constexpr uint32_t WALK_SORT_KEY_BITS = SORT_KEY_BITS + 4;
+constexpr uint32_t WALK_SORT_MIN_READS = 2048;   // a class with fewer reads keeps the caller's order (the sort is ~8 launches)
+static_assert(MAX_STREAMS <= 16, "stream index in the walks' sort key");
 hipError_t launch_first_pos(const uint32_t* list, uint32_t n, const uint32_t* d_read_off, const uint32_t* d_read_word,
                             uint32_t* keys, hipStream_t stream);
+hipError_t launch_walk_keys(const uint32_t* list, uint32_t n, const uint8_t* tier_of, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, uint32_t* keys, hipStream_t stream);
 hipError_t sort_reads_temp_bytes(uint32_t n, size_t* bytes);
 hipError_t launch_sort_reads(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream);
+                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream, uint32_t key_bits = SORT_KEY_BITS);
 // scatter: read indices grouped by tier into `list` (tier t occupies [tier_off[t], tier_off[t+1]))
 hipError_t launch_scatter(const uint8_t* tier_of, const uint32_t* slot_in_blk, uint32_t n_reads, const uint32_t* blk_counts,
                           uint32_t* tier_info, uint32_t* list, hipStream_t stream);

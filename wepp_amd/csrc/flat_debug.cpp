@@ -8,9 +8,7 @@
 #include "errors.hpp"
 #include "flatmat.hpp"
 
-struct wepp_flat {
-    wepp::FlatMAT f;
-};
+extern "C" uint64_t wepp_debug_flatten_count(void) { return wepp::flatten_count(); }
 
 extern "C" int wepp_flat_create(const wepp_tree_desc* tree, wepp_flat_t** out) {
     if (!tree || !out) return wepp::set_error(WEPP_EINVAL, "null argument");

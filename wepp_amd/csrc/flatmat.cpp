@@ -19,6 +19,7 @@
 #include "flatmat.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <numeric>
 
@@ -411,6 +412,9 @@ int build_window_stream(const FlatMAT& f, uint32_t lo, uint32_t hi, Stream& st, 
 
 }  // namespace
 
+static std::atomic<uint64_t> g_flatten_count{0};
+uint64_t flatten_count() { return g_flatten_count.load(std::memory_order_relaxed); }
+
 int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool topology_only) {
     const uint32_t N = t.n_nodes;
     if (N == 0 || !t.parent || !t.mut_off) { err = "empty tree or null arrays"; return WEPP_EINVAL; }
@@ -608,6 +612,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
     }
 
     if (topology_only) return WEPP_OK;     // orders, parents, leaf flags: all the Fitch-Sankoff pass needs
+    g_flatten_count.fetch_add(1, std::memory_order_relaxed);
 
     // ---- tie-break rank: larger num_leaves first, then larger BFS index -----
     f.rank2dfs.resize(N);

@@ -190,8 +190,18 @@ struct FlatMAT {
 constexpr uint32_t WIN_SIZE = 2560, WIN_STRIDE = 1024, MAX_WINDOWS = 32;
 constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of wepp_mat_stats
 
+// flatten_tree calls of this process that built the full image (not topology_only): lets a test see that a
+// multi-device run flattened once
+uint64_t flatten_count();
+
 // Returns WEPP_OK or an error code; `err` receives the message.
 // topology_only: stop after the orders / parents / per-node flags (no tie-break ranks, sweep streams, EPP stream)
 int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err, bool topology_only = false);
 
 }  // namespace wepp
+
+// the object behind wepp_flat_t (include/wepp_place.h): a flat image on the host, built once, uploaded to any number
+// of devices (wepp_mat_upload) and inspected by the CPU tests (wepp_flat_get)
+struct wepp_flat {
+    wepp::FlatMAT f;
+};

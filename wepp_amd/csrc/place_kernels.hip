@@ -373,6 +373,18 @@ __global__ void k_first_pos(const uint32_t* __restrict__ list, uint32_t n, const
     keys[i] = (read_off[r + 1] > so) ? w_pos(read_word[so]) + 1u : 0u;
 }
 
+// sort key of the reads of a walk class's list: (stream, first listed position) -- the list is grouped by stream
+// already (plan ids ascend), so a sort by this key reorders the reads inside every stream's range only
+__global__ void k_walk_keys(const uint32_t* __restrict__ list, uint32_t n, const uint8_t* __restrict__ tier_of,
+                            const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                            uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = list[i], so = read_off[r];
+    const uint32_t first = (read_off[r + 1] > so) ? w_pos(read_word[so]) + 1u : 0u;
+    keys[i] = (plan_index(tier_of[r]) << SORT_KEY_BITS) | first;
+}
+
 // -----------------------------------------------------------------------------
 // The sweep.  grid = ntiles * nchunks single-wave workgroups.
 // LDS: [bm_words] position bitmap of the tile, then (S_IN_LDS) the tile's read
@@ -1298,7 +1310,17 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     uint32_t* stk = cur_l + KW * 64;
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
     auto sword = [&](int j) -> uint32_t { return ((S16[(j >> 1) * 64 + lane] >> ((j & 1) * 16)) & 0x1FFu) << 20; };
-    const uint32_t unit = blockIdx.x * WALK_WAVES + wv;
+    // Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8), each with its own L2:
+    // XCD x takes the x-th CONTIGUOUS eighth of the launch's waves, so that the waves resident on one XCD hold
+    // neighbouring reads of the position-sorted list -- the same few amplicons' lists of the index
+    uint32_t unit;
+    {
+        const uint32_t g = gridDim.x, b = blockIdx.x, per = g / WALK_XCDS, rem = g % WALK_XCDS;
+        const uint32_t x = b % WALK_XCDS, i = b / WALK_XCDS;      // XCD x's i-th workgroup
+        // (the first `rem` XCDs hold one workgroup more)
+        const uint32_t wg = x * per + min(x, rem) + i;
+        unit = wg * WALK_WAVES + wv;
+    }
     if (unit >= pl.p[pl.n - 1].wave_end) return;
 #ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
     unsigned long long ts_[6];
@@ -2070,6 +2092,13 @@ hipError_t launch_first_pos(const uint32_t* list, uint32_t n, const uint32_t* d_
                             uint32_t* keys, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_first_pos, dim3((n + 255) / 256), dim3(256), 0, stream, list, n, d_read_off, d_read_word, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_keys(const uint32_t* list, uint32_t n, const uint8_t* tier_of, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, uint32_t* keys, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_walk_keys, dim3((n + 255) / 256), dim3(256), 0, stream, list, n, tier_of, d_read_off, d_read_word, keys);
     return hipGetLastError();
 }
 

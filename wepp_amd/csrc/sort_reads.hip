@@ -18,12 +18,12 @@ namespace wepp {
 hipError_t sort_reads_temp_bytes(uint32_t n, size_t* bytes) {
     *bytes = 0;
     return rocprim::radix_sort_pairs(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, SORT_KEY_BITS, nullptr);
+                                     (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, WALK_SORT_KEY_BITS, nullptr);
 }
 
 hipError_t launch_sort_reads(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream) {
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, SORT_KEY_BITS,
+                             uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream, uint32_t key_bits) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, key_bits,
                                      stream);
 }
 

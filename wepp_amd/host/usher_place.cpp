@@ -32,13 +32,16 @@ void flatten(MAT::Tree* T, FlatTree& f) {
     // index, so ascending id under a parent is the stored child order.
     f.bfs = T->breadth_first_expansion();
     const size_t n = f.bfs.size();
-    std::unordered_map<const MAT::Node*, int32_t> id;
-    id.reserve(n * 2);
-    for (size_t k = 0; k < n; k++) id[f.bfs[k]] = (int32_t)k;
-    f.parent.resize(n);
+    // the children of bfs[head] follow one another in the expansion, behind everything queued before them: the
+    // parent's index falls out of the order itself (no Node* -> index map over 16 M nodes)
+    f.parent.assign(n, -1);
+    for (size_t head = 0, next = 1; head < n; head++)
+        for (size_t c = 0; c < f.bfs[head]->children.size(); c++) f.parent[next++] = (int32_t)head;
     f.mut_off.assign(n + 1, 0);
+    size_t total_muts = 0;
+    for (size_t k = 0; k < n; k++) total_muts += f.bfs[k]->mutations.size();
+    f.mut_pos.reserve(total_muts); f.mut_ref.reserve(total_muts); f.mut_par.reserve(total_muts); f.mut_mut.reserve(total_muts);
     for (size_t k = 0; k < n; k++) {
-        f.parent[k] = f.bfs[k]->parent ? id[f.bfs[k]->parent] : -1;
         for (auto& m : f.bfs[k]->mutations) {
             f.mut_pos.push_back(m.position);
             f.mut_ref.push_back((uint8_t)m.ref_nuc);
@@ -142,8 +145,15 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
     std::vector<std::vector<int32_t>> shard_imp_pos(G);
     std::vector<std::vector<uint8_t>> shard_imp_nuc(G);
     auto shard_lo = [&](uint32_t g) { return (uint32_t)((uint64_t)R * g / G); };
+    // ONE flatten for the node (the reference pays its expansion once per sample, usher_common.cpp:339); every device
+    // thread uploads the same image
+    wepp_flat_t* image = nullptr;
+    if (wepp_flat_create(&flat.desc, &image) != WEPP_OK) {
+        fprintf(stderr, "ERROR: %s\n", wepp_last_error());
+        return 1;
+    }
     auto place_shard = [&](uint32_t g) {
-        if (wepp_mat_create(&flat.desc, devices[g], &mats[g]) != WEPP_OK) { errors[g] = wepp_last_error(); return; }
+        if (wepp_mat_upload(image, devices[g], &mats[g]) != WEPP_OK) { errors[g] = wepp_last_error(); return; }
         const uint32_t lo = shard_lo(g), hi = shard_lo(g + 1), n = hi - lo;
         if (n == 0) return;
         std::vector<uint32_t> off, words;
@@ -177,6 +187,7 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
     };
     auto destroy_all = [&]() { for (auto m : mats) if (m) wepp_mat_destroy(m); };
     run_on_devices(place_shard);
+    wepp_flat_destroy(image);
     for (uint32_t g = 0; g < G; g++)
         if (!errors[g].empty()) {
             fprintf(stderr, "ERROR: %s\n", errors[g].c_str());
