@@ -128,8 +128,13 @@ int wepp_mat_bfs_order(const wepp_mat_t *mat, uint32_t *bfs_ids);
  *     best_node_has_unique -> flags[r] & WEPP_FLAG_HAS_UNIQUE
  * Host buffers in, host buffers out (H2D / D2H inside); synchronous: the
  * results are in the caller's buffers on return.  Batches of 65 536 reads and
- * more are checked, staged and moved out by host worker threads the handle
- * starts at the first such call and keeps (wepp_amd/csrc/host_pool.hpp).  Any
+ * more run as a pipeline of 2-4 sub-batches (contiguous ranges of the reads):
+ * host worker threads the handle starts at the first such call and keeps
+ * (wepp_amd/csrc/host_pool.hpp) check and stage the next sub-batch while the
+ * previous one's words go up, the one before runs its kernels and the results
+ * of the one before that come down and are moved out.  Buffers the caller has
+ * pinned (hipHostMalloc / hipHostRegister) are the source / target of the DMA
+ * as they stand: no staging pass.  Results never depend on the split.  Any
  * output pointer may be NULL.  per_node_scores, when non-NULL, receives n_reads * n_nodes
  * int32 values: the -p mode's node_set_difference[k] in BFS order
  * (src/usher_common.cpp:403-409, +1 for ineligible nodes src/usher_mapper.cpp:500-505). */
@@ -195,6 +200,10 @@ int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
  * never results.  WEPP_ELIMIT when enabling on a tree with a stream of 2^25 nodes or more (the walk's interval
  * stack packs a subtree end into 25 bits; such a tree is placed by sweeps). */
 int wepp_mat_set_use_walk(wepp_mat_t *mat, int enable);
+
+/* Tuning knob: sub-batches wepp_place_batch cuts a batch of 65 536 reads or more into (1..8; 0 = default:
+ * 4 from 262 144 reads, 2 below).  Affects speed only, never results. */
+int wepp_mat_set_pipeline(wepp_mat_t *mat, uint32_t sub_batches);
 
 /* Timing of the dominant kernel (k_sweep), measured with HIP events recorded on
  * the launch stream around the sweep (+ the 10-80 us finalize) launches of every

@@ -559,6 +559,54 @@ def test_full_size_nrich_and_long_shard():
     print("full-size N-rich / long-shard report:", json.dumps(rep))
 
 
+def test_pipeline_equals_unsplit_call(oracle):
+    """wepp_place_batch cuts a large batch into sub-batches that overlap staging, H2D, kernels and D2H
+    (include/wepp_place.h): whatever the split -- 1, 2, 3, 4 or 8 sub-batches --, with pageable buffers or with
+    buffers the caller pinned, the four result arrays and the per-read plan ids are those of the unsplit call, and
+    the unsplit call equals the oracle on a sample."""
+    import torch
+    g = w.generate_tree(61, 120_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
+    reads = g.reads(62, 300_001, p_substitution=0.003, p_n=0.02, p_iupac=0.1)
+    mat = w.Mat(g.tree)
+    mat.set_pipeline(1)
+    whole = mat.place_batch(reads)
+    plans = mat.last_plans(reads.n_reads)
+    every = np.arange(0, reads.n_reads, 601)
+    sub = Reads(np.concatenate([[0], np.cumsum(np.diff(reads.read_off.astype(np.int64))[every])]).astype(np.uint32),
+                np.concatenate([reads.read_word[reads.read_off[q]:reads.read_off[q + 1]] for q in every]))
+    want = oracle.OracleTree(g.tree).incremental().place_batch(sub, nthreads=os.cpu_count() or 1)
+    assert (whole.score[every] == want["score"]).all() and (whole.best_bfs_j[every] == want["best_j"]).all()
+    assert (whole.num_best[every] == want["num_best"]).all() and (whole.has_unique[every] == want["has_unique"]).all()
+    for S in (2, 3, 4, 8, 0):
+        mat.set_pipeline(S)
+        got = mat.place_batch(reads)
+        for f in ("score", "best_bfs_j", "num_best", "flags"):
+            assert (getattr(got, f) == getattr(whole, f)).all(), (S, f)
+        pc, ps = mat.last_plans(reads.n_reads)
+        assert (pc == plans[0]).all() and (ps == plans[1]).all(), S
+    # buffers the caller pinned: DMA straight from / into them
+    pin = lambda a: torch.from_numpy(a.copy()).pin_memory().numpy()
+    preads = Reads.__new__(Reads)
+    preads.read_off, preads.read_word = pin(reads.read_off), pin(reads.read_word)
+    out = w.PlacementResult(pin(np.zeros(reads.n_reads, np.uint32)), pin(np.zeros(reads.n_reads, np.int32)),
+                            pin(np.zeros(reads.n_reads, np.uint32)), pin(np.zeros(reads.n_reads, np.uint32)))
+    mat.set_pipeline(4)
+    got = mat.place_batch(preads, out=out)
+    assert got.score is out.score
+    for f in ("score", "best_bfs_j", "num_best", "flags"):
+        assert (getattr(got, f) == getattr(whole, f)).all(), ("pinned", f)
+    # a rejected batch leaves the handle usable, whichever sub-batch the bad read is in
+    broken = Reads(reads.read_off.copy(), reads.read_word.copy())
+    r_bad = int(np.nonzero(np.diff(reads.read_off.astype(np.int64)) >= 2)[0][-1])
+    a = int(broken.read_off[r_bad])
+    broken.read_word[a], broken.read_word[a + 1] = broken.read_word[a + 1], broken.read_word[a]
+    with pytest.raises(w.WeppError, match=f"read {r_bad}:"):
+        mat.place_batch(broken)
+    again = mat.place_batch(reads)
+    assert (again.score == whole.score).all() and (again.best_bfs_j == whole.best_bfs_j).all()
+    mat.close()
+
+
 def test_two_handles_two_host_threads(oracle):
     """include/wepp_place.h: different handles may be used concurrently from different host threads.
     Two handles on device 0, each placing its own contiguous shard of the batch from its own thread

@@ -123,6 +123,7 @@ _SIGS = {
     "wepp_mat_set_tile_reads": (ctypes.c_int, [_V, ctypes.c_uint32]),
     "wepp_mat_set_use_crowns": (ctypes.c_int, [_V, ctypes.c_int]),
     "wepp_mat_set_use_walk": (ctypes.c_int, [_V, ctypes.c_int]),
+    "wepp_mat_set_pipeline": (ctypes.c_int, [_V, ctypes.c_uint32]),
     "wepp_mat_last_tiers": (ctypes.c_int, [_V, _V, ctypes.c_uint32]),
     "wepp_mat_last_plans": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32]),
     "wepp_mat_last_walk": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),

@@ -375,6 +375,10 @@ class Mat:
         """Per-read walks on (default) / off (every read placed by a sweep); speed only, never results."""
         check(lib.wepp_mat_set_use_walk(self._h, 1 if enable else 0))
 
+    def set_pipeline(self, sub_batches):
+        """Sub-batches place_batch cuts a large batch into (0 = default); speed only, never results."""
+        check(lib.wepp_mat_set_pipeline(self._h, int(sub_batches)))
+
     def place_batch(self, reads, per_node_scores=False, out=None):
         """Host buffers in/out: wepp_place_batch.  out = a PlacementResult of a previous call with the
         same number of reads, to reuse its arrays."""

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -42,8 +44,16 @@ void release(wepp_mat* h) {
         if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
-    for (int i = 0; i < 4; i++)
-        if (h->out_ev[i]) (void)hipEventDestroy(h->out_ev[i]);
+    for (uint32_t i = 0; i < wepp_mat::kPipeMax; i++) {
+        if (h->pipe_up[i]) (void)hipEventDestroy(h->pipe_up[i]);
+        if (h->pipe_done[i]) (void)hipEventDestroy(h->pipe_done[i]);
+        if (h->pipe_out[i]) (void)hipEventDestroy(h->pipe_out[i]);
+    }
+    if (h->pipe_h2d) (void)hipStreamDestroy(h->pipe_h2d);
+    if (h->pipe_d2h) (void)hipStreamDestroy(h->pipe_d2h);
+    if (h->pipe_compute) (void)hipStreamDestroy(h->pipe_compute);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->d_plan_of) (void)hipFree(h->d_plan_of);
     delete h;
 }
 
@@ -237,6 +247,13 @@ extern "C" int wepp_mat_set_use_crowns(wepp_mat_t* mat, int enable) {
     return WEPP_OK;
 }
 
+extern "C" int wepp_mat_set_pipeline(wepp_mat_t* mat, uint32_t sub_batches) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    if (sub_batches > wepp_mat::kPipeMax) return set_error(WEPP_EINVAL, "at most 8 sub-batches");
+    mat->pipe_sub_batches = sub_batches;
+    return WEPP_OK;
+}
+
 extern "C" int wepp_mat_set_use_walk(wepp_mat_t* mat, int enable) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
     if (enable && !mat->walk_ok)
@@ -245,15 +262,21 @@ extern "C" int wepp_mat_set_use_walk(wepp_mat_t* mat, int enable) {
     return WEPP_OK;
 }
 
-extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word,
-                                       uint32_t n_reads, uint64_t n_read_words, uint32_t* d_best_bfs_j,
-                                       int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags,
-                                       void* hip_stream) {
-    if (!mat || !d_read_off) return set_error(WEPP_EINVAL, "null argument");
-    if (n_read_words && !d_read_word) return set_error(WEPP_EINVAL, "null read_word");
-    if (n_reads == 0) return WEPP_OK;
-    hipStream_t stream = (hipStream_t)hip_stream;
-    HIP_TRY(hipSetDevice(mat->device));
+namespace {
+// The placement of one batch whose reads are on the device.  plan_base / plan_total: the batch is reads
+// [plan_base, plan_base + n_reads) of a call of plan_total reads (a sub-batch of wepp_place_batch's pipeline; a
+// direct wepp_place_batch_device call is the whole: base 0, total n_reads) -- where its plan ids go in d_plan_of.
+int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
+                 uint32_t* d_best_bfs_j, int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags, hipStream_t stream,
+                 uint32_t plan_base, uint32_t plan_total) {
+    if (plan_total > mat->plan_of_bytes) {
+        // (only ever at the first sub-batch of a call: plan_total is the whole call's)
+        if (mat->d_plan_of) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->d_plan_of); mat->d_plan_of = nullptr; mat->plan_of_bytes = 0; }
+        const size_t need = (size_t)plan_total + plan_total / 4 + 256;
+        hipError_t e = hipMalloc((void**)&mat->d_plan_of, need);
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc plan ids: ") + hipGetErrorString(e));
+        mat->plan_of_bytes = need;
+    }
     const uint32_t T = mat->tile_reads;
     const uint32_t ns = mat->dev.n_streams;
 
@@ -270,7 +293,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         ws_moved = true;
         return WEPP_OK;
     };
-    const size_t tier_bytes = ((size_t)n_reads + 255) & ~(size_t)255;
+    const size_t tier_bytes = 0;       // (the plan ids live in mat->d_plan_of)
     const size_t list_bytes = (((size_t)n_reads * 4) + 255) & ~(size_t)255;
     // WEPP_SORT_READS=0 (A/B aid): keep the caller's read order on the whole-tree stream too
     static const bool sort_reads = !(getenv("WEPP_SORT_READS") && getenv("WEPP_SORT_READS")[0] == '0');
@@ -293,7 +316,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     void* sort_tmp = nullptr;
     auto carve = [&]() {
         char* p = (char*)mat->ws;
-        tier_of = (uint8_t*)p; p += tier_bytes;
+        tier_of = mat->d_plan_of + plan_base;
         list = (uint32_t*)p; p += list_bytes;
         root_score = (int32_t*)p; p += list_bytes;
         slot_in_blk = (uint32_t*)p; p += list_bytes;
@@ -309,7 +332,10 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
     uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
 
-    static const uint32_t job_events = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS"))) : WALK_JOB_EVENTS;
+    // events per job of the two chunked classes: WEPP_WALK_JOB_EVENTS fixes them, else they follow the handle's
+    // traffic (device_mat.hpp: WALK_TARGET_JOBS)
+    static const uint32_t job_events_env = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::min(0xFFFF, std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS")))) : 0u;
+    const uint32_t job_events = job_events_env ? (job_events_env | (job_events_env << 16)) : (mat->job_events[0] | (mat->job_events[1] << 16));
     static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
     static const uint32_t stack8 = getenv("WEPP_WALK_STACK8") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK8")) : WALK8_ROWS;
     static const uint32_t stack16 = getenv("WEPP_WALK_STACK16") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK16")) : WALK16_ROWS;
@@ -340,6 +366,11 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
     }
     const uint32_t* info = mat->h_info;
+    for (uint32_t cc = 0; cc < 2; cc++) {
+        const uint64_t ev = (uint64_t)info[TI_EVENTS + cc] << 6;
+        const uint32_t je = (uint32_t)std::min<uint64_t>(WALK_JOB_EVENTS_MAX, std::max<uint64_t>(WALK_JOB_EVENTS, ev / WALK_TARGET_JOBS));
+        mat->job_events[cc] = (je + 15u) & ~15u;       // (what the NEXT call's k_route cuts this class's walks into)
+    }
 
     // ---- plan the launches ---------------------------------------------------------
     struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense, window, win_table; size_t part_off; const uint32_t* lst; const DevStream* st; uint64_t sbytes; };
@@ -370,7 +401,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             d.job0 = (uint32_t)n_jobs[cc];
             walkc_off[cc] = info[TI_OFF + plan_id(cls, 0)];
             d.list = nullptr;
-            d.wave_end = (wc.n ? wc.p[wc.n - 1].wave_end : 0u) + (d.n_list + 63) / 64;
+            d.wave_end = (wc.n ? wc.p[wc.n - 1].wave_end : 0u) + walk_plan_waves(d.n_list);
             wc.n++;
             n_jobs[cc] += d.n_list;
             walkc_reads[cc] += count;
@@ -384,7 +415,7 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
             d.n_list = count;
             walk_off[cls][wp.n] = info[TI_OFF + id];
             d.list = nullptr;
-            d.wave_end = (wp.n ? wp.p[wp.n - 1].wave_end : 0u) + (count + 63) / 64;
+            d.wave_end = (wp.n ? wp.p[wp.n - 1].wave_end : 0u) + walk_plan_waves(count);
             wp.n++;
             walk_reads += count;
             continue;
@@ -538,9 +569,14 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
         if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
         for (uint32_t cls = 0; cls < 2; cls++) {
             if (!walk[cls].n) continue;
+            // (the plain classes keep the caller's order unless WEPP_WALK_SORT_PLAIN=1: their reads have at most 16
+            // events each, mostly on streams the L2s hold anyway, and a sort of 1 M reads costs 0.15 ms of a 0.3 ms step)
+            static const bool sort_plain = getenv("WEPP_WALK_SORT_PLAIN") && getenv("WEPP_WALK_SORT_PLAIN")[0] == '1';
             bool sorted = false;
-            int rc = sort_class(cls, 1 + cls, q, sorted);
-            if (rc != WEPP_OK) return rc;
+            if (sort_plain) {
+                int rc = sort_class(cls, 1 + cls, q, sorted);
+                if (rc != WEPP_OK) return rc;
+            }
             if (sorted)
                 for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = val_in + walk_off[cls][k];
             HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
@@ -661,9 +697,22 @@ extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_o
     mat->last_bytes = bytes;
     mat->acc_passes += passes;
     mat->acc_bytes += bytes;
-    mat->last_n_reads = n_reads;
-    mat->last_walk_reads = walk_reads;
+    mat->last_n_reads = plan_base + n_reads == plan_total ? plan_total : 0;   // (complete once the last sub-batch is in)
+    mat->last_walk_reads = (plan_base ? mat->last_walk_reads : 0) + walk_reads;
     return WEPP_OK;
+}
+}  // namespace
+
+extern "C" int wepp_place_batch_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                                       uint32_t n_reads, uint64_t n_read_words, uint32_t* d_best_bfs_j,
+                                       int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags,
+                                       void* hip_stream) {
+    if (!mat || !d_read_off) return set_error(WEPP_EINVAL, "null argument");
+    if (n_read_words && !d_read_word) return set_error(WEPP_EINVAL, "null read_word");
+    if (n_reads == 0) return WEPP_OK;
+    HIP_TRY(hipSetDevice(mat->device));
+    return place_device(mat, d_read_off, d_read_word, n_reads, d_best_bfs_j, d_score, d_num_best, d_flags,
+                        (hipStream_t)hip_stream, 0, n_reads);
 }
 
 extern "C" int wepp_mat_timing_reset(wepp_mat_t* mat) {
@@ -706,6 +755,22 @@ extern "C" int wepp_mat_last_timing(wepp_mat_t* mat, float* mean_sweep_ms, uint3
     return WEPP_OK;
 }
 
+namespace {
+// pinned (hipHostMalloc / hipHostRegister) host memory can be the source or the target of a DMA as it stands
+bool is_pinned_host(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+// Host buffers in, host buffers out.  A large batch runs as a PIPELINE of sub-batches (contiguous ranges of the
+// reads): the handle's host workers check the read words of sub-batch k+1 and move them into pinned staging while
+// sub-batch k's words go up on one copy stream, the kernels of k-1 run on the compute stream, the results of k-2
+// come down on a second copy stream and the workers move those of k-3 out to the caller's arrays.  Buffers the
+// caller has pinned are used as they are (no staging pass).  The results are the ones of the unsplit call: a
+// read's placement does not depend on its batch (tests/test_gpu_parity.py::test_pipeline_equals_unsplit_call).
 extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word,
                                 uint32_t n_reads, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
                                 uint32_t* flags, int32_t* per_node_scores) {
@@ -720,169 +785,240 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     // WEPP_DEBUG_TIMING=1: wall time of the call's phases to stderr
     static const bool dbg_time = getenv("WEPP_DEBUG_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
-    auto t_last = t_begin;
-    double t_phase[5] = {0, 0, 0, 0, 0};
-    auto lap = [&](int i) {
-        if (!dbg_time) return;
-        const auto now = std::chrono::steady_clock::now();
-        t_phase[i] = std::chrono::duration<double, std::milli>(now - t_last).count();
-        t_last = now;
-    };
-    uint32_t *d_off = nullptr, *d_word = nullptr, *d_out = nullptr;
-    int32_t* d_pns = nullptr;
-    int rc = WEPP_OK;
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+
     hipError_t e = hipSuccess;
-    const size_t off_bytes = (((size_t)(n_reads + 1) * 4) + 255) & ~(size_t)255;
-    {
-        // the device copies of the caller's buffers live on the handle and only grow: no hipMalloc /
-        // hipFree (and the device-wide synchronisation they imply) per call
-        const size_t in_need = off_bytes + std::max<size_t>(nw * 4, 16);
-        const size_t out_need = (size_t)n_reads * 16;
-        if (in_need > mat->io_in_bytes) {
-            if (mat->io_in) { (void)hipFree(mat->io_in); mat->io_in = nullptr; mat->io_in_bytes = 0; }
-            e = hipMalloc(&mat->io_in, in_need + in_need / 4);
-            if (e == hipSuccess) mat->io_in_bytes = in_need + in_need / 4;
+    if (!mat->pipe_compute) {
+        e = hipStreamCreateWithFlags(&mat->pipe_compute, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mat->pipe_h2d, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mat->pipe_d2h, hipStreamNonBlocking);
+        for (uint32_t i = 0; i < wepp_mat::kPipeMax && e == hipSuccess; i++) {
+            e = hipEventCreateWithFlags(&mat->pipe_up[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&mat->pipe_done[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&mat->pipe_out[i], hipEventDisableTiming);
         }
-        if (e == hipSuccess && out_need > mat->io_out_bytes) {
-            if (mat->io_out) { (void)hipFree(mat->io_out); mat->io_out = nullptr; mat->io_out_bytes = 0; }
-            e = hipMalloc(&mat->io_out, out_need + out_need / 4);
-            if (e == hipSuccess) mat->io_out_bytes = out_need + out_need / 4;
-        }
-        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-        d_off = (uint32_t*)mat->io_in;
-        d_word = (uint32_t*)((char*)mat->io_in + off_bytes);
-        d_out = (uint32_t*)mat->io_out;
-        // pinned staging (grow-only), laid out like the device buffer: offsets, then (256-byte aligned) words
-        const size_t need = std::max(in_need, out_need);
-        if (need > mat->pin_bytes) {
-            if (mat->pin) { (void)hipHostFree(mat->pin); mat->pin = nullptr; mat->pin_bytes = 0; }
-            e = hipHostMalloc(&mat->pin, need + need / 4, hipHostMallocDefault);
-            if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
-            mat->pin_bytes = need + need / 4;
-        }
+        if (e != hipSuccess) return hip_fail(e, "pipeline streams / events");
     }
-    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.
-    // Checked by the handle's host workers on large batches, each task moving its reads into the pinned staging
-    // buffer as it goes (one pass over the input instead of a check and two memcpys); the first offending read
-    // (lowest index) is reported.
+    // ---- buffers: grow-only, on the handle (no hipMalloc / hipFree per call) ----
+    const size_t off_bytes = (((size_t)(n_reads + 1) * 4) + 255) & ~(size_t)255;
+    const size_t in_need = off_bytes + std::max<size_t>(nw * 4, 16), out_need = (size_t)n_reads * 16;
+    const bool in_pinned = is_pinned_host(read_off) && (nw == 0 || is_pinned_host(read_word));
+    void* dst[4] = {best_bfs_j, score, num_best, flags};
+    bool out_pinned[4];
+    bool any_staged_out = false;
+    for (int i = 0; i < 4; i++) { out_pinned[i] = dst[i] && is_pinned_host(dst[i]); any_staged_out = any_staged_out || (dst[i] && !out_pinned[i]); }
     {
-        uint32_t* pin_off = (uint32_t*)mat->pin;
-        uint32_t* pin_word = (uint32_t*)((char*)mat->pin + off_bytes);
-        // exact, read by read: only run on a range the fast pass below found something in
-        auto check_exact = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
-            for (uint32_t r = lo; r < hi; r++) {
-                if (read_off[r + 1] < read_off[r] || read_off[r + 1] > nw) { bad = r; what = 0; return; }
-                for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
-                    if ((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu)) { bad = r; what = 1; return; }
-                for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
-                    if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0) { bad = r; what = 2; return; }
-            }
+        auto grow_dev = [&](void*& p, size_t& have, size_t need) -> hipError_t {
+            if (need <= have) return hipSuccess;
+            if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; have = 0; }
+            hipError_t r = hipMalloc(&p, need + need / 4);
+            if (r == hipSuccess) have = need + need / 4;
+            return r;
         };
-        // fast pass over a range of reads: branch-free loops the compiler vectorises.  Offsets: monotone and inside
-        // the word array.  Words: no zero mask; positions ascend from one word to the next except where a read
-        // starts -- the descents are counted over all words and over the read starts, and must be the same number.
-        auto check = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
-            uint32_t off_bad = (read_off[lo] > nw) ? 1u : 0u;
-            for (uint32_t r = lo; r < hi; r++) {
-                const uint32_t a = read_off[r], b = read_off[r + 1];
-                off_bad |= (uint32_t)(b < a) | (uint32_t)(b > nw);
-                pin_off[r] = a;
-            }
+        auto grow_pin = [&](void*& p, size_t& have, size_t need) -> hipError_t {
+            if (need <= have) return hipSuccess;
+            if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; have = 0; }
+            hipError_t r = hipHostMalloc(&p, need + need / 4, hipHostMallocDefault);
+            if (r == hipSuccess) have = need + need / 4;
+            return r;
+        };
+        e = grow_dev(mat->io_in, mat->io_in_bytes, in_need);
+        if (e == hipSuccess) e = grow_dev(mat->io_out, mat->io_out_bytes, out_need);
+        if (e == hipSuccess && !in_pinned) e = grow_pin(mat->pin, mat->pin_bytes, in_need);
+        if (e == hipSuccess && any_staged_out) e = grow_pin(mat->pin_out, mat->pin_out_bytes, out_need);
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("device / pinned buffers of the batch: ") + hipGetErrorString(e));
+    }
+    uint32_t* const d_off = (uint32_t*)mat->io_in;
+    uint32_t* const d_word = (uint32_t*)((char*)mat->io_in + off_bytes);
+    uint32_t* const d_out = (uint32_t*)mat->io_out;
+    uint32_t* const pin_off = in_pinned ? nullptr : (uint32_t*)mat->pin;
+    uint32_t* const pin_word = in_pinned ? nullptr : (uint32_t*)((char*)mat->pin + off_bytes);
+    uint32_t* const po = (uint32_t*)mat->pin_out;
+
+    // ---- sub-batches and tasks ----
+    const bool big = n_reads >= (1u << 16);
+    if (big && !mat->pool) {
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        mat->pool.reset(new HostPool(std::min<uint32_t>(15, hw > 1 ? hw - 1 : 1)));
+    }
+    static const uint32_t pipe_env = getenv("WEPP_PIPE_SUBBATCHES") ? (uint32_t)std::max(1, atoi(getenv("WEPP_PIPE_SUBBATCHES"))) : 0u;
+    const uint32_t pipe_knob = mat->pipe_sub_batches ? mat->pipe_sub_batches : pipe_env;
+    uint32_t S = !big || per_node_scores ? 1u : pipe_knob ? pipe_knob : (n_reads >= (1u << 18) ? 4u : 2u);
+    S = std::min<uint32_t>(S, wepp_mat::kPipeMax);
+    const uint32_t threads = big ? mat->pool->workers() + 1 : 1;
+    const uint32_t PS = big ? std::max(1u, (4 * threads + S - 1) / S) : 1;     // staging parts per sub-batch
+    const uint32_t PO = big ? 4 : 1;                                           // copy-out parts per (sub-batch, array)
+    auto sub_lo = [&](uint32_t k) { return (uint32_t)((uint64_t)n_reads * k / S); };
+    const uint32_t n_stage = S * PS, n_copy = any_staged_out ? S * 4 * PO : 0;
+
+    // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.  Checked by the
+    // staging tasks, each moving its reads into the pinned staging buffer as it goes (one pass over the input); the
+    // first offending read (lowest index) is reported.
+    // exact, read by read: only run on a range the fast pass below found something in
+    auto check_exact = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
+        for (uint32_t r = lo; r < hi; r++) {
+            if (read_off[r + 1] < read_off[r] || read_off[r + 1] > nw) { bad = r; what = 0; return; }
+            for (uint32_t k = read_off[r] + 1; k < read_off[r + 1]; k++)
+                if ((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu)) { bad = r; what = 1; return; }
+            for (uint32_t k = read_off[r]; k < read_off[r + 1]; k++)
+                if (((read_word[k] >> 24) & 15u) == 0 || ((read_word[k] >> 20) & 15u) == 0) { bad = r; what = 2; return; }
+        }
+    };
+    // fast pass over a range of reads: branch-free loops the compiler vectorises.  Offsets: monotone and inside
+    // the word array.  Words: no zero mask; positions ascend from one word to the next except where a read
+    // starts -- the descents are counted over all words and over the read starts, and must be the same number.
+    auto check = [&](uint32_t lo, uint32_t hi, uint32_t& bad, int& what) {
+        uint32_t off_bad = (read_off[lo] > nw) ? 1u : 0u;
+        for (uint32_t r = lo; r < hi; r++) {
+            const uint32_t a = read_off[r], b = read_off[r + 1];
+            off_bad |= (uint32_t)(b < a) | (uint32_t)(b > nw);
+        }
+        if (pin_off) {
+            std::memcpy(pin_off + lo, read_off + lo, (size_t)(hi - lo) * 4);
             if (hi == n_reads) pin_off[hi] = read_off[hi];
-            if (off_bad) { check_exact(lo, hi, bad, what); return; }
-            const uint32_t a0 = read_off[lo], b0 = read_off[hi];
-            uint32_t zero = 0, descents = 0, at_starts = 0;
+        }
+        if (off_bad) { check_exact(lo, hi, bad, what); return; }
+        const uint32_t a0 = read_off[lo], b0 = read_off[hi];
+        uint32_t zero = 0, descents = 0, at_starts = 0;
+        if (pin_word) {
             for (uint32_t k = a0; k < b0; k++) {
                 const uint32_t w = read_word[k];
                 zero |= (uint32_t)(((w >> 24) & 15u) == 0) | (uint32_t)(((w >> 20) & 15u) == 0);
                 pin_word[k] = w;
             }
-            for (uint32_t k = a0 + 1; k < b0; k++) descents += (uint32_t)((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu));
-            for (uint32_t r = lo + 1; r < hi; r++) {
-                const uint32_t s0 = read_off[r];
-                if (read_off[r + 1] > s0 && s0 > a0) at_starts += (uint32_t)((read_word[s0] & 0xFFFFFu) <= (read_word[s0 - 1] & 0xFFFFFu));
+        } else {
+            for (uint32_t k = a0; k < b0; k++) {
+                const uint32_t w = read_word[k];
+                zero |= (uint32_t)(((w >> 24) & 15u) == 0) | (uint32_t)(((w >> 20) & 15u) == 0);
             }
-            if (zero || descents != at_starts) check_exact(lo, hi, bad, what);
-        };
-        const bool big = n_reads >= (1u << 16);
-        if (big && !mat->pool) {
-            const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-            mat->pool.reset(new HostPool(std::min<uint32_t>(15, hw > 1 ? hw - 1 : 1)));
         }
-        const uint32_t nt = big ? 4 * (mat->pool->workers() + 1) : 1;
-        std::vector<uint32_t> bad(nt, 0xFFFFFFFFu);
-        std::vector<int> what(nt, 0);
-        auto task = [&](uint32_t i) {
-            check((uint32_t)((uint64_t)n_reads * i / nt), (uint32_t)((uint64_t)n_reads * (i + 1) / nt), bad[i], what[i]);
-        };
-        if (nt == 1) task(0);
-        else mat->pool->run(nt, task);
-        for (uint32_t i = 0; i < nt; i++) {
-            if (bad[i] == 0xFFFFFFFFu) continue;
-            if (what[i] == 0) return set_error(WEPP_EINVAL, "read_off not monotone");
-            if (what[i] == 1)
-                return set_error(WEPP_EINVAL, "read " + std::to_string(bad[i]) + ": entries must be sorted by position with unique positions");
-            return set_error(WEPP_EINVAL, "read " + std::to_string(bad[i]) + ": zero nucleotide mask");
+        for (uint32_t k = a0 + 1; k < b0; k++) descents += (uint32_t)((read_word[k] & 0xFFFFFu) <= (read_word[k - 1] & 0xFFFFFu));
+        for (uint32_t r = lo + 1; r < hi; r++) {
+            const uint32_t s0 = read_off[r];
+            if (read_off[r + 1] > s0 && s0 > a0) at_starts += (uint32_t)((read_word[s0] & 0xFFFFFu) <= (read_word[s0 - 1] & 0xFFFFFu));
         }
+        if (zero || descents != at_starts) check_exact(lo, hi, bad, what);
+    };
+    std::vector<uint32_t> bad(n_stage, 0xFFFFFFFFu);
+    std::vector<int> what(n_stage, 0);
+    std::vector<std::atomic<uint32_t>> staged(S);          // staging parts of a sub-batch that are done
+    std::vector<std::atomic<int>> launched(S);             // 0: not yet; 1: its D2H is enqueued (pipe_out[k] recorded); -1: never will be
+    for (uint32_t k = 0; k < S; k++) { staged[k].store(0); launched[k].store(0); }
+    std::vector<hipError_t> copy_err(std::max<uint32_t>(n_copy, 1), hipSuccess);
+    auto stage_task = [&](uint32_t t) {
+        const uint32_t k = t / PS, part = t % PS;
+        const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
+        const uint32_t a = lo + (uint32_t)((uint64_t)(hi - lo) * part / PS), b = lo + (uint32_t)((uint64_t)(hi - lo) * (part + 1) / PS);
+        if (b > a) check(a, b, bad[t], what[t]);
+        staged[k].fetch_add(1, std::memory_order_release);
+    };
+    auto copy_task = [&](uint32_t t) {          // t in [0, n_copy): (sub-batch, array, part)
+        const uint32_t k = t / (4 * PO), i = (t / PO) % 4, part = t % PO;
+        if (!dst[i] || out_pinned[i]) return;
+        int st;
+        while ((st = launched[k].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        if (st < 0) return;
+        (void)hipSetDevice(mat->device);                              // (a worker thread starts on device 0)
+        copy_err[t] = hipEventSynchronize(mat->pipe_out[k]);          // the sub-batch's four arrays have landed
+        if (copy_err[t] != hipSuccess) return;
+        const size_t lo = sub_lo(k), hi = sub_lo(k + 1);
+        const size_t a = lo + (hi - lo) * part / PO, b = lo + (hi - lo) * (part + 1) / PO;
+        std::memcpy((uint32_t*)dst[i] + a, po + (size_t)i * n_reads + a, (b - a) * 4);
+    };
+    const std::function<void(uint32_t)> task = [&](uint32_t t) { if (t < n_stage) stage_task(t); else copy_task(t - n_stage); };
+
+    // ---- the launch sequence (this thread): H2D, kernels, D2H of every sub-batch ----
+    int rc = WEPP_OK;
+    std::string rc_msg;
+    double t_launch[wepp_mat::kPipeMax] = {};
+    bool rejected = false;
+    auto launch_all = [&]() {
+        for (uint32_t k = 0; k < S; k++) {
+            while (staged[k].load(std::memory_order_acquire) < PS) std::this_thread::yield();
+            bool ok = rc == WEPP_OK && !rejected;
+            for (uint32_t t = k * PS; t < (k + 1) * PS && ok; t++) ok = bad[t] == 0xFFFFFFFFu;
+            if (!ok) {       // nothing of a rejected batch reaches a kernel, and nothing behind it is worth placing
+                rejected = true;
+                launched[k].store(-1, std::memory_order_release);
+                continue;
+            }
+            const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
+            const uint32_t w0 = read_off[lo], w1 = read_off[hi];
+            const uint32_t* src_off = in_pinned ? read_off : pin_off;
+            const uint32_t* src_word = in_pinned ? read_word : pin_word;
+            // (offset `lo` went up with the sub-batch before: the kernels of k-1 may be reading it)
+            const uint32_t o0 = k ? lo + 1 : lo;
+            hipError_t he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(hi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+            if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+            if (he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d);
+            if (he == hipSuccess) he = hipStreamWaitEvent(mat->pipe_compute, mat->pipe_up[k], 0);
+            if (he == hipSuccess) {
+                // (the offsets of a sub-batch index the whole call's word array: no rebasing)
+                const int prc = place_device(mat, d_off + lo, d_word, hi - lo, d_out + lo, (int32_t*)(d_out + n_reads) + lo,
+                                             d_out + 2 * (size_t)n_reads + lo, d_out + 3 * (size_t)n_reads + lo, mat->pipe_compute, lo, n_reads);
+                if (prc != WEPP_OK) { rc = prc; rc_msg = wepp_last_error(); launched[k].store(-1, std::memory_order_release); continue; }
+            }
+            if (he == hipSuccess) he = hipEventRecord(mat->pipe_done[k], mat->pipe_compute);
+            if (he == hipSuccess) he = hipStreamWaitEvent(mat->pipe_d2h, mat->pipe_done[k], 0);
+            for (int i = 0; i < 4 && he == hipSuccess; i++) {
+                if (!dst[i]) continue;
+                uint32_t* to = out_pinned[i] ? (uint32_t*)dst[i] : po + (size_t)i * n_reads;
+                he = hipMemcpyAsync(to + lo, d_out + (size_t)i * n_reads + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, mat->pipe_d2h);
+            }
+            if (he == hipSuccess) he = hipEventRecord(mat->pipe_out[k], mat->pipe_d2h);
+            if (he != hipSuccess) {
+                rc = hip_fail(he, "H2D / kernels / D2H of a sub-batch");
+                rc_msg = wepp_last_error();
+                launched[k].store(-1, std::memory_order_release);
+                continue;
+            }
+            launched[k].store(1, std::memory_order_release);
+            if (dbg_time) t_launch[k] = since();
+        }
+    };
+    if (big) {
+        mat->pool->start(n_stage + n_copy, task);
+        launch_all();
+        mat->pool->finish();
+    } else {
+        for (uint32_t t = 0; t < n_stage; t++) stage_task(t);
+        launch_all();
+        for (uint32_t t = 0; t < n_copy; t++) copy_task(t);
     }
-    lap(0);
-    // offsets and words in one DMA, stream-ordered before the kernels (the staging buffer is pinned: the call returns at once)
-    e = hipMemcpyAsync(d_off, mat->pin, off_bytes + nw * 4, hipMemcpyHostToDevice, nullptr);
-    if (dbg_time) (void)hipDeviceSynchronize();
-    lap(1);
-    if (e != hipSuccess) { rc = hip_fail(e, "H2D copy of the reads"); goto done; }
-    rc = wepp_place_batch_device(mat, d_off, d_word, n_reads, nw, d_out, (int32_t*)(d_out + n_reads),
-                                 d_out + 2 * (size_t)n_reads, d_out + 3 * (size_t)n_reads, nullptr);
-    if (rc != WEPP_OK) goto done;
+    // everything this call put on the handle's streams has finished before it returns -- also after an error, and
+    // when no result array was asked for (the staging buffers belong to the next call then)
+    {
+        hipError_t s1 = hipStreamSynchronize(mat->pipe_d2h), s2 = hipStreamSynchronize(mat->pipe_compute), s3 = hipStreamSynchronize(mat->pipe_h2d);
+        const hipError_t se = s1 != hipSuccess ? s1 : s2 != hipSuccess ? s2 : s3;
+        if (se != hipSuccess && rc == WEPP_OK) { rc = hip_fail(se, "placement kernels / copies"); rc_msg = wepp_last_error(); }
+    }
+    for (uint32_t t = 0; t < n_stage; t++) {
+        if (bad[t] == 0xFFFFFFFFu) continue;
+        if (what[t] == 0) return set_error(WEPP_EINVAL, "read_off not monotone");
+        if (what[t] == 1)
+            return set_error(WEPP_EINVAL, "read " + std::to_string(bad[t]) + ": entries must be sorted by position with unique positions");
+        return set_error(WEPP_EINVAL, "read " + std::to_string(bad[t]) + ": zero nucleotide mask");
+    }
+    if (rc != WEPP_OK) return set_error(rc, rc_msg);
+    for (uint32_t t = 0; t < n_copy; t++)
+        if (copy_err[t] != hipSuccess) return hip_fail(copy_err[t], "D2H copy of the results");
     if (per_node_scores) {
+        int32_t* d_pns = nullptr;
         const size_t nb = (size_t)n_reads * mat->dev.N * sizeof(int32_t);
         e = hipMalloc((void**)&d_pns, nb);
-        if (e != hipSuccess) { rc = set_error(WEPP_ENOMEM, std::string("hipMalloc per_node_scores: ") + hipGetErrorString(e)); goto done; }
+        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc per_node_scores: ") + hipGetErrorString(e));
         e = launch_scores(mat->dev, mat->streams.back(), d_off, d_word, n_reads, d_pns, nullptr);
         if (e == hipSuccess) e = hipMemcpy(per_node_scores, d_pns, nb, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { rc = hip_fail(e, "per-node score kernel"); goto done; }
+        (void)hipFree(d_pns);
+        if (e != hipSuccess) return hip_fail(e, "per-node score kernel");
     }
-    if (dbg_time) { (void)hipDeviceSynchronize(); lap(2); }
-    {
-        // the four result arrays come back one after the other; an array is moved out to the caller's buffer (four
-        // tasks, a quarter each) while the next one is still on the bus
-        uint32_t* po = (uint32_t*)mat->pin;
-        void* dst[4] = {best_bfs_j, score, num_best, flags};
-        const bool pooled = n_reads >= (1u << 16) && mat->pool;
-        for (int i = 0; i < 4 && e == hipSuccess; i++) {
-            if (!dst[i]) continue;
-            if (!mat->out_ev[i]) e = hipEventCreateWithFlags(&mat->out_ev[i], hipEventDisableTiming);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(po + (size_t)i * n_reads, d_out + (size_t)i * n_reads, (size_t)n_reads * 4, hipMemcpyDeviceToHost, nullptr);
-            if (e == hipSuccess) e = hipEventRecord(mat->out_ev[i], nullptr);
-        }
-        if (e != hipSuccess) { (void)hipDeviceSynchronize(); rc = hip_fail(e, "placement kernels / D2H copy of the results"); goto done; }
-        constexpr uint32_t PARTS = 4, NT = 4 * PARTS;       // an array moves out in four parts
-        hipError_t task_err[NT];
-        for (uint32_t t = 0; t < NT; t++) task_err[t] = hipSuccess;
-        auto move = [&](uint32_t t) {
-            const int i = (int)(t / PARTS);
-            if (!dst[i]) return;
-            (void)hipSetDevice(mat->device);                              // (a worker thread starts on device 0)
-            task_err[t] = hipEventSynchronize(mat->out_ev[i]);             // synchronises with the kernels
-            if (task_err[t] != hipSuccess) return;
-            const size_t lo = (size_t)n_reads * (t % PARTS) / PARTS, hi = (size_t)n_reads * (t % PARTS + 1) / PARTS;
-            std::memcpy((uint32_t*)dst[i] + lo, po + (size_t)i * n_reads + lo, (hi - lo) * 4);
-        };
-        if (pooled) mat->pool->run(NT, move);
-        else for (uint32_t t = 0; t < NT; t++) move(t);
-        for (uint32_t t = 0; t < NT; t++)
-            if (task_err[t] != hipSuccess) { rc = hip_fail(task_err[t], "placement kernels / D2H copy of the results"); goto done; }
+    if (dbg_time) {
+        fprintf(stderr, "[place_batch] %u reads in %u sub-batches (%s in, %s out): D2H of sub-batch k enqueued at", n_reads, S,
+                in_pinned ? "caller-pinned" : "staged", any_staged_out ? "staged" : "caller-pinned");
+        for (uint32_t k = 0; k < S; k++) fprintf(stderr, " %.3f", t_launch[k]);
+        fprintf(stderr, " ms; total %.3f ms\n", since());
     }
-    lap(3);
-    lap(4);
-    if (dbg_time)
-        fprintf(stderr, "[place_batch] %u reads: check+stage %.3f  H2D %.3f  kernels %.3f  D2H+copy-out %.3f  total %.3f ms (H2D and kernels synchronised for this print)\n",
-                n_reads, t_phase[0], t_phase[1], t_phase[2], t_phase[3],
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-done:
-    if (d_pns) (void)hipFree(d_pns);
-    return rc;
+    return WEPP_OK;
 }
 
 namespace {
@@ -1061,11 +1197,11 @@ extern "C" int wepp_excess_mutations(wepp_mat_t* mat, const uint32_t* read_off, 
 // diagnostic: the sweep stream every read of the handle's most recent placement call was routed to
 extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_reads) {
     if (!mat || !tiers) return set_error(WEPP_EINVAL, "null argument");
-    if (n_reads != mat->last_n_reads || !mat->ws)
+    if (n_reads != mat->last_n_reads || !mat->d_plan_of)
         return set_error(WEPP_EINVAL, "n_reads differs from the handle's last placement call");
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(tiers, mat->ws, n_reads, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tiers, mat->d_plan_of, n_reads, hipMemcpyDeviceToHost));
     for (uint32_t r = 0; r < n_reads; r++)       // the workspace holds plan ids (device_mat.hpp: plan_id)
         tiers[r] = plan_class(tiers[r]) == PLAN_WIN ? (uint8_t)(mat->dev.n_streams - 1) : (uint8_t)plan_index(tiers[r]);
     return WEPP_OK;
@@ -1074,11 +1210,11 @@ extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_r
 // diagnostic: the full plan id (class and stream) of every read of the handle's most recent placement call
 extern "C" int wepp_mat_last_plans(wepp_mat_t* mat, uint8_t* plan_class_out, uint8_t* plan_stream_out, uint32_t n_reads) {
     if (!mat || !plan_class_out || !plan_stream_out) return set_error(WEPP_EINVAL, "null argument");
-    if (n_reads != mat->last_n_reads || !mat->ws)
+    if (n_reads != mat->last_n_reads || !mat->d_plan_of)
         return set_error(WEPP_EINVAL, "n_reads differs from the handle's last placement call");
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(plan_stream_out, mat->ws, n_reads, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(plan_stream_out, mat->d_plan_of, n_reads, hipMemcpyDeviceToHost));
     for (uint32_t r = 0; r < n_reads; r++) {
         const uint32_t id = plan_stream_out[r];
         plan_class_out[r] = (uint8_t)plan_class(id);

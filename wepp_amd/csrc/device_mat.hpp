@@ -93,6 +93,11 @@ __host__ __device__ inline uint32_t plan_index(uint32_t id) { return id >= PLAN_
 // a job finds the state of a sequential walk at its first node by binary searches in the read's lists and
 // the chains of enclosing entries (ix_up) -- whose (score, rank, count) partials k_finalize_jobs combines.
 constexpr uint32_t WALK_JOB_EVENTS = 32;
+// ... by default; a handle follows its traffic: the events per job of a chunked class in the NEXT call are the class's
+// events in this call over WALK_TARGET_JOBS, within [WALK_JOB_EVENTS, WALK_JOB_EVENTS_MAX] -- few long chains when a
+// class holds a few thousand reads (the default batch), long jobs, whose start state (a third of a short job's
+// cycles and bytes) is amortised, when it holds 10^8 events (N-rich batches).  Speed only: results never depend on it.
+constexpr uint32_t WALK_JOB_EVENTS_MAX = 256, WALK_TARGET_JOBS = 1u << 20;
 // most stack rows a walk workgroup gets (<= WALK8_STACK / WALK16_STACK, what the kernels take; WEPP_WALK_STACK8 /
 // WEPP_WALK_STACK16 lower them): a read that could hold more intervals open at once (sum of ix_nest over its
 // positions) is left to the sweeps.  A launch asks LDS for the deepest stack its reads can need (k_route's maximum
@@ -101,6 +106,10 @@ constexpr uint32_t WALK_JOB_EVENTS = 32;
 // class) 21.5 -> 19.9 ms, nothing on the other legs: the walks are not short of waves.
 constexpr uint32_t WALK_WAVES = 2;         // waves per workgroup of k_walk (their LDS regions are private)
 constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of a launch runs on XCD b % 8
+// waves of a walk plan are padded to a multiple of this, so that every plan starts at a workgroup index that is a
+// multiple of the XCD count and its waves can be dealt to the XCDs in contiguous runs (k_walk)
+constexpr uint32_t WALK_PLAN_ALIGN = WALK_XCDS * WALK_WAVES;
+inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
@@ -260,6 +269,7 @@ hipError_t sweep_set_max_lds(uint32_t bytes);
 // then, per chunked class and stream, the jobs of its chunked walks
 constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
                    TI_OPEN = TI_JOBS + 2 * MAX_STREAMS,      // [4] deepest stack of the walk classes (WALK8, WALK16, WALKC8, WALKC16)
-                   TI_WORDS = TI_OPEN + 4;
+                   TI_EVENTS = TI_OPEN + 4,                  // [2] events (in units of 64) of the reads of the two chunked classes
+                   TI_WORDS = TI_EVENTS + 2;
 
 }  // namespace wepp

@@ -23,6 +23,7 @@ struct wepp_mat {
     std::vector<DevStream> streams;
     std::vector<DevWalk> walks;       // position index + range-query structures of every stream (k_walk)
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
+    uint32_t job_events[2] = {WALK_JOB_EVENTS, WALK_JOB_EVENTS};   // events per job of the chunked classes in the next call
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
     unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset
     std::vector<uint64_t> stream_bytes;
@@ -54,7 +55,18 @@ struct wepp_mat {
     void* pin = nullptr;              // pinned staging of the same (pageable caller buffers go through it)
     size_t pin_bytes = 0;
     std::unique_ptr<HostPool> pool;   // host workers of wepp_place_batch (started by the first large batch)
-    hipEvent_t out_ev[4] = {};        // one per result array: its D2H copy has landed in the staging buffer
+    // wepp_place_batch as a pipeline: sub-batch k's reads go up on pipe_h2d while the kernels of k-1 run on
+    // pipe_compute and the results of k-2 come down on pipe_d2h; one event per sub-batch and stage
+    static constexpr uint32_t kPipeMax = 8;
+    uint32_t pipe_sub_batches = 0;    // 0: chosen per call (4 from 262 144 reads, 2 from 65 536, else 1)
+    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_compute = nullptr;
+    hipEvent_t pipe_up[kPipeMax] = {}, pipe_done[kPipeMax] = {}, pipe_out[kPipeMax] = {};
+    void* pin_out = nullptr;          // pinned staging of the results (the reads' staging is `pin`)
+    size_t pin_out_bytes = 0;
+    // plan id of every read of the most recent placement call (k_route writes it; wepp_mat_last_tiers / _plans read it);
+    // grow-only, outside the workspace so that the sub-batches of one host call add up to the whole call's picture
+    uint8_t* d_plan_of = nullptr;
+    size_t plan_of_bytes = 0;
     // grow-only workspace: tier of each read, read list, routing counters, partial results
     void* ws = nullptr;
     size_t ws_bytes = 0;

@@ -36,6 +36,13 @@ class HostPool {
     // reference the caller's locals, which must outlive them), and run() rethrows it on the calling thread.
     void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
         if (n == 0) return;
+        start(n, fn);
+        finish();
+    }
+    // The same in two halves: start() hands the tasks to the workers and returns; the caller does something else (the
+    // GPU launches of a pipelined wepp_place_batch) and then calls finish(), which works along on what is left and
+    // waits for the rest.  Tasks are taken in ascending order of i.  `fn` must stay alive until finish() returns.
+    void start(uint32_t n, const std::function<void(uint32_t)>& fn) {
         {
             // (a worker that woke up late for the previous round may still be looking at its counters)
             std::unique_lock<std::mutex> lk(m_);
@@ -48,6 +55,8 @@ class HostPool {
             gen_++;
         }
         cv_.notify_all();
+    }
+    void finish() {
         const uint32_t mine = work();
         std::exception_ptr err;
         {

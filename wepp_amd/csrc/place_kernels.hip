@@ -202,12 +202,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           uint32_t* __restrict__ tier_info,
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next) {
-    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4];
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
     if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
     if (threadIdx.x < 4) open_of[threadIdx.x] = 0;
+    if (threadIdx.x < 2) events_of[threadIdx.x] = 0;
     if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
@@ -276,8 +277,10 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 // many events: jobs of about `job_events`, cut at quantiles of the longest list
                 const uint32_t small = (k <= WALK8_K && open_max <= stack8) ? 1u : 0u;
                 cls = small ? PLAN_WALKC8 : PLAN_WALKC16;
-                const uint32_t nj = min((events + job_events - 1) / job_events, longest);
+                const uint32_t je = small ? (job_events & 0xFFFFu) : (job_events >> 16);   // (per class, capi.cpp)
+                const uint32_t nj = min((events + je - 1) / je, longest);
                 job_n[r] = nj;
+                atomicAdd(&events_of[small ? 0 : 1], events);
                 atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
                 atomicMax(&open_of[small ? 2 : 3], open_max);
             }
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     }
     if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
     if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
+    if (threadIdx.x < 2 && events_of[threadIdx.x]) atomicAdd(&tier_info[TI_EVENTS + threadIdx.x], (events_of[threadIdx.x] + 63) >> 6);
 }
 
 // -----------------------------------------------------------------------------
@@ -1310,17 +1314,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     uint32_t* stk = cur_l + KW * 64;
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
     auto sword = [&](int j) -> uint32_t { return ((S16[(j >> 1) * 64 + lane] >> ((j & 1) * 16)) & 0x1FFu) << 20; };
-    // Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8), each with its own L2:
-    // XCD x takes the x-th CONTIGUOUS eighth of the launch's waves, so that the waves resident on one XCD hold
-    // neighbouring reads of the position-sorted list -- the same few amplicons' lists of the index
-    uint32_t unit;
-    {
-        const uint32_t g = gridDim.x, b = blockIdx.x, per = g / WALK_XCDS, rem = g % WALK_XCDS;
-        const uint32_t x = b % WALK_XCDS, i = b / WALK_XCDS;      // XCD x's i-th workgroup
-        // (the first `rem` XCDs hold one workgroup more)
-        const uint32_t wg = x * per + min(x, rem) + i;
-        unit = wg * WALK_WAVES + wv;
-    }
+    const uint32_t unit = blockIdx.x * WALK_WAVES + wv;
     if (unit >= pl.p[pl.n - 1].wave_end) return;
 #ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
     unsigned long long ts_[6];
@@ -1336,7 +1330,17 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     uint32_t pi = 0;
     while (pi + 1 < pl.n && unit >= pl.p[pi].wave_end) pi++;
     const WalkPlanDev& q = pl.p[pi];
-    const uint32_t tile = unit - (pi ? pl.p[pi - 1].wave_end : 0u);
+    // Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8), each with its own L2.  A
+    // plan's waves start at a workgroup index that is a multiple of 8 and their number is a multiple of 16
+    // (walk_plan_waves), so the plan's workgroup i is on XCD i % 8: XCD x takes the x-th CONTIGUOUS eighth of the
+    // plan's tiles -- neighbouring reads of the position-sorted list, i.e. the same few amplicons' lists of the index.
+    // (Per plan, not per launch: the plans of a launch differ in cost per read by orders of magnitude.)
+    uint32_t tile;
+    {
+        const uint32_t first = pi ? pl.p[pi - 1].wave_end : 0u;
+        const uint32_t wgs = (q.wave_end - first) / WALK_WAVES, wg = (unit - first) / WALK_WAVES;
+        tile = ((wg % WALK_XCDS) * (wgs / WALK_XCDS) + wg / WALK_XCDS) * WALK_WAVES + wv;
+    }
     const DevWalk ix = m.walks[q.tier];
     const uint32_t slot = tile * 64 + lane;
     const bool have = slot < q.n_list;
