@@ -155,6 +155,19 @@ int wepp_imputed_mutations(wepp_mat_t *mat, const uint32_t *read_off, const uint
                            uint32_t n_reads, const uint32_t *best_bfs_j, uint32_t *imp_off,
                            int32_t *imp_pos, uint8_t *imp_nuc, uint64_t capacity);
 
+/* best_j_vec: the BFS indices of ALL optimal nodes of every read -- what pass 1 collects for pass 2
+ * (src/usher_common.cpp:376-381, filled at src/usher_mapper.cpp:475-476,497; pass 2 loops over it at
+ * src/usher_common.cpp:413-446).  `score` / `num_best` are the outputs of wepp_place_batch for the same reads on
+ * this handle; best_off[n_reads + 1] receives the CSR over the reads (best_off[r + 1] - best_off[r] = num_best[r]),
+ * best_nodes[best_off[r] .. best_off[r + 1]) the optimal nodes of read r in ascending BFS index (the reference's
+ * vector is unordered).  capacity = size of best_nodes; WEPP_ELIMIT (best_off filled: best_off[n_reads] is the
+ * needed size) when it is too small; WEPP_EINVAL when score / num_best are not this read's placement.
+ * Cost: every node of a read's own stream (the crown its bound admits, wepp_mat_stats::stream_nodes) is evaluated
+ * once -- a second pass for batches of samples, not for every read of a sequencing run. */
+int wepp_best_nodes(wepp_mat_t *mat, const uint32_t *read_off, const uint32_t *read_word, uint32_t n_reads,
+                    const int32_t *score, const uint32_t *num_best, uint64_t *best_off, uint32_t *best_nodes,
+                    uint64_t capacity);
+
 /* ---- excess mutations of (sample, node) pairs --------------------------------------- *
  * node_excess_mutations[j] as mapper2_body appends it with compute_vecs for sample
  * pair_read[i] at the node with BFS index pair_bfs_j[i]: first the node's own mutations the
@@ -368,6 +381,12 @@ typedef struct {
 } wepp_epp_out;
 int wepp_epp_map(wepp_mat_t *mat, const wepp_epp_reads *reads, uint32_t genome_size, uint32_t max_cached_epp,
                  wepp_epp_out *out);
+/* The size of the EPP lists is only known once the map has run (the sum of the multiplicities <= max_cached_epp).
+ * When epp_nodes is too small (epp_capacity < epp_off[n_reads]; epp_capacity = 0 with epp_nodes = NULL asks for
+ * exactly that) wepp_epp_map still delivers EVERY other output, keeps the lists on the handle and returns
+ * WEPP_ELIMIT; the caller sizes its buffer from epp_off[n_reads] and collects them here -- the map never runs twice.
+ * The pending lists belong to the handle's most recent wepp_epp_map and are dropped by the fetch. */
+int wepp_epp_fetch_lists(wepp_mat_t *mat, uint32_t *epp_nodes, uint64_t capacity);
 /* caller node id of the haplotype with arena (pre-order) index k, for k = 0 .. n_nodes-1 */
 int wepp_mat_dfs_order(const wepp_mat_t *mat, uint32_t *ids);
 /* device time of the calling thread's last wepp_epp_map, by phase (HIP events), and its work:

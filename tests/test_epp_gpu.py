@@ -39,6 +39,26 @@ def test_fuzz_small_trees(oracle, rpl, monkeypatch):
         mat.close()
 
 
+def test_short_list_buffer_is_fetched_not_recomputed(oracle):
+    """wepp_epp_map with too small an epp_nodes buffer (or none: the capacity query) still delivers every other
+    output, reports WEPP_ELIMIT with epp_off filled, and the lists come from wepp_epp_fetch_lists -- equal to a call
+    whose buffer was large enough; a second fetch has nothing left."""
+    import ctypes
+    rng = np.random.default_rng(4242)
+    genome = 60
+    tree, ref = ft.random_tree(rng, genome=genome, n_nodes=60)
+    reads = epp_fuzz.random_epp_reads(rng, tree, ref, genome, n_reads=300)
+    mat = w.Mat(tree)
+    full = mat.epp_map(reads, genome)
+    assert len(full["epp_nodes"]) > 8
+    for cap in (0, 1, len(full["epp_nodes"]) - 1):
+        got = mat.epp_map(reads, genome, epp_capacity=cap)          # (the binding fetches on WEPP_ELIMIT)
+        _check(got, full, reads.n_reads, cap)
+    rc = w._lib.lib.wepp_epp_fetch_lists(mat._h, None, 0)
+    assert rc == 1 and "no EPP lists are pending" in w._lib.lib.wepp_last_error().decode()
+    mat.close()
+
+
 def test_edge_cases(oracle):
     # single-node tree, reads with no mutations, all-N reads, a window of one base, degree 0
     tree = w.Tree.from_lists([-1], [[]])

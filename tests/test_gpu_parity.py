@@ -640,6 +640,56 @@ def test_two_handles_two_host_threads(oracle):
     assert not errs, errs
 
 
+def test_best_nodes_vs_oracle(oracle):
+    """best_j_vec (usher_common.cpp:376-381, filled at usher_mapper.cpp:475-476,497): the BFS indices of all optimal
+    nodes of a sample, against the oracle's vector -- every (tree, sample) pair of the fuzz trees, then 1 000 reads
+    on a 100 K-node tree (reads of every routed stream, short and 1.2 kb) with work skipping on and off."""
+    rng = np.random.default_rng(808)
+    n_nodes = 0
+    for it in range(30):
+        tree, ref = ft.random_tree(rng)
+        samples = [ft.random_sample(rng, ref) for _ in range(8)]
+        reads = ft.reads_from_samples(samples)
+        mat = w.Mat(tree)
+        ot = oracle.OracleTree(tree)
+        res = mat.place_batch(reads)
+        got = mat.best_nodes(reads, res)
+        for q, S in enumerate(samples):
+            cols = list(zip(*S)) if S else ([], [], [], [])
+            want = ot.place_sample(*cols, want_best_vec=True)
+            assert got[q].tolist() == want["best_j_vec"].tolist(), (it, q)
+            assert res.best_bfs_j[q] in got[q]
+            n_nodes += len(got[q])
+        mat.close()
+    assert n_nodes > 300
+    g = w.generate_tree(71, 100_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
+    short = g.reads(72, 900, p_substitution=0.004, p_n=0.02, p_iupac=0.1)
+    long_ = g.reads(73, 100, read_len=1200, amplicon_len=1200, amplicon_step=1020, p_substitution=0.03, p_n=0.02)
+    reads = Reads(np.concatenate([short.read_off, long_.read_off[1:] + short.read_off[-1]]),
+                  np.concatenate([short.read_word, long_.read_word]))
+    mat = w.Mat(g.tree)
+    inc = oracle.OracleTree(g.tree).incremental()
+    res = mat.place_batch(reads)
+    assert len(np.unique(mat.last_tiers(reads.n_reads))) >= 4
+    for crowns in (True, False):
+        mat.set_use_crowns(crowns)
+        got = mat.best_nodes(reads, res)
+        for q in range(reads.n_reads):
+            want = inc.place_sample(*reads.entries(q), want_best_vec=True)
+            assert got[q].tolist() == want["best_j_vec"].tolist(), (crowns, q)
+    # a score that is not the read's: reported, not listed
+    wrong = w.PlacementResult(res.best_bfs_j, res.score + 1, res.num_best, res.flags)
+    with pytest.raises(w.WeppError, match="not this read's placement"):
+        mat.best_nodes(reads, wrong)
+    # capacity: WEPP_ELIMIT with the needed size
+    off = np.zeros(reads.n_reads + 1, np.uint64)
+    small = np.zeros(1, np.uint32)
+    rc = w._lib.lib.wepp_best_nodes(mat._h, reads.read_off.ctypes.data, reads.read_word.ctypes.data, reads.n_reads,
+                                    res.score.ctypes.data, res.num_best.ctypes.data, off.ctypes.data, small.ctypes.data, 1)
+    assert rc == 4 and int(off[-1]) == int(res.num_best.sum())
+    mat.close()
+
+
 @pytest.mark.gpu
 def test_excess_mutations_vs_oracle(oracle):
     """node_excess_mutations (usher_mapper.cpp:223-228, :253-258, :357-388, :394-446 with

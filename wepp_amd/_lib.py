@@ -114,6 +114,7 @@ _SIGS = {
     "wepp_mat_bfs_order": (ctypes.c_int, [_V, _V]),
     "wepp_place_batch": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, _V, _V, _V, _V, _V]),
     "wepp_imputed_mutations": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, _V, _V, _V, _V, ctypes.c_uint64]),
+    "wepp_best_nodes": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, _V, _V, _V, _V, ctypes.c_uint64]),
     "wepp_excess_mutations": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32, ctypes.c_uint32, _V, _V, _V, _V, _V, _V, _V,
                                              ctypes.c_uint64]),
     "wepp_place_batch_device": (
@@ -142,6 +143,7 @@ _SIGS = {
     "wepp_fitch_last_timing": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)] * 4),
     "wepp_epp_map": (ctypes.c_int, [_V, ctypes.POINTER(EppReadsC), ctypes.c_uint32, ctypes.c_uint32,
                                     ctypes.POINTER(EppOutC)]),
+    "wepp_epp_fetch_lists": (ctypes.c_int, [_V, _V, ctypes.c_uint64]),
     "wepp_mat_dfs_order": (ctypes.c_int, [_V, _V]),
     "wepp_epp_last_timing": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)] * 4 + [
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),

@@ -399,6 +399,18 @@ class Mat:
             res.per_node_scores = pns
         return res
 
+    def best_nodes(self, reads, res):
+        """wepp_best_nodes: best_j_vec of every read (BFS indices of all optimal nodes, ascending) as a list of
+        arrays; res = the PlacementResult of place_batch for the same reads."""
+        n = reads.n_reads
+        off = np.zeros(n + 1, np.uint64)
+        cap = int(res.num_best.astype(np.uint64).sum())
+        nodes = np.zeros(max(cap, 1), np.uint32)
+        rw = reads.read_word if reads.read_word.size else np.zeros(1, np.uint32)
+        check(lib.wepp_best_nodes(self._h, _ptr(reads.read_off), _ptr(rw), n, _ptr(np.ascontiguousarray(res.score, np.int32)),
+                                  _ptr(np.ascontiguousarray(res.num_best, np.uint32)), _ptr(off), _ptr(nodes), cap))
+        return [nodes[int(off[r]):int(off[r + 1])] for r in range(n)]
+
     def excess_mutations(self, reads, pair_read, pair_bfs_j):
         """wepp_excess_mutations: per (read, node) pair the list of (position, ref, par, mut)."""
         pr = np.ascontiguousarray(pair_read, np.uint32); pj = np.ascontiguousarray(pair_bfs_j, np.uint32)
@@ -443,7 +455,13 @@ class Mat:
         o = _lib.EppOutC(_ptr(mp).value, _ptr(mult).value, _ptr(eoff).value if want_lists else None,
                          _ptr(enodes).value if want_lists else None, cap, _ptr(score).value,
                          _ptr(counts).value if want_counts else None, _ptr(div).value if want_divergence else None)
-        check(lib.wepp_epp_map(self._h, ctypes.byref(rd), int(genome_size), int(max_cached_epp), ctypes.byref(o)))
+        rc = lib.wepp_epp_map(self._h, ctypes.byref(rd), int(genome_size), int(max_cached_epp), ctypes.byref(o))
+        if rc == 4 and want_lists and int(eoff[R]) > cap:
+            # the guess was short: everything else is complete, the lists wait on the handle (wepp_epp_fetch_lists)
+            enodes = np.zeros(int(eoff[R]), np.uint32)
+            check(lib.wepp_epp_fetch_lists(self._h, _ptr(enodes), int(eoff[R])))
+        else:
+            check(rc)
         out = dict(max_parsimony=mp[:R], multiplicity=mult[:R], score=score, counts=counts, divergence=div)
         if want_lists:
             out["epp_off"] = eoff

@@ -1194,6 +1194,91 @@ extern "C" int wepp_excess_mutations(wepp_mat_t* mat, const uint32_t* read_off, 
     return WEPP_OK;
 }
 
+// best_j_vec: every optimal node of every read (usher_common.cpp:376-381, 413-446)
+extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const uint32_t* read_word, uint32_t n_reads,
+                               const int32_t* score, const uint32_t* num_best, uint64_t* best_off, uint32_t* best_nodes,
+                               uint64_t capacity) {
+    if (!mat || !read_off || !score || !num_best || !best_off) return set_error(WEPP_EINVAL, "null argument");
+    {
+        int rc = check_read_csr(read_off, read_word, n_reads);
+        if (rc != WEPP_OK) return rc;
+    }
+    best_off[0] = 0;
+    for (uint32_t r = 0; r < n_reads; r++) best_off[r + 1] = best_off[r] + num_best[r];
+    const uint64_t total = best_off[n_reads];
+    if (total > capacity) return set_error(WEPP_ELIMIT, "best-node list too small: need " + std::to_string(total));
+    if (n_reads == 0 || total == 0) return WEPP_OK;
+    if (!best_nodes) return set_error(WEPP_EINVAL, "null argument");
+    if (total >= (1ull << 32)) return set_error(WEPP_ELIMIT, "more than 2^32 optimal nodes in one call; split the batch");
+    const uint64_t nw = read_off[n_reads];
+    HIP_TRY(hipSetDevice(mat->device));
+    // device buffers (grow-only io_in): offsets | words | scores | CSR offsets | cursors | routing arrays | the list
+    const size_t b_off = pad256((size_t)(n_reads + 1) * 4), b_word = pad256(std::max<size_t>(nw * 4, 16));
+    const size_t b_r = pad256((size_t)n_reads * 4), b_o64 = pad256((size_t)(n_reads + 1) * 8), b_r1 = pad256(n_reads);
+    const size_t up = b_off + b_word + b_r + b_o64;                       // uploaded in one staged copy
+    const size_t fixed = up + b_r /* cursors */ + b_r1 /* plan ids */ + 4 * b_r /* list, root score, slot, jobs */;
+    {
+        int rc = reserve_io(mat, fixed + pad256(total * 4), std::max(up, (size_t)total * 4));
+        if (rc != WEPP_OK) return rc;
+    }
+    char* hp = (char*)mat->pin;
+    std::memcpy(hp, read_off, (size_t)(n_reads + 1) * 4);
+    if (nw) std::memcpy(hp + b_off, read_word, nw * 4);
+    std::memcpy(hp + b_off + b_word, score, (size_t)n_reads * 4);
+    std::memcpy(hp + b_off + b_word + b_r, best_off, (size_t)(n_reads + 1) * 8);
+    char* dp = (char*)mat->io_in;
+    HIP_TRY(hipMemcpy(dp, hp, up, hipMemcpyHostToDevice));
+    const uint32_t *d_off = (const uint32_t*)dp, *d_word = (const uint32_t*)(dp + b_off);
+    const int32_t* d_best = (const int32_t*)(dp + b_off + b_word);
+    const unsigned long long* d_o64 = (const unsigned long long*)(dp + b_off + b_word + b_r);
+    char* q = dp + up;
+    uint32_t* d_cursor = (uint32_t*)q; q += b_r;
+    uint8_t* d_plan = (uint8_t*)q; q += b_r1;
+    uint32_t* d_list = (uint32_t*)q; q += b_r;
+    int32_t* d_root = (int32_t*)q; q += b_r;
+    uint32_t* d_slot = (uint32_t*)q; q += b_r;
+    uint32_t* d_jobs = (uint32_t*)q; q += b_r;
+    uint32_t* d_nodes = (uint32_t*)q;
+    HIP_TRY(hipMemsetAsync(d_cursor, 0, (size_t)n_reads * 4, nullptr));
+    // the stream of every read: the routing of a placement call with the walks and the window streams off (a
+    // window stream folds runs of nodes into pseudo-nodes: nothing to list there)
+    DevMAT dm = mat->dev;
+    dm.n_windows = 0;
+    uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
+    uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
+    uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
+    HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
+                         d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, nullptr));
+    mat->info_idx ^= 1u;
+    HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
+    HIP_TRY(hipMemcpy(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t* info = mat->h_info;
+    for (uint32_t id = 0; id < MAX_PLANS; id++) {
+        const uint32_t count = info[TI_COUNT + id];
+        if (!count) continue;
+        if (plan_class(id) != PLAN_SWEEP || plan_index(id) >= mat->streams.size())
+            return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+        HIP_TRY(launch_best_nodes(mat->dev, mat->streams[plan_index(id)], d_off, d_word, d_list + info[TI_OFF + id], count, d_best,
+                                  d_o64, d_cursor, d_nodes, nullptr));
+    }
+    {
+        hipError_t e = hipMemcpy(hp, d_nodes, total * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "best-node kernel");
+        std::vector<uint32_t> taken(n_reads);
+        e = hipMemcpy(taken.data(), d_cursor, (size_t)n_reads * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "best-node kernel");
+        for (uint32_t r = 0; r < n_reads; r++)
+            if (taken[r] != num_best[r])
+                return set_error(WEPP_EINVAL, "read " + std::to_string(r) + ": score / num_best are not this read's placement on this tree (" +
+                                              std::to_string(taken[r]) + " nodes attain the score, num_best says " + std::to_string(num_best[r]) + ")");
+    }
+    std::memcpy(best_nodes, hp, total * 4);
+    // (the kernel fills a read's slice in the order its waves get there: ascending BFS index is the contract)
+    for (uint32_t r = 0; r < n_reads; r++)
+        if (num_best[r] > 1) std::sort(best_nodes + best_off[r], best_nodes + best_off[r + 1]);
+    return WEPP_OK;
+}
+
 // diagnostic: the sweep stream every read of the handle's most recent placement call was routed to
 extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_reads) {
     if (!mat || !tiers) return set_error(WEPP_EINVAL, "null argument");

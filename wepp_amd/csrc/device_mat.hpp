@@ -254,6 +254,9 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
                            int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
 hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t* d_read_off,
                          const uint32_t* d_read_word, uint32_t n_reads, int32_t* d_out, hipStream_t stream);
+hipError_t launch_best_nodes(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                             const uint32_t* list, uint32_t n_list, const int32_t* d_best, const unsigned long long* d_off,
+                             uint32_t* d_cursor, uint32_t* d_nodes, hipStream_t stream);
 // one thread per (read, ambiguous entry) pair listed in `pairs` (read index, word index)
 hipError_t launch_imputed(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word,
                           const uint32_t* d_best_bfs_j, const uint32_t* d_pairs, uint32_t n_pairs,

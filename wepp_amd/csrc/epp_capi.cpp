@@ -304,15 +304,18 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     // EPP lists of the reads with few enough placements (initial_filter.cpp:205-210)
     std::vector<uint64_t> epp_base(R, ~0ull);
     uint64_t epp_total = 0;
+    bool lists_overflow = false;
     if (out->epp_off) {
         out->epp_off[0] = 0;
         for (uint32_t r = 0; r < R; r++) {
             if (out->multiplicity[r] <= max_cached_epp) { epp_base[r] = epp_total; epp_total += out->multiplicity[r]; }
             out->epp_off[r + 1] = epp_total;
         }
-        if (epp_total > out->epp_capacity)
-            return set_error(WEPP_ELIMIT, "epp_nodes holds " + std::to_string(out->epp_capacity) + " entries, " + std::to_string(epp_total) + " needed");
+        // too small a list buffer does not stop the call: everything else is computed and delivered, the lists stay
+        // with the handle for wepp_epp_fetch_lists, and the call reports WEPP_ELIMIT at its end
+        lists_overflow = epp_total > out->epp_capacity || (epp_total && !out->epp_nodes);
     }
+    mat->epp_pending.clear();
 
     // ---- pass 2 ----------------------------------------------------------------------------
     const bool want_cnt = out->hap_read_counts || out->hap_divergence;
@@ -355,7 +358,12 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     HIP_TRY(d2h_staged(out->hap_score, d_score, (size_t)N * 8, stream));
     if (d_counts) HIP_TRY(d2h_staged(out->hap_read_counts, d_counts, (size_t)N * EPP_BINS * 4, stream));
     if (d_div) HIP_TRY(d2h_staged(out->hap_divergence, d_div, (size_t)N * 8, stream));
-    if (epp_total) HIP_TRY(d2h_staged(out->epp_nodes, d_enodes, epp_total * 4, stream));
+    if (epp_total && lists_overflow) {
+        try { mat->epp_pending.resize(epp_total); } catch (const std::bad_alloc&) {
+            return set_error(WEPP_ENOMEM, "out of host memory for " + std::to_string(epp_total) + " EPP list entries");
+        }
+        HIP_TRY(d2h_staged(mat->epp_pending.data(), d_enodes, epp_total * 4, stream));
+    } else if (epp_total) HIP_TRY(d2h_staged(out->epp_nodes, d_enodes, epp_total * 4, stream));
     HIP_TRY(hipStreamSynchronize(stream));
 #undef GET
     g_last = EppTiming{};
@@ -367,5 +375,20 @@ extern "C" int wepp_epp_map(wepp_mat_t* mat, const wepp_epp_reads* rd, uint32_t 
     g_last.stream_events = total_events;
     g_last.groups = G;
     g_last.jobs = n_jobs;
+    if (lists_overflow)
+        return set_error(WEPP_ELIMIT, "epp_nodes holds " + std::to_string(out->epp_capacity) + " entries, " + std::to_string(epp_total) +
+                                      " needed: every other output is complete, fetch the lists with wepp_epp_fetch_lists");
+    return WEPP_OK;
+}
+
+// the EPP lists of the handle's last wepp_epp_map that did not fit the caller's buffer (nothing is computed again)
+extern "C" int wepp_epp_fetch_lists(wepp_mat_t* mat, uint32_t* epp_nodes, uint64_t capacity) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    if (mat->epp_pending.empty()) return set_error(WEPP_EINVAL, "no EPP lists are pending on this handle");
+    if (capacity < mat->epp_pending.size())
+        return set_error(WEPP_ELIMIT, "epp_nodes holds " + std::to_string(capacity) + " entries, " + std::to_string(mat->epp_pending.size()) + " needed");
+    if (!epp_nodes) return set_error(WEPP_EINVAL, "null argument");
+    std::memcpy(epp_nodes, mat->epp_pending.data(), mat->epp_pending.size() * 4);
+    std::vector<uint32_t>().swap(mat->epp_pending);
     return WEPP_OK;
 }

@@ -45,6 +45,7 @@ struct wepp_mat {
         std::vector<std::pair<void*, size_t>> blocks;
         ~DevBlockCache() { for (auto& b : blocks) (void)hipFree(b.first); }
     } epp_cache;
+    std::vector<uint32_t> epp_pending;   // EPP lists of the last wepp_epp_map that did not fit the caller's buffer (wepp_epp_fetch_lists)
     std::vector<void*> allocs;
     uint32_t tile_reads = 64;
     int use_crowns = 1;

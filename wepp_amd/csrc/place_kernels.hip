@@ -1823,12 +1823,26 @@ __global__ __launch_bounds__(256) void k_finalize_jobs(DevMAT m, const uint32_t*
 // (read, chunk of the whole-tree stream), lane = node; an R x N output only makes
 // sense for small batches, so no tiling and no pruning here.
 // -----------------------------------------------------------------------------
+// EMIT (wepp_best_nodes: best_j_vec, usher_common.cpp:376-381, filled at usher_mapper.cpp:475-476,497): the same
+// evaluation of every node of the read's OWN stream (the crown k_route picked: every node that can reach the read's
+// best score is in it), nothing written per node; a node that competes and attains the read's best score -- known from
+// the placement call -- is appended to the read's slice of the list (BFS index; slot from a per-read counter, the
+// host sorts a slice afterwards).  `list` = the reads routed to this stream.
+struct BestOut {
+    const uint32_t* list;            // reads of this stream
+    const int32_t* best;             // [n_reads] best score of every read (wepp_place_batch)
+    const unsigned long long* off;   // [n_reads + 1] CSR over the reads
+    uint32_t* cursor;                // [n_reads] slots taken
+    uint32_t* nodes;                 // the list
+    const uint32_t* rank2bfs;        // tie-break rank -> BFS index (a stream's nodes carry their global rank)
+};
+template <bool EMIT>
 __global__ __launch_bounds__(64) void k_scores(DevStream m, const uint32_t* __restrict__ dfs2bfs,
                                                const uint32_t* __restrict__ read_off,
                                                const uint32_t* __restrict__ read_word, uint32_t n_reads,
-                                               uint32_t blocks_per_chunk, int32_t* __restrict__ out) {
+                                               uint32_t blocks_per_chunk, int32_t* __restrict__ out, BestOut bo) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t r = blockIdx.x % n_reads;
+    const uint32_t r = EMIT ? bo.list[blockIdx.x % n_reads] : blockIdx.x % n_reads;
     const uint32_t chunk = blockIdx.x / n_reads;
     const uint32_t so = read_off[r], k = read_off[r + 1] - so;
     int c = 0;                                    // wave-uniform running c_S
@@ -1903,7 +1917,12 @@ __global__ __launch_bounds__(64) void k_scores(DevStream m, const uint32_t* __re
             const int ncom = (int)ncom0 + dcom;
             elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);
         } else elig = st & NS_ELIG0_DEV;
-        if (nvalid) out[(size_t)r * m.n + dfs2bfs[sum.node0 + lane]] = elig ? score : score + 1;
+        if (EMIT) {
+            if (nvalid && elig && score == bo.best[r]) {
+                const uint32_t slot = atomicAdd(&bo.cursor[r], 1u);
+                if (bo.off[r] + slot < bo.off[r + 1]) bo.nodes[bo.off[r] + slot] = bo.rank2bfs[(uint32_t)key];
+            }
+        } else if (nvalid) out[(size_t)r * m.n + dfs2bfs[sum.node0 + lane]] = elig ? score : score + 1;
         c += net;
     }
 }
@@ -2240,8 +2259,25 @@ hipError_t launch_scores(const DevMAT& m, const DevStream& full, const uint32_t*
     nchunks = std::min(nchunks, full.ncp);
     const uint32_t bpc = ((full.ncp + nchunks - 1) / nchunks) * full.cp_stride;
     nchunks = (full.NB + bpc - 1) / bpc;
-    hipLaunchKernelGGL(k_scores, dim3(n_reads * nchunks), dim3(64), 0, stream, full, m.dfs2bfs, d_read_off,
-                       d_read_word, n_reads, bpc, d_out);
+    hipLaunchKernelGGL(k_scores<false>, dim3(n_reads * nchunks), dim3(64), 0, stream, full, m.dfs2bfs, d_read_off,
+                       d_read_word, n_reads, bpc, d_out, BestOut{});
+    return hipGetLastError();
+}
+
+// the optimal nodes of the reads `list` (routed to stream `st`), see k_scores<true>
+hipError_t launch_best_nodes(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                             const uint32_t* list, uint32_t n_list, const int32_t* d_best, const unsigned long long* d_off,
+                             uint32_t* d_cursor, uint32_t* d_nodes, hipStream_t stream) {
+    if (n_list == 0) return hipSuccess;
+    // enough waves to fill the chip, cut at checkpoints, no chunk shorter than 8 blocks
+    uint32_t nchunks = std::max<uint32_t>(1, (8192 + n_list - 1) / n_list);
+    nchunks = std::min<uint32_t>(nchunks, std::max<uint32_t>(1, st.NB / 8));
+    nchunks = std::min(nchunks, st.ncp);
+    const uint32_t bpc = ((st.ncp + nchunks - 1) / nchunks) * st.cp_stride;
+    nchunks = (st.NB + bpc - 1) / bpc;
+    if ((uint64_t)n_list * nchunks >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_scores<true>, dim3(n_list * nchunks), dim3(64), 0, stream, st, (const uint32_t*)nullptr, d_read_off,
+                       d_read_word, n_list, bpc, (int32_t*)nullptr, BestOut{list, d_best, d_off, d_cursor, d_nodes, m.rank2bfs});
     return hipGetLastError();
 }
 

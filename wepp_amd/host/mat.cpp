@@ -395,6 +395,18 @@ void save_mutation_annotated_tree(const Tree& tree, std::string const& filename)
         for (auto& l : cn.second) put_len(c, 2, l);
         put_len(out, 3, c);
     }
+    if (filename.size() > 3 && filename.compare(filename.size() - 3, 3, ".gz") == 0) {
+        // gzip like UCSC's public MATs (the loader inflates, mutation_annotated_tree.cpp:528-543); in slices: gzwrite takes 32-bit lengths
+        gzFile f = gzopen(filename.c_str(), "wb1");
+        if (!f) throw mat_error("ERROR: Could not write the mutation-annotated tree file: " + filename + "!");
+        for (size_t at = 0; at < out.size();) {
+            const unsigned n = (unsigned)std::min<size_t>(out.size() - at, 1u << 30);
+            if (gzwrite(f, out.data() + at, n) != (int)n) { gzclose(f); throw mat_error("ERROR: Could not write the mutation-annotated tree file: " + filename + "!"); }
+            at += n;
+        }
+        if (gzclose(f) != Z_OK) throw mat_error("ERROR: Could not write the mutation-annotated tree file: " + filename + "!");
+        return;
+    }
     std::ofstream f(filename, std::ios::binary);
     if (!f) throw mat_error("ERROR: Could not write the mutation-annotated tree file: " + filename + "!");
     f.write(out.data(), (std::streamsize)out.size());

@@ -2,6 +2,7 @@
 #include "usher_place.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -17,7 +18,11 @@ struct FileCloser {
 };
 }  // namespace
 
+usher_place_timing usher_last_timing;
+
 namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct FlatTree {                    // wepp_tree_desc of a MAT::Tree, node id = BFS index
     std::vector<MAT::Node*> bfs;
@@ -107,8 +112,12 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
         std::stable_sort(missing_samples.begin(), missing_samples.end());
         if (reverse_sort) std::reverse(missing_samples.begin(), missing_samples.end());
     }
+    usher_last_timing = usher_place_timing{};
+    const uint64_t flattens_before = wepp_debug_flatten_count();
+    double t_mark = now_s();
     FlatTree flat;
     flatten(T, flat);
+    usher_last_timing.describe_s = now_s() - t_mark;
     const std::vector<MAT::Node*>& bfs = flat.bfs;
     const size_t total_nodes = bfs.size();
 
@@ -148,12 +157,18 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
     // ONE flatten for the node (the reference pays its expansion once per sample, usher_common.cpp:339); every device
     // thread uploads the same image
     wepp_flat_t* image = nullptr;
+    t_mark = now_s();
     if (wepp_flat_create(&flat.desc, &image) != WEPP_OK) {
         fprintf(stderr, "ERROR: %s\n", wepp_last_error());
         return 1;
     }
+    usher_last_timing.flatten_s = now_s() - t_mark;
+    std::vector<double> upload_s(G, 0.0), place_s(G, 0.0);
     auto place_shard = [&](uint32_t g) {
+        const double t0 = now_s();
         if (wepp_mat_upload(image, devices[g], &mats[g]) != WEPP_OK) { errors[g] = wepp_last_error(); return; }
+        upload_s[g] = now_s() - t0;
+        struct Stop { double t0; double& out; ~Stop() { out = now_s() - t0; } } stop{now_s(), place_s[g]};
         const uint32_t lo = shard_lo(g), hi = shard_lo(g + 1), n = hi - lo;
         if (n == 0) return;
         std::vector<uint32_t> off, words;
@@ -188,6 +203,10 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
     auto destroy_all = [&]() { for (auto m : mats) if (m) wepp_mat_destroy(m); };
     run_on_devices(place_shard);
     wepp_flat_destroy(image);
+    usher_last_timing.upload_s = *std::max_element(upload_s.begin(), upload_s.end());
+    usher_last_timing.place_s = *std::max_element(place_s.begin(), place_s.end());
+    usher_last_timing.flattens = wepp_debug_flatten_count() - flattens_before;
+    t_mark = now_s();
     for (uint32_t g = 0; g < G; g++)
         if (!errors[g].empty()) {
             fprintf(stderr, "ERROR: %s\n", errors[g].c_str());
@@ -364,5 +383,6 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
                                 (flags[q] & WEPP_FLAG_HAS_UNIQUE) != 0});
     }
     destroy_all();
+    usher_last_timing.write_s = now_s() - t_mark;
     return 0;
 }

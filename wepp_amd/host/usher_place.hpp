@@ -21,6 +21,15 @@ struct usher_place_result {       // what the reference keeps in locals per samp
     bool best_node_has_unique;    // :374
 };
 
+// Wall time of the phases of the calling process's last usher_place_samples (seconds): tree -> flat description,
+// the ONE flatten of the node (wepp_flat_create), the slowest device thread's upload (wepp_mat_upload) and its
+// placement + pass-2 calls, the writers.  `flattens` = full flattens the call ran (1, whatever the device count).
+struct usher_place_timing {
+    double describe_s = 0, flatten_s = 0, upload_s = 0, place_s = 0, write_s = 0;
+    uint64_t flattens = 0;
+};
+extern usher_place_timing usher_last_timing;
+
 // Places every sample of `missing_samples` (in order) on `T`.
 //   outdir                   directory for the TSV files ("" = write none)
 //   max_uncertainty / max_parsimony   thresholds of the warnings at :453-466

@@ -234,17 +234,17 @@ int cartesian_map(MAT::Tree& condensed, const std::vector<raw_read>& reads, size
     std::vector<uint64_t> epp_off(R + 1);
     out.score.assign(N, 0.0);
     out.dist_divergence.assign(N, 0.0);
-    // The EPP lists hold what the reads' multiplicities add up to, at most MAX_CACHED_EPP_SIZE each: sized
-    // from a typical guess first, then -- wepp_epp_map reports the needed total with WEPP_ELIMIT -- exactly
-    // (the worst case, R * 2048 entries, is 8 GiB per million reads).
+    // The EPP lists hold what the reads' multiplicities add up to, at most MAX_CACHED_EPP_SIZE each: known only once
+    // the map has run (the worst case, R * 2048 entries, is 8 GiB per million reads).  A typical guess first; when it is
+    // short the map still delivers everything else and keeps the lists (WEPP_ELIMIT): they are fetched into a buffer
+    // of the reported size -- the map itself runs ONCE.
     epp.resize(std::max<size_t>(R, 1) * 16);
-    int rc = WEPP_OK;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        wepp_epp_out o{pars.data(), mult.data(), epp_off.data(), epp.data(), epp.size(), out.score.data(), counts.data(),
-                       out.dist_divergence.data()};
-        rc = wepp_epp_map(mat, &in, (uint32_t)genome_size, MAX_CACHED_EPP_SIZE, &o);
-        if (rc != WEPP_ELIMIT || attempt == 1 || epp_off[R] <= epp.size()) break;
+    wepp_epp_out o{pars.data(), mult.data(), epp_off.data(), epp.data(), epp.size(), out.score.data(), counts.data(),
+                   out.dist_divergence.data()};
+    int rc = wepp_epp_map(mat, &in, (uint32_t)genome_size, MAX_CACHED_EPP_SIZE, &o);
+    if (rc == WEPP_ELIMIT && epp_off[R] > epp.size()) {
         epp.assign((size_t)epp_off[R], 0);
+        rc = wepp_epp_fetch_lists(mat, epp.data(), epp.size());
     }
     if (rc == WEPP_OK) rc = wepp_mat_dfs_order(mat, order.data());
     if (rc != WEPP_OK) {

@@ -2,6 +2,9 @@
 // (the placement-only invocation of /root/reference/src/usher.cpp:141-183).
 // A thin driver around usher_place_samples; also `--dump` prints what the loaders
 // parsed (used by the CPU tests, needs no GPU).
+#include <sys/resource.h>
+
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,14 +15,16 @@
 
 static void usage() {
     fprintf(stderr, "usage: wepp-usher -i <mat.pb[.gz]> -v <samples.vcf[.gz]> [-d <outdir>] [-p] [-e max_uncertainty] "
-                    "[-E max_parsimony] [-s|-S|-A] [-r] [--device N | --devices 0,1,...] [--dump]\n"
+                    "[-E max_parsimony] [-s|-S|-A] [-r] [--device N | --devices 0,1,...] [--dump] [--report]\n"
+                    "       --report prints one JSON line to stdout: seconds per phase (load, VCF, tree description, flatten, upload, "
+                    "placement, writers), full flattens, peak resident memory\n"
                     "       -n/--no-add is required: samples are placed on the tree as given, never added to it\n");
 }
 
 int main(int argc, char** argv) {
     std::string pb, vcf, outdir = ".";
     bool print_scores = false, dump = false, sort1 = false, sort2 = false, sort3 = false, reverse_sort = false;
-    bool no_add = false;
+    bool no_add = false, report = false;
     std::vector<int> devices;
     uint32_t max_uncertainty = 1000000, max_parsimony = 1000000;   // usher.cpp:77-80 defaults
     int device = 0;
@@ -44,13 +49,18 @@ int main(int argc, char** argv) {
             for (auto& d : ids) devices.push_back(atoi(d.c_str()));
         }
         else if (a == "--dump") dump = true;
+        else if (a == "--report") report = true;
         else { usage(); return 1; }
     }
     if (pb.empty() || vcf.empty()) { usage(); return 1; }
     try {
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         MAT::Tree T = MAT::load_mutation_annotated_tree(pb);
+        const double t_load = now() - t0;
         std::vector<Missing_Sample> missing_samples;
         MAT::read_vcf(&T, vcf, missing_samples);
+        const double t_vcf = now() - t0 - t_load;
         if (dump) {
             auto bfs = T.breadth_first_expansion();
             printf("nodes %zu\n", bfs.size());
@@ -78,8 +88,19 @@ int main(int argc, char** argv) {
             return 1;                                               // usher_common.cpp:14-71 style validation
         }
         if (devices.empty()) devices.push_back(device);
-        return usher_place_samples(outdir, max_uncertainty, max_parsimony, print_scores, missing_samples, low_conf, &T,
-                                   devices, nullptr, sort1, sort2, sort3, reverse_sort);
+        const int rc = usher_place_samples(outdir, max_uncertainty, max_parsimony, print_scores, missing_samples, low_conf, &T,
+                                           devices, nullptr, sort1, sort2, sort3, reverse_sort);
+        if (report) {
+            struct rusage ru{};
+            getrusage(RUSAGE_SELF, &ru);
+            const usher_place_timing& t = usher_last_timing;
+            printf("{\"nodes\": %zu, \"samples\": %zu, \"devices\": %zu, \"load_pb_s\": %.3f, \"read_vcf_s\": %.3f, \"describe_s\": %.3f, "
+                   "\"flatten_s\": %.3f, \"upload_s\": %.3f, \"place_s\": %.3f, \"write_s\": %.3f, \"total_s\": %.3f, \"flattens\": %llu, "
+                   "\"peak_rss_mb\": %.1f, \"rc\": %d}\n",
+                   T.size(), missing_samples.size(), devices.size(), t_load, t_vcf, t.describe_s, t.flatten_s, t.upload_s, t.place_s, t.write_s,
+                   now() - t0, (unsigned long long)t.flattens, ru.ru_maxrss / 1024.0, rc);
+        }
+        return rc;
     } catch (const std::exception& e) {
         fprintf(stderr, "%s\n", e.what());
         return 1;
