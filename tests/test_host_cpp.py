@@ -237,3 +237,31 @@ def test_wepp_usher_devices_and_chunked_scores(tmp_path):
     assert open(p3 / "parsimony-scores.tsv").read() == open(p4 / "parsimony-scores.tsv").read()
     r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-d", str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 1 and "--no-add" in r.stderr
+
+
+@pytest.mark.gpu
+def test_one_flatten_for_three_devices(tmp_path):
+    """The multi-GPU host loop flattens the tree ONCE and uploads the image from every device thread
+    (wepp_flat_create + wepp_mat_upload; the reference re-expands the tree per sample, usher_common.cpp:339): with
+    `--devices 0,0,0` on a 300 K-node tree written by the repo's own .pb.gz writer (wepp-synth) the run reports one
+    full flatten, writes the same placement_stats.tsv as the single-device run, and its peak resident memory stays
+    within 1.3x of it."""
+    import json
+    synth = os.path.join(ROOT, "wepp_amd", "wepp-synth")
+    pb, vcf = str(tmp_path / "t.pb.gz"), str(tmp_path / "s.vcf")
+    subprocess.run([synth, "--nodes", "300000", "--seed", "5", "--pb", pb, "--samples", "600", "--vcf", vcf, "--read-len", "400",
+                    "--p-n", "0.01"], check=True, capture_output=True)
+
+    def run(name, *extra):
+        out = tmp_path / name
+        out.mkdir()
+        r = subprocess.run([CLI, "-i", pb, "-v", vcf, "-n", "-d", str(out), "--report"] + list(extra), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return out, json.loads(r.stdout.strip().splitlines()[-1])
+
+    one, rep1 = run("one")
+    three, rep3 = run("three", "--devices", "0,0,0")
+    assert rep1["flattens"] == 1 and rep3["flattens"] == 1 and rep3["devices"] == 3
+    assert rep1["nodes"] == 300000 and rep1["samples"] == 600
+    assert open(one / "placement_stats.tsv").read() == open(three / "placement_stats.tsv").read()
+    assert rep3["peak_rss_mb"] <= 1.3 * rep1["peak_rss_mb"], (rep1, rep3)

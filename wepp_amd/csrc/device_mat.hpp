@@ -105,6 +105,7 @@ constexpr uint32_t WALK_JOB_EVENTS_MAX = 256, WALK_TARGET_JOBS = 1u << 20;
 // Measured (16 M nodes, 1 M reads with 5 % N): rows 16/32 -> 12/20 (2 -> 3.5 waves per SIMD for the 16-entry
 // class) 21.5 -> 19.9 ms, nothing on the other legs: the walks are not short of waves.
 constexpr uint32_t WALK_WAVES = 2;         // waves per workgroup of k_walk (their LDS regions are private)
+constexpr uint32_t WALK_QUEUE = 6;         // sub-ranges a lane can hold back for the exact query before the wave drains them (k_walk)
 constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of a launch runs on XCD b % 8
 // waves of a walk plan are padded to a multiple of this, so that every plan starts at a workgroup index that is a
 // multiple of the XCD count and its waves can be dealt to the XCDs in contiguous runs (k_walk)

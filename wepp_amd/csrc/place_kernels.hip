@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     extern __shared__ uint32_t lds_all[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t* S16 = lds_all + wv * (KW / 2 + KW + sd_rows) * 64;
+    uint32_t* S16 = lds_all + wv * (KW / 2 + KW + sd_rows + 2 * WALK_QUEUE) * 64;
     uint32_t* cur_l = S16 + (KW / 2) * 64;
     uint32_t* stk = cur_l + KW * 64;
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
@@ -1528,13 +1528,79 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
         }
     }
 
-    // small streams: nearly every range between two events holds a node that can tie the best (a crown is
-    // made of low-score nodes), so the exact query is issued at once, with the other loads of the iteration;
-    // large ones ask the sparse table first (there nearly every range fails it)
-    const bool eager = ix.n <= m.walk_eager_nodes;
+    // ---- the loop: one iteration per NODE EVENT ----
+    // A lane's next stop is the next node that carries one of its listed positions (or the end of its node range).
+    // The intervals that end on the way are not stops of their own: [pos, stop) is pre-tested ONCE, with the lowest
+    // c any of its nodes sees (c_low: the running minimum over the pops), against a byte that stands for a superset
+    // of the range -- the fetched entry's own pre-test byte (the minimum static score of the eligible nodes since its
+    // list's previous entry; flatmat.hpp: ix_pre) or, where there is none, the sparse table's.  Nearly every range
+    // fails it and costs nothing more; one that passes is cut at the interval ends into sub-ranges of constant c,
+    // which go to a per-lane QUEUE in LDS.  The queue is drained -- table byte, then the exact aggregate of the
+    // sub-ranges that still pass (four independent 16-byte loads), `take` -- when some lane's queue is full and at
+    // the end of the walk: the rare, divergent part of an iteration runs with many lanes at once instead of with two
+    // or three in every iteration.  A candidate taken late only delays a tighter `bs` (more sub-ranges queued, never
+    // a different result: `take` is commutative).
+    uint32_t* que = stk + sd_rows * 64;        // [WALK_QUEUE][2][64]: (a | c + bias in the top bits), b
+    uint32_t qn = 0;
 #ifdef WEPP_WALK_STATS
     uint32_t st_live = 0, st_pass = 0;
 #endif
+    auto drain = [&]() {
+        while (__ballot(qn > 0)) {
+            if (qn > 0) {
+                qn--;
+                const uint32_t qa = que[(qn * 2) * 64 + lane], b = que[(qn * 2 + 1) * 64 + lane];
+                const uint32_t a = qa & ((1u << (32 - WALK_DELTA_BITS)) - 1u);
+                const int cq = (int)(qa >> (32 - WALK_DELTA_BITS)) - (int)WALK_DELTA_BIAS;
+                // the table byte of [a, b): the minimum over [a, a + 2^lvl), the first level that reaches b
+                const uint32_t len = b - a;
+                const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
+                const uint32_t mn = ix.sp[(size_t)lvl * ix.n + a];
+                lane_bytes += 1;
+                if (mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + cq <= bs)) {
+#ifdef WEPP_WALK_STATS
+                    st_pass++;
+#endif
+                    // exact aggregate of the statically eligible nodes of [a, b): suffix of the first node's block,
+                    // disjoint sparse table over the whole blocks in between, prefix of the last node's block
+                    const uint32_t last = b - 1;
+                    const uint32_t ba = a / RQ_BLK, bl = last / RQ_BLK;
+                    SegNode ag{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
+                    auto join = [&](const SegNode x) {
+                        if (x.base < ag.base) ag = x;
+                        else if (x.base == ag.base) { ag.cnt += x.cnt; if (x.rank < ag.rank) { ag.rank = x.rank; ag.hu = x.hu; } }
+                    };
+                    if (ba == bl) {
+                        // inside one block: its prefix up to the last node, unless the range starts behind the
+                        // block's first node -- then node by node
+                        lane_bytes += 16;
+                        if (a == ba * RQ_BLK) join(ix.rq_pre[last]);
+                        else if (b == ix.n || b == (ba + 1) * RQ_BLK) join(ix.rq_suf[a]);
+                        else
+                            for (uint32_t i = a; i < b; i++) {
+                                if (i > a) lane_bytes += 16;
+                                const NodeRec x = ix.nrec[i];
+                                if (x.nstat & NS_ELIG0_DEV) {
+                                    const uint32_t hu = (x.nstat & NS_ROOT_DEV) ? 0u : (x.nstat & NS_MASKED_DEV) ? 1u :
+                                                        (((x.nstat >> 14) & NS_CNT_MASK_DEV) < (x.nstat & NS_CNT_MASK_DEV) ? 1u : 0u);
+                                    join(SegNode{x.base, x.rank, 1u, hu});
+                                }
+                            }
+                    } else {
+                        const uint32_t lo = ba + 1, hi = bl - 1;
+                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
+                        const uint32_t L = lo < hi ? 31u - (uint32_t)__builtin_clz(lo ^ hi) : 0u;
+                        const SegNode* trow = ix.rq_dst + (size_t)L * ix.rq_blocks;
+                        const SegNode s1 = ix.rq_suf[a], s2 = ix.rq_pre[last];
+                        const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
+                        join(s1); join(s2); join(s3); join(s4);
+                        lane_bytes += 32 + (lo <= hi ? 16 : 0) + (lo < hi ? 16 : 0);
+                    }
+                    if (ag.cnt && ag.base + cq <= bs) take(ag.base + cq, ag.rank, ag.cnt, ag.hu);
+                }
+            }
+        }
+    };
     while (__ballot(pos < n)) {
         iters++;
 #ifdef WEPP_WALK_STATS
@@ -1544,8 +1610,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
 #pragma unroll
         for (int j = 1; j < KW; j++) i_next = min(i_next, head[j]);
         const bool live = pos < n;
-        const uint32_t stop = min(min(i_next, top_end), n);
-        const bool at_node = live && i_next < top_end && i_next < n;
+        const uint32_t stop = min(i_next, n);
+        const bool at_node = live && i_next < n;
         const unsigned long long b_at = __ballot(at_node);
         n_ent += (uint32_t)__popcll(b_at);
         // ---- everything this iteration reads from memory is requested here, together ----
@@ -1560,88 +1626,71 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             ecur = cur_l[js * 64 + lane];
             ent = ix.ix_ent[ecur];             // 32 bytes: the mutation, the list's next node and the node's own record
         }
-        // the sparse-table byte of [pos, stop): the minimum over [pos, pos + 2^lvl), the first level that reaches
-        // `stop`.  A lane whose range ends at the fetched entry's node asks that entry's byte first (use_pre);
-        // every other lane's table byte is requested here, with the entry, not behind it
+        // a range without an entry byte (the stream carries none, or the range runs to the end of the lane's nodes)
+        // asks the sparse table: requested here, with the entry, not behind it
         const bool ranged = live && stop > pos;
-        const bool use_pre = ranged && !eager && ix.has_pre && at_node && k >= IX_PRE_MIN_LISTS;
-        size_t sp_at = 0;
-        uint32_t mn_early = SP_NONE;
-        if (ranged && !eager) {
+        const bool by_table = ranged && !(ix.has_pre && at_node);
+        uint32_t mn = SP_NONE;
+        if (by_table) {
             const uint32_t len = stop - pos;
             const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
-            sp_at = (size_t)lvl * ix.n + pos;
-            if (!use_pre) mn_early = ix.sp[sp_at];
+            mn = ix.sp[(size_t)lvl * ix.n + pos];
         }
-        n_spb += (uint32_t)__popcll(__ballot(ranged && !eager && !use_pre));
-        // ---- the nodes [pos, stop): none of them carries a listed position, c is constant ----
-        if (live && stop > pos) {
-            const uint32_t last = stop - 1;
-            const uint32_t ba = pos / RQ_BLK, bl = last / RQ_BLK;
-            bool pass = true;
-            if (!eager) {
-                // the range ends at the node of the entry fetched above: that entry's byte is the minimum of a
-                // superset (everything since its list's previous entry), no table byte needed unless it passes
-                // (a read with one or two lists gains nothing: its ranges ARE the ranges between its list's entries, and
-                // when such a range cannot be skipped the table byte would be fetched after the entry instead of with it)
-                bool by_entry = false;
-                uint32_t mn = mn_early;
-                if (use_pre) {
-                    const uint32_t pb = ent.rank >> IX_RANK_BITS;
-                    by_entry = pb == SP_NONE || (pb < SP_CLAMP && (int)pb + c > bs);
-                    if (!by_entry) { mn = ix.sp[sp_at]; lane_bytes += 1; }   // (rare on the large streams: the byte of the table after all)
-                }
-                pass = !by_entry && mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
-            }
-#ifdef WEPP_WALK_STATS
-            st_pass += (uint32_t)__popcll(__ballot(pass));
-#endif
-            if (__ballot(pass)) {
-                if (pass) {
-                    // exact aggregate of the statically eligible nodes of [pos, stop): suffix of the first node's
-                    // block, disjoint sparse table over the whole blocks in between, prefix of the last node's
-                    // block -- four independent 16-byte loads (flatmat.hpp)
-                    SegNode ag{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
-                    auto join = [&](const SegNode x) {
-                        if (x.base < ag.base) ag = x;
-                        else if (x.base == ag.base) { ag.cnt += x.cnt; if (x.rank < ag.rank) { ag.rank = x.rank; ag.hu = x.hu; } }
-                    };
-                    if (ba == bl) {
-                        // inside one block: its prefix up to the last node, unless the range starts behind the
-                        // block's first node -- then node by node
-                        lane_bytes += 16;
-                        if (pos == ba * RQ_BLK) join(ix.rq_pre[last]);
-                        else if (last + 1 == min(ix.n, (ba + 1) * RQ_BLK)) join(ix.rq_suf[pos]);
-                        else
-                            for (uint32_t i = pos; i < stop; i++) {
-                                if (i > pos) lane_bytes += 16;
-                                const NodeRec x = ix.nrec[i];
-                                if (x.nstat & NS_ELIG0_DEV) {
-                                    const uint32_t hu = (x.nstat & NS_ROOT_DEV) ? 0u : (x.nstat & NS_MASKED_DEV) ? 1u :
-                                                        (((x.nstat >> 14) & NS_CNT_MASK_DEV) < (x.nstat & NS_CNT_MASK_DEV) ? 1u : 0u);
-                                    join(SegNode{x.base, x.rank, 1u, hu});
-                                }
-                            }
-                    } else {
-                        const uint32_t lo = ba + 1, hi = bl - 1;
-                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
-                        const uint32_t L = lo < hi ? 31u - (uint32_t)__builtin_clz(lo ^ hi) : 0u;
-                        const SegNode* trow = ix.rq_dst + (size_t)L * ix.rq_blocks;
-                        const SegNode s1 = ix.rq_suf[pos], s2 = ix.rq_pre[last];
-                        const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
-                        join(s1); join(s2); join(s3); join(s4);
-                        lane_bytes += 32 + (lo <= hi ? 16 : 0) + (lo < hi ? 16 : 0);
+        n_spb += (uint32_t)__popcll(__ballot(by_table));
+        // ---- the intervals that end before the stop: the lowest c on the way ----
+        int c_run = c, c_low = c;
+        uint32_t t = sp;
+        {
+            uint32_t te = top_end;
+            int td = top_d;
+            while (__ballot(live && t > 0 && te <= stop)) {
+                if (live && t > 0 && te <= stop) {
+                    c_run -= td;
+                    c_low = min(c_low, c_run);
+                    t--;
+                    if (t) {
+                        const uint32_t e = stk[(t - 1) * 64 + lane];
+                        te = e >> WALK_DELTA_BITS;
+                        td = (int)(e & ((1u << WALK_DELTA_BITS) - 1u)) - (int)WALK_DELTA_BIAS;
                     }
-                    if (ag.cnt && ag.base + c <= bs) take(ag.base + c, ag.rank, ag.cnt, ag.hu);
                 }
             }
-            pos = stop;
         }
-        if (live && pos < n) {
-            if (!at_node) {
-                // the innermost open interval ends here: its nodes are behind us
-                c -= top_d;
-                sp--;
+        // ---- the nodes [pos, stop): none of them carries a listed position ----
+        if (ranged) {
+            if (!by_table) mn = ent.rank >> IX_RANK_BITS;      // the entry's byte: everything since its list's previous entry
+            const bool look = mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c_low <= bs);
+            // the sub-ranges of constant c, innermost interval first, into the queue (drained first when a lane is short of room)
+            uint32_t a = pos, tq = sp;
+            int cc = c;
+            bool more_q = look;
+            while (__ballot(more_q)) {
+                if (__ballot(more_q && qn == WALK_QUEUE)) drain();
+                if (more_q) {
+                    uint32_t b = stop;
+                    int d = 0;
+                    if (tq > t) {
+                        const uint32_t e = stk[(tq - 1) * 64 + lane];
+                        b = e >> WALK_DELTA_BITS;
+                        d = (int)(e & ((1u << WALK_DELTA_BITS) - 1u)) - (int)WALK_DELTA_BIAS;
+                        tq--;
+                    } else more_q = false;
+                    if (b > a) {
+                        que[(qn * 2) * 64 + lane] = a | ((uint32_t)(cc + (int)WALK_DELTA_BIAS) << (32 - WALK_DELTA_BITS));
+                        que[(qn * 2 + 1) * 64 + lane] = b;
+                        qn++;
+                        a = b;
+                    }
+                    cc -= d;
+                }
+            }
+        }
+        if (live) {
+            // the pops take effect
+            c = c_run;
+            pos = stop;
+            if (t != sp) {
+                sp = t;
                 if (sp) {
                     const uint32_t e = stk[(sp - 1) * 64 + lane];
                     top_end = e >> WALK_DELTA_BITS;
@@ -1703,6 +1752,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             }
         }
     }
+    drain();
     WALK_STAMP(4);          // walked
     if (have) {
         if (CHUNKED) {
@@ -2192,8 +2242,8 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
 }
 
 // LDS of a walk workgroup: WALK_WAVES waves, each KW / 2 rows of read alleles + KW rows of cursors + sd_rows of
-// stack (64 lanes x 4 bytes a row)
-static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVES * (kw / 2 + kw + sd_rows) * 256; }
+// stack + 2 * WALK_QUEUE rows of queued sub-ranges (64 lanes x 4 bytes a row)
+static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVES * (kw / 2 + kw + sd_rows + 2 * WALK_QUEUE) * 256; }
 // stack rows of a launch: the deepest stack its reads can need (k_route), at least one row for the job decode's
 // scratch, never more than the class admits
 static uint32_t walk_stack_rows(uint32_t open_max, uint32_t sd) { return std::min(sd, std::max(open_max, 2u)); }
