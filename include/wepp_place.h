@@ -101,6 +101,9 @@ typedef struct {
     int32_t  stream_tau[16];
     uint64_t stream_nodes[16];
     uint64_t stream_bytes_of[16];
+    /* window crowns (see wepp_mat_last_crowns): how many were built, their nodes in all */
+    uint32_t n_window_crowns;
+    uint64_t window_crown_nodes;
 } wepp_mat_stats;
 
 /* Per-read result flags (out parameter `flags`). */
@@ -250,6 +253,13 @@ int wepp_mat_last_tiers(wepp_mat_t *mat, uint8_t *tiers, uint32_t n_reads);
 #define WEPP_PLAN_WALKC16 4   /* walk cut into jobs, up to 16 positions                    */
 #define WEPP_PLAN_WIN     5   /* sweep of a genome window's stream (long reads)            */
 int wepp_mat_last_plans(wepp_mat_t *mat, uint8_t *plan_class, uint8_t *plan_stream, uint32_t n_reads);
+/* plan_stream == WEPP_WINDOW_CROWN_SLOT: the read walked a WINDOW CROWN -- the nodes whose score for any read
+ * confined to its genome window can be as low as the read's root score (positions outside the window cost every
+ * such read the same), far fewer than the tree-wide crown of root score + entries.  wepp_mat_last_crowns tells
+ * which: window[r] = index of the genome window, crown[r] = index of the crown among the window's (increasing
+ * bound); 255 / 255 for a read placed otherwise. */
+#define WEPP_WINDOW_CROWN_SLOT 15
+int wepp_mat_last_crowns(wepp_mat_t *mat, uint8_t *window, uint8_t *crown, uint32_t n_reads);
 
 /* Diagnostic: reads of the handle's most recent placement call that walked their own events (k_walk;
  * the others were placed by sweeps of their stream), and the loop iterations (one per event, interval end or

@@ -63,7 +63,9 @@ def main():
     for label, rd in batches:
         res = mat.place_batch(rd)
         pcls, pst = mat.last_plans(rd.n_reads)
-        key = pcls.astype(np.int32) * 64 + pst
+        _, wcrown = mat.last_crowns(rd.n_reads)
+        # (reads on window crowns -- stream slot 15 -- are counted per crown level)
+        key = pcls.astype(np.int32) * 1024 + pst.astype(np.int32) * 16 + np.where(wcrown == 255, 0, wcrown)
         pick = []
         for k in np.unique(key):
             pick.extend(np.nonzero(key == k)[0][:200].tolist())
@@ -81,12 +83,13 @@ def main():
         for k in np.unique(key):
             members = key == k
             assert (checked & members).sum() >= min(200, members.sum()), (label, int(k))
-            plans[f"{w.PLAN_NAMES[k // 64]}:{k % 64}"] = [int(members.sum()), int((checked & members).sum())]
+            plans[f"{w.PLAN_NAMES[k // 1024]}:{(k // 16) % 64}" + (f".{k % 16}" if (k // 16) % 64 == w.WINDOW_CROWN_SLOT else "")] = \
+                [int(members.sum()), int((checked & members).sum())]
         classes_seen |= set(np.unique(pcls).tolist())
         out["batches"].append({"reads": label, "n_reads": rd.n_reads, "checked": int(len(pick)),
                                "checker_s": round(time.perf_counter() - t1, 1), "plans_total_checked": plans})
     if n_nodes >= 1_000_000:
-        assert {w.PLAN_WALKC8, w.PLAN_WALKC16} <= classes_seen, sorted(classes_seen)
+        assert {w.PLAN_WALK8, w.PLAN_WALK16} <= classes_seen, sorted(classes_seen)
     out["classes_seen"] = [w.PLAN_NAMES[c] for c in sorted(classes_seen)]
 
     # ---- configs[4] at its per-GPU shard size: 1.2 kb reads (window plans cut into their product number of waves) ----

@@ -472,8 +472,13 @@ def test_full_size_parity_and_properties(oracle):
     pcls, pst = mat.last_plans(reads.n_reads)
     assert (np.where(pcls == w.PLAN_WIN, mat.stats.n_streams - 1, pst) == tiers).all()
     present = [int(t) for t in np.unique(tiers)]
-    assert len(present) >= 6, present                      # the batch reaches many crown streams
-    plan_key = pcls.astype(np.int32) * 64 + pst
+    # a read that walks a window crown (stream slot 15) counts per crown LEVEL of its window: every level the batch
+    # reaches gets its share of checked reads, like every tree-wide stream
+    _, wcrown = mat.last_crowns(reads.n_reads)
+    assert ((wcrown != 255) == ((pst == w.WINDOW_CROWN_SLOT) & (pcls != w.PLAN_WIN) & (pcls != w.PLAN_SWEEP))).all()
+    plan_key = pcls.astype(np.int32) * 1024 + pst.astype(np.int32) * 16 + np.where(wcrown == 255, 0, wcrown)
+    assert len(np.unique(plan_key)) >= 6, np.unique(plan_key)      # the batch reaches many streams and crown levels
+    assert (pst == w.WINDOW_CROWN_SLOT).mean() > 0.3               # ... most of its reads with entries through window crowns
     pick = []
     for key in np.unique(plan_key):
         pick.extend(np.nonzero(plan_key == key)[0][:900].tolist())
@@ -486,8 +491,8 @@ def test_full_size_parity_and_properties(oracle):
     checked[pick] = True
     for key in np.unique(plan_key):
         members = plan_key == key
-        assert (checked & members).sum() >= min(200, members.sum()), (w.PLAN_NAMES[key // 64], key % 64)
-    assert {w.PLAN_WALK8, w.PLAN_WALKC8} <= set(np.unique(pcls).tolist())
+        assert (checked & members).sum() >= min(200, members.sum()), (w.PLAN_NAMES[key // 1024], (key // 16) % 64, key % 16)
+    assert w.PLAN_WALK8 in set(np.unique(pcls).tolist())
     # 2. the faithful oracle: 2 reads per tier
     few = np.array([q for t in present for q in np.nonzero(tiers == t)[0][:2].tolist()])
     same(res, few, ot.place_batch(gather(few), nthr, node_parallel=True))
@@ -553,7 +558,7 @@ def test_full_size_nrich_and_long_shard():
     run = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=1500)
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
     rep = json.loads(run.stdout.strip().splitlines()[-1])
-    assert rep["nodes"] == 16_000_000 and {"walkc8", "walkc16"} <= set(rep["classes_seen"])
+    assert rep["nodes"] == 16_000_000 and {"walk8", "walk16"} <= set(rep["classes_seen"])
     assert all(b["checked"] >= 5000 for b in rep["batches"]) and rep["long_reads"]["checked"] >= 500
     assert rep["long_reads"]["window_plan_share"] > 0.9
     print("full-size N-rich / long-shard report:", json.dumps(rep))
@@ -670,7 +675,7 @@ def test_best_nodes_vs_oracle(oracle):
     mat = w.Mat(g.tree)
     inc = oracle.OracleTree(g.tree).incremental()
     res = mat.place_batch(reads)
-    assert len(np.unique(mat.last_tiers(reads.n_reads))) >= 4
+    assert len(np.unique(mat.last_tiers(reads.n_reads))) >= 2
     for crowns in (True, False):
         mat.set_use_crowns(crowns)
         got = mat.best_nodes(reads, res)

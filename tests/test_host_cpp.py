@@ -239,6 +239,38 @@ def test_wepp_usher_devices_and_chunked_scores(tmp_path):
     assert r.returncode == 1 and "--no-add" in r.stderr
 
 
+def test_synthetic_pb_gz_round_trip(tmp_path):
+    """wepp-synth writes the generator's tree with the repo's own save_mutation_annotated_tree (gzipped like UCSC's
+    public MATs) and the samples as a VCF; the loaders read both back (--load-only: no GPU) and the tree they build is
+    the generated one: same node count, and -- node by node through --dump -- the same parents and mutations as
+    wepp_amd.generate_tree with the same seed."""
+    import json
+    synth = os.path.join(ROOT, "wepp_amd", "wepp-synth")
+    pb, vcf = str(tmp_path / "t.pb.gz"), str(tmp_path / "s.vcf.gz")
+    r = subprocess.run([synth, "--nodes", "3000", "--seed", "9", "--pb", pb, "--samples", "40", "--vcf", vcf, "--read-len", "300"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(pb, "rb").read(2) == b"\x1f\x8b"                      # gzip magic
+    rep = json.loads(subprocess.run([CLI, "-i", pb, "-v", vcf, "--load-only"], check=True, capture_output=True, text=True).stdout)
+    assert rep["nodes"] == 3000 and rep["samples"] == 40
+    nodes, samples = _run_dump(pb, vcf)
+    g = w.generate_tree(9, 3000)
+    parent, muts = _tree_lists(g.tree)
+    has_child = [False] * 3000
+    for p_ in parent:
+        if p_ >= 0:
+            has_child[p_] = True
+    leaves = {f"s{i}": i for i in range(3000) if not has_child[i]}
+    assert len(samples) == 40
+    n_checked = 0
+    for name, i in leaves.items():
+        par_name, got = nodes[name]
+        want = sorted([(p, r, pa, mu) for (p, r, pa, mu) in muts[i] if mu != pa], key=lambda t: t[0])
+        assert got == want, name
+        n_checked += 1
+    assert n_checked > 1000
+
+
 @pytest.mark.gpu
 def test_one_flatten_for_three_devices(tmp_path):
     """The multi-GPU host loop flattens the tree ONCE and uploads the image from every device thread

@@ -156,3 +156,49 @@ def test_range_queries_against_brute_force():
             sup = np.nonzero(elig[a:min(m.n, a + (1 << (ln - 1).bit_length()))])[0] + a
             assert m.range_min(a, b) == min(int(base[sup].min()), wm.SP_CLAMP) <= min(mn, wm.SP_CLAMP)
             assert m.range_exact(a, b)[:3] == (mn, int(rank[at].min()), len(at))
+
+
+def test_window_crowns_hold_every_node_that_can_win(oracle):
+    """Window crowns (flatmat.hpp: wcrowns): the walk of a read confined to a genome window, run on the crown of its
+    window whose bound is the read's ROOT score, gives the oracle's placement (score, node, number of optimal nodes,
+    has_unique) -- on trees whose mutations crowd a few windows (long genome, 1024-position stride), with reads that
+    list up to 16 positions of one window, most of them N; whole and cut into jobs."""
+    rng = np.random.default_rng(77)
+    n = covered = 0
+    levels = set()
+    for it in range(6):
+        g = w.generate_tree(100 + it, 4000, genome_len=5000, p_ambiguous=0.02, p_masked_node=0.01, root_mutations=it % 2,
+                            p_back_mutation=0.1)
+        ot = oracle.OracleTree(g.tree)
+        fv = w.FlatView(g.tree)
+        tau = fv.get("wc_tau").view(np.int32).reshape(-1, 6)
+        nodes = fv.get("wc_nodes").reshape(-1, 6)
+        assert tau.shape[0] >= 4 and (nodes[:, 0] > 0).all()
+        assert fv.stats.n_window_crowns == int((nodes > 0).sum()) and fv.stats.window_crown_nodes == int(nodes.sum())
+        reads = g.reads(200 + it, 160, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.01, p_n=0.04, p_iupac=0.2)
+        models = {}
+        for q in range(reads.n_reads):
+            pos, ref, mut, miss = reads.entries(q)
+            S = list(zip(pos.tolist(), ref.tolist(), mut.tolist(), miss.tolist()))
+            if not S or len(S) > 16:
+                continue
+            wi = S[0][0] // 1024
+            if wi >= tau.shape[0] or S[-1][0] >= wi * 1024 + 2560:
+                continue
+            rs = _root_score(fv, S)
+            ci = next((i for i in range(6) if nodes[wi, i] and rs <= tau[wi, i]), None)
+            n += 1
+            if ci is None:
+                continue
+            m = models.get((wi, ci)) or models.setdefault((wi, ci), wm.WalkModel(fv, f"c{wi}.{ci}"))
+            o = ot.place_sample(pos, ref, mut, miss)
+            want = (o["score"], o["best_j"], o["num_best"], o["has_unique"])
+            assert m.result(S, rs) == want, (it, q, wi, ci, S)
+            npos = len(m.ix_off) - 1
+            longest = max([int(m.ix_off[p + 1]) - int(m.ix_off[p]) - 1 for (p, _, _, _) in S if p < npos] + [0])
+            if longest >= 2:
+                assert m.result(S, rs, 2) == want, (it, q, "two jobs")
+            assert m.n < len(fv.get("nkey"))          # a crown, not the tree
+            covered += 1
+            levels.add(ci)
+    assert covered > 500 and covered > 0.6 * n and len(levels) >= 3

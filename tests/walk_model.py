@@ -46,7 +46,6 @@ class WalkModel:
         self.max_stack = 0
         self.n_exact = 0
         self.n_segments = 0
-        self.queue_depth = 3      # (k_walk: WALK_QUEUE; small here so that the fuzz drains mid-walk often)
 
     # ---- range queries -------------------------------------------------------------------
     def range_min(self, a, b):
@@ -179,58 +178,34 @@ class WalkModel:
                 if rank < br:
                     br, bhu = rank, hu
 
-        # sub-ranges of constant c that passed the merged pre-test, held back for the exact query (k_walk's per-lane
-        # queue); drained when full and at the end -- `take` is commutative, a late candidate only delays a tighter bs
-        queue = []
-
-        def drain():
-            while queue:
-                a, b, cq = queue.pop()
-                m = self.range_min(a, b)
-                if m != SP_NONE and (m >= SP_CLAMP or m + cq <= bs):
-                    self.n_exact += 1
-                    base, rank, k, hu = self.range_exact(a, b)
-                    if k and base + cq <= bs:
-                        take(base + cq, rank, k, hu)
+        def segment(a, b, entry=None):
+            self.n_segments += 1
+            if self.has_pre and entry is not None:
+                # the range ends at the node of list entry `entry`: its byte stands for a superset of [a, b)
+                pb = int(self.ix_pre_byte[entry])
+                if pb == SP_NONE or (pb < SP_CLAMP and pb + c > bs):
+                    self.n_by_entry += 1
+                    return
+            m = self.range_min(a, b)
+            if m != SP_NONE and (m >= SP_CLAMP or m + c <= bs):
+                self.n_exact += 1
+                base, rank, k, hu = self.range_exact(a, b)
+                if k and base + c <= bs:
+                    take(base + c, rank, k, hu)
 
         while True:
             i_next = min(head) if head else IX_NONE
-            stop = min(i_next, n_end)
-            at_node = i_next < n_end
-            # the intervals that end before the stop are not stops of their own: the lowest c on the way
-            c_run = c_low = c
-            t = len(stack)
-            while t > 0 and stack[t - 1][0] <= stop:
-                c_run -= stack[t - 1][1]
-                c_low = min(c_low, c_run)
-                t -= 1
+            e_next = stack[-1][0] if stack else IX_NONE
+            stop = min(i_next, e_next, n_end)
             if stop > pos:
-                self.n_segments += 1
-                if self.has_pre and at_node:
-                    # the range ends at the node of a list entry: its byte stands for a superset of [pos, stop)
-                    m = int(self.ix_pre_byte[cur[head.index(i_next)]])
-                    self.n_by_entry += 1
-                else:
-                    m = self.range_min(pos, stop)
-                if m != SP_NONE and (m >= SP_CLAMP or m + c_low <= bs):
-                    a, cc = pos, c
-                    for (end, d) in reversed(stack[t:]):          # innermost interval first
-                        if end > a:
-                            if len(queue) == self.queue_depth:
-                                drain()
-                            queue.append((a, end, cc))
-                            a = end
-                        cc -= d
-                    assert cc == c_run
-                    if stop > a:
-                        if len(queue) == self.queue_depth:
-                            drain()
-                        queue.append((a, stop, cc))
-            c = c_run
-            del stack[t:]
-            pos = stop
+                at_node = i_next < e_next and i_next < n_end
+                segment(pos, stop, cur[head.index(i_next)] if at_node else None)
+                pos = stop
             if pos >= n_end:
                 break
+            if e_next <= i_next:
+                c -= stack.pop()[1]
+                continue
             # the node at i_next: every listed mutation it carries
             node = i_next
             key, st = int(self.nkey[node]), int(self.nstat[node])
@@ -268,7 +243,6 @@ class WalkModel:
                 self.max_stack = max(self.max_stack, len(stack))
             c += dsum
             pos = node + 1
-        drain()
         return bs, br, cnt, bhu
 
     def whole_stream(self):

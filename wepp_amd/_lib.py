@@ -63,6 +63,8 @@ class MatStats(ctypes.Structure):
         ("stream_tau", ctypes.c_int32 * 16),
         ("stream_nodes", ctypes.c_uint64 * 16),
         ("stream_bytes_of", ctypes.c_uint64 * 16),
+        ("n_window_crowns", ctypes.c_uint32),
+        ("window_crown_nodes", ctypes.c_uint64),
     ]
 
 
@@ -127,6 +129,7 @@ _SIGS = {
     "wepp_mat_set_pipeline": (ctypes.c_int, [_V, ctypes.c_uint32]),
     "wepp_mat_last_tiers": (ctypes.c_int, [_V, _V, ctypes.c_uint32]),
     "wepp_mat_last_plans": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32]),
+    "wepp_mat_last_crowns": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32]),
     "wepp_mat_last_walk": (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "wepp_mat_timing_reset": (ctypes.c_int, [_V]),
     "wepp_mat_last_timing": (

@@ -16,6 +16,7 @@ A, C, G, T, N = 1, 2, 4, 8, 15  # nucleotide masks, src/mutation_annotated_tree.
 # how a read was placed (include/wepp_place.h WEPP_PLAN_*, Mat.last_plans)
 PLAN_WALK8, PLAN_WALK16, PLAN_SWEEP, PLAN_WALKC8, PLAN_WALKC16, PLAN_WIN = range(6)
 PLAN_NAMES = ("walk8", "walk16", "sweep", "walkc8", "walkc16", "window")
+WINDOW_CROWN_SLOT = 15   # stream slot of the window crowns in Mat.last_plans / last_tiers (Mat.last_crowns tells which crown)
 
 
 def pack_read_word(position, ref_nuc, mut_nuc, is_missing=0):
@@ -502,6 +503,13 @@ class Mat:
         st = np.zeros(int(n_reads), np.uint8)
         check(lib.wepp_mat_last_plans(self._h, _ptr(cls), _ptr(st), int(n_reads)))
         return cls, st
+
+    def last_crowns(self, n_reads):
+        """(window, crown of the window) of every read of the last call that walked a window crown; 255 otherwise."""
+        win = np.zeros(int(n_reads), np.uint8)
+        cr = np.zeros(int(n_reads), np.uint8)
+        check(lib.wepp_mat_last_crowns(self._h, _ptr(win), _ptr(cr), int(n_reads)))
+        return win, cr
 
     def last_walk(self):
         """(reads of the last call placed by the per-read walk, walk loop iterations since timing_reset)."""

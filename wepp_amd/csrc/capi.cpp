@@ -54,6 +54,7 @@ void release(wepp_mat* h) {
     if (h->pipe_compute) (void)hipStreamDestroy(h->pipe_compute);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->d_plan_of) (void)hipFree(h->d_plan_of);
+    if (h->d_wsid_of) (void)hipFree(h->d_wsid_of);
     delete h;
 }
 
@@ -160,6 +161,62 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         h->stats.stream_tau[i] = st.tau;
         h->stats.stream_nodes[i] = st.n;
         h->stats.stream_bytes_of[i] = st.stream_bytes();
+    }
+    // ---- the window crowns' arena: the walk structures of all of them, array by array (device_mat.hpp: WcInfo) ----
+    {
+        std::vector<WcInfo> info(f.wcrowns.size() * WC_MAX);
+        std::vector<IxHead> a_head;
+        std::vector<IxEnt> a_ent;
+        std::vector<uint8_t> a_nest, a_sp;
+        std::vector<NodeRec> a_nrec;
+        std::vector<SegNode> a_pre, a_suf, a_dst;
+        size_t tot_n = 0, tot_ent = 0, tot_head = 0, tot_sp = 0, tot_dst = 0;
+        for (const auto& wc : f.wcrowns)
+            for (const Stream& st : wc) {
+                tot_n += st.n; tot_ent += st.ix_ent.size(); tot_head += st.ix_head.size(); tot_sp += st.sp.size(); tot_dst += st.rq_dst.size();
+            }
+        if (tot_ent >= 0xFFFFFFF0ull || tot_n >= 0xFFFFFFF0ull || tot_head >= 0xFFFFFFF0ull || tot_dst >= 0xFFFFFFF0ull) {
+            release(h);
+            return set_error(WEPP_ELIMIT, "window crowns exceed 2^32 index entries");
+        }
+        a_head.reserve(tot_head); a_ent.reserve(tot_ent); a_nest.reserve(tot_head); a_sp.reserve(tot_sp);
+        a_nrec.reserve(tot_n); a_pre.reserve(tot_n); a_suf.reserve(tot_n); a_dst.reserve(tot_dst);
+        for (size_t w = 0; w < f.wcrowns.size(); w++)
+            for (size_t i = 0; i < f.wcrowns[w].size(); i++) {
+                const Stream& st = f.wcrowns[w][i];
+                WcInfo& wi = info[w * WC_MAX + i];
+                const uint32_t ent_off = (uint32_t)a_ent.size();
+                wi.n = st.n;
+                wi.rq_blocks = st.rq_blocks;
+                wi.last_ent = ent_off + (uint32_t)st.ix_ent.size() - 1;
+                wi.has_pre = st.ix_pre.empty() ? 0u : st.ix_pre[0];
+                wi.node_off = (uint32_t)a_nrec.size();
+                wi.head_off = (uint32_t)a_head.size();
+                wi.nest_off = (uint32_t)a_nest.size();
+                wi.dst_off = (uint32_t)a_dst.size();
+                wi.sp_off = a_sp.size();
+                wi.tau = st.tau;
+                wi.whole = st.whole;
+                for (IxHead hd : st.ix_head) { hd.off += ent_off; a_head.push_back(hd); }
+                for (IxEnt e : st.ix_ent) { if (e.up != IX_NONE) e.up += ent_off; a_ent.push_back(e); }
+                a_nest.insert(a_nest.end(), st.ix_nest.begin(), st.ix_nest.end());
+                a_nrec.insert(a_nrec.end(), st.nrec.begin(), st.nrec.end());
+                a_pre.insert(a_pre.end(), st.rq_pre.begin(), st.rq_pre.end());
+                a_suf.insert(a_suf.end(), st.rq_suf.begin(), st.rq_suf.end());
+                a_dst.insert(a_dst.end(), st.rq_dst.begin(), st.rq_dst.end());
+                a_sp.insert(a_sp.end(), st.sp.begin(), st.sp.end());
+                h->wc_nodes += st.n;
+                h->wc_count++;
+            }
+        DevWalk arena{};                           // (n = 0: never a stream of its own)
+        UP(arena.ix_head, a_head) UP(arena.ix_ent, a_ent) UP(arena.ix_nest, a_nest) UP(arena.nrec, a_nrec)
+        UP(arena.rq_pre, a_pre) UP(arena.rq_suf, a_suf) UP(arena.rq_dst, a_dst) UP(arena.sp, a_sp)
+        UP(d.wc_info, info)
+        d.wc_windows = (uint32_t)f.wcrowns.size();
+        h->stats.n_window_crowns = h->wc_count;
+        h->stats.window_crown_nodes = h->wc_nodes;
+        h->walks.resize(MAX_STREAMS, DevWalk{});
+        h->walks[WC_SLOT] = arena;
     }
     UP(d.walks, h->walks)
 #undef UP
@@ -272,8 +329,10 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     if (plan_total > mat->plan_of_bytes) {
         // (only ever at the first sub-batch of a call: plan_total is the whole call's)
         if (mat->d_plan_of) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->d_plan_of); mat->d_plan_of = nullptr; mat->plan_of_bytes = 0; }
+        if (mat->d_wsid_of) { (void)hipFree(mat->d_wsid_of); mat->d_wsid_of = nullptr; }
         const size_t need = (size_t)plan_total + plan_total / 4 + 256;
         hipError_t e = hipMalloc((void**)&mat->d_plan_of, need);
+        if (e == hipSuccess) e = hipMalloc((void**)&mat->d_wsid_of, need * 4);
         if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc plan ids: ") + hipGetErrorString(e));
         mat->plan_of_bytes = need;
     }
@@ -300,7 +359,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     size_t sort_temp = 0;
     if (sort_reads) HIP_TRY(sort_reads_temp_bytes(n_reads, &sort_temp));
     sort_temp = (sort_temp + 255) & ~(size_t)255;
-    // fixed part of the workspace: tier | list | root_score | slot in block | jobs | sort keys in/out | sorted lists |
+    // fixed part of the workspace: list | root_score | slot in block | jobs | sort keys in/out | sorted lists |
     // sort temp of the whole-tree plan and of the four walk classes (their sorts run on different side streams)
     constexpr uint32_t N_SORTS = 5;
     const size_t fixed_bytes = tier_bytes + 4 * list_bytes + (sort_reads ? 3 * list_bytes + N_SORTS * sort_temp : 0);
@@ -312,6 +371,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     uint8_t* tier_of = nullptr;
     uint32_t *list = nullptr, *slot_in_blk = nullptr, *key_in = nullptr, *key_out = nullptr, *val_in = nullptr;
     uint32_t* job_n = nullptr;       // jobs of every read whose walk is cut into chunks (k_route)
+    uint32_t* wsid = nullptr;        // the window crown (index into DevMAT::wc_info) of every read routed to slot WC_SLOT
     int32_t* root_score = nullptr;
     void* sort_tmp = nullptr;
     auto carve = [&]() {
@@ -321,6 +381,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         root_score = (int32_t*)p; p += list_bytes;
         slot_in_blk = (uint32_t*)p; p += list_bytes;
         job_n = (uint32_t*)p; p += list_bytes;
+        wsid = mat->d_wsid_of + plan_base;
         if (sort_reads) {
             key_in = (uint32_t*)p; p += list_bytes;
             key_out = (uint32_t*)p; p += list_bytes;
@@ -346,7 +407,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         tier_info = mat->d_info + mat->info_idx * TI_WORDS;
         uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
         HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, stack8, stack16, job_n, tier_of, root_score, blk_counts,
-                             tier_info, slot_in_blk, tier_info_next, stream));
+                             tier_info, slot_in_blk, tier_info_next, wsid, stream));
         mat->info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
         return WEPP_OK;
@@ -388,8 +449,12 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
         const uint32_t t = plan_index(id), cls = plan_class(id);
-        if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : t >= ns))
-            return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+        {
+            // (slot WC_SLOT of a walk class = the window crowns: one plan, a crown per read)
+            const bool walk_cls = cls == PLAN_WALK8 || cls == PLAN_WALK16 || cls == PLAN_WALKC8 || cls == PLAN_WALKC16;
+            if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : (t >= ns && !(walk_cls && t == WC_SLOT && mat->dev.wc_windows))))
+                return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+        }
         if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
             // the reads with many events: their walks are cut into jobs (below); the plans of a chunked class
             // are the streams, the jobs of stream t numbered behind those of the streams before it
@@ -580,7 +645,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             if (sorted)
                 for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = val_in + walk_off[cls][k];
             HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
-                                d_num_best, d_flags, mat->d_work, q));
+                                d_num_best, d_flags, mat->d_work, wsid, q));
         }
         if (fork) {
             HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
@@ -637,7 +702,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 bytes += (uint64_t)R3 * (12 + 8 + 12 + 16) + (uint64_t)J * 12;
                 HIP_TRY(launch_gather_jobs(list3, R3, job_n, jcnt, q));
                 HIP_TRY(launch_exclusive_scan_u32(jcnt, joff, R3, jtmp, scan_temp[cc], q));
-                HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, info[TI_OPEN + 2 + cc], jb, d_read_off, d_read_word, root_score, mat->d_work, q));
+                HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, info[TI_OPEN + 2 + cc], jb, d_read_off, d_read_word, root_score, mat->d_work, wsid, q));
                 HIP_TRY(launch_finalize_jobs(mat->dev, list3, R3, jb, d_read_off, d_read_word, d_best_bfs_j, d_score,
                                              d_num_best, d_flags, q));
                 if (fork) {
@@ -1248,7 +1313,7 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
     uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
     HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
-                         d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, nullptr));
+                         d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, nullptr));
     mat->info_idx ^= 1u;
     HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
     HIP_TRY(hipMemcpy(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1304,6 +1369,25 @@ extern "C" int wepp_mat_last_plans(wepp_mat_t* mat, uint8_t* plan_class_out, uin
         const uint32_t id = plan_stream_out[r];
         plan_class_out[r] = (uint8_t)plan_class(id);
         plan_stream_out[r] = (uint8_t)plan_index(id);
+    }
+    return WEPP_OK;
+}
+
+// diagnostic: the window crown (window, crown of the window) of every read of the last call that walked one
+extern "C" int wepp_mat_last_crowns(wepp_mat_t* mat, uint8_t* window_out, uint8_t* crown_out, uint32_t n_reads) {
+    if (!mat || !window_out || !crown_out) return set_error(WEPP_EINVAL, "null argument");
+    if (n_reads != mat->last_n_reads || !mat->d_plan_of)
+        return set_error(WEPP_EINVAL, "n_reads differs from the handle's last placement call");
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> sid(n_reads);
+    std::vector<uint8_t> plan(n_reads);
+    HIP_TRY(hipMemcpy(sid.data(), mat->d_wsid_of, (size_t)n_reads * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(plan.data(), mat->d_plan_of, n_reads, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const bool in_arena = plan_class(plan[r]) != PLAN_WIN && plan_class(plan[r]) != PLAN_SWEEP && plan_index(plan[r]) == WC_SLOT;
+        window_out[r] = in_arena ? (uint8_t)(sid[r] / WC_MAX) : (uint8_t)255;
+        crown_out[r] = in_arena ? (uint8_t)(sid[r] % WC_MAX) : (uint8_t)255;
     }
     return WEPP_OK;
 }

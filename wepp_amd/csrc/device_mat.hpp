@@ -54,6 +54,20 @@ struct DevWalk {
     const uint8_t* sp;
 };
 
+// One window crown (flatmat.hpp: wcrowns) inside the ARENA: the walk structures of all window crowns are
+// concatenated, array by array (the DevWalk of slot WC_SLOT holds the arena's base pointers), and a crown is the
+// offsets of its slices.  Entry indices (ix_head::off, IxEnt::up) are absolute in the arena; node indices are local.
+// Which crown a read walks is a per-READ value (k_route), so a wave of the slot's plans holds lanes of different
+// crowns: k_walk keeps these numbers per lane.
+struct WcInfo {
+    uint32_t n, rq_blocks, last_ent, has_pre;     // n == 0: no such crown
+    uint32_t node_off, head_off, nest_off, dst_off;   // into nrec / rq_pre / rq_suf, ix_head, ix_nest, rq_dst
+    unsigned long long sp_off;                    // into sp
+    int32_t tau;
+    uint32_t pad;
+    SegNode whole;
+};
+
 // tree-wide arrays (global DFS indices)
 struct DevMAT {
     uint32_t N, bm_words, max_pos, n_streams;
@@ -70,7 +84,9 @@ struct DevMAT {
     const uint32_t* bfs2dfs;      // inverse of dfs2bfs
     const uint32_t* parent_dfs;   // DFS index of the parent (root: 0)
     const uint8_t* maxnest;       // [max_pos + 1] most mutations at one position along a root path
-    const DevWalk* walks;         // [n_streams] device array
+    const DevWalk* walks;         // [MAX_STREAMS] device array: the streams' walk structures; [WC_SLOT] = the window crowns' arena
+    const WcInfo* wc_info;        // [wc_windows * WC_MAX] the window crowns of every genome window, increasing tau
+    uint32_t wc_windows;          // 0: none built
 };
 
 // A placement call sorts its reads into PLANS: plan id = class * MAX_STREAMS + stream, the windows' plans behind
@@ -105,7 +121,6 @@ constexpr uint32_t WALK_JOB_EVENTS_MAX = 256, WALK_TARGET_JOBS = 1u << 20;
 // Measured (16 M nodes, 1 M reads with 5 % N): rows 16/32 -> 12/20 (2 -> 3.5 waves per SIMD for the 16-entry
 // class) 21.5 -> 19.9 ms, nothing on the other legs: the walks are not short of waves.
 constexpr uint32_t WALK_WAVES = 2;         // waves per workgroup of k_walk (their LDS regions are private)
-constexpr uint32_t WALK_QUEUE = 6;         // sub-ranges a lane can hold back for the exact query before the wave drains them (k_walk)
 constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of a launch runs on XCD b % 8
 // waves of a walk plan are padded to a multiple of this, so that every plan starts at a workgroup index that is a
 // multiple of the XCD count and its waves can be dealt to the XCDs in contiguous runs (k_walk)
@@ -141,12 +156,12 @@ struct WalkPlans {
 // cls = 0 / 1: the plans of one class in ONE launch, a wave = 64 reads; writes the final per-read results
 hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
                        const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream);
+                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
-                            hipStream_t stream);
+                            const uint32_t* wsid, hipStream_t stream);
 hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t n_list, const WalkJobs& jb,
                                 const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t* best_bfs_j,
                                 int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
@@ -178,7 +193,7 @@ constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chain
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
                         uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, hipStream_t stream);
+                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, uint32_t* wsid, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
 constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less than the sort
@@ -186,7 +201,7 @@ constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less tha
 // of the index -- then sit in neighbouring lanes and waves, and a wave's gathers hit lines its neighbours have just
 // brought into the L2 instead of opening a DRAM row each.  Key = stream << SORT_KEY_BITS | position + 1.
 constexpr uint32_t WALK_SORT_KEY_BITS = SORT_KEY_BITS + 4;
-constexpr uint32_t WALK_SORT_MIN_READS = 2048;   // a class with fewer reads keeps the caller's order (the sort is ~8 launches)
+constexpr uint32_t WALK_SORT_MIN_READS = 32768;  // a class with fewer reads keeps the caller's order (the sort is ~8 launches on its chain: 50 us of a 0.3 ms step)
 static_assert(MAX_STREAMS <= 16, "stream index in the walks' sort key");
 hipError_t launch_first_pos(const uint32_t* list, uint32_t n, const uint32_t* d_read_off, const uint32_t* d_read_word,
                             uint32_t* keys, hipStream_t stream);

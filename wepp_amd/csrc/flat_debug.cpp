@@ -39,6 +39,24 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
         *elem_bytes = (uint32_t)sizeof(obj.n[0]);                       \
         return WEPP_OK;                                                 \
     }
+    // window crowns: "wc_tau" / "wc_nodes" = [windows x WC_MAX] tau (INT32_MAX: none) and node count of every crown
+    if (std::strcmp(name, "wc_tau") == 0 || std::strcmp(name, "wc_nodes") == 0) {
+        wepp_flat* self = const_cast<wepp_flat*>(flat);
+        if (self->wc_tau.empty()) {
+            self->wc_tau.assign(f.wcrowns.size() * wepp::WC_MAX, 0x7FFFFFFF);
+            self->wc_nodes.assign(f.wcrowns.size() * wepp::WC_MAX, 0);
+            for (size_t w = 0; w < f.wcrowns.size(); w++)
+                for (size_t i = 0; i < f.wcrowns[w].size(); i++) {
+                    self->wc_tau[w * wepp::WC_MAX + i] = f.wcrowns[w][i].tau;
+                    self->wc_nodes[w * wepp::WC_MAX + i] = f.wcrowns[w][i].n;
+                }
+        }
+        const bool tau = name[3] == 't';
+        *data = tau ? (const void*)self->wc_tau.data() : (const void*)self->wc_nodes.data();
+        *count = self->wc_tau.size();
+        *elem_bytes = 4;
+        return WEPP_OK;
+    }
     size_t si = f.streams.size() - 1;
     if (name[0] >= '0' && name[0] <= '9' && std::strchr(name, ':')) {
         si = (size_t)std::strtoul(name, nullptr, 10);
@@ -55,7 +73,16 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
         name = std::strchr(name, ':') + 1;
         if (si >= f.wstreams.size()) return wepp::set_error(WEPP_EINVAL, "window stream index out of range");
     }
-    const wepp::Stream& st = win ? f.wstreams[si] : f.streams[si];
+    // "c<w>.<i>:" selects crown i of genome window w (flatmat.hpp: wcrowns)
+    const bool wcr = name[0] == 'c' && name[1] >= '0' && name[1] <= '9' && std::strchr(name, '.') && std::strchr(name, ':');
+    size_t ci = 0;
+    if (wcr) {
+        si = (size_t)std::strtoul(name + 1, nullptr, 10);
+        ci = (size_t)std::strtoul(std::strchr(name, '.') + 1, nullptr, 10);
+        name = std::strchr(name, ':') + 1;
+        if (si >= f.wcrowns.size() || ci >= f.wcrowns[si].size()) return wepp::set_error(WEPP_EINVAL, "window crown index out of range");
+    }
+    const wepp::Stream& st = wcr ? f.wcrowns[si][ci] : win ? f.wstreams[si] : f.streams[si];
     FIELD(st, ncnt)
     FIELD(st, nkey) FIELD(st, nstat) FIELD(st, blk_node0) FIELD(st, blk_eoff) FIELD(st, blk_sum) FIELD(st, ev_word)
     FIELD(st, ev_meta) FIELD(st, ev_lb) FIELD(st, cp_off) FIELD(st, cp_word)
@@ -79,6 +106,8 @@ extern "C" int wepp_flat_scalars(const wepp_flat_t* flat, wepp_mat_stats* stats,
         stats->max_position = f.max_pos;
         stats->stream_bytes = f.full().stream_bytes();
         stats->n_streams = (uint32_t)f.streams.size();
+        for (const auto& wc : f.wcrowns)
+            for (const wepp::Stream& st : wc) { stats->n_window_crowns++; stats->window_crown_nodes += st.n; }
         for (size_t i = 0; i < f.streams.size(); i++) {
             stats->stream_tau[i] = f.streams[i].tau;
             stats->stream_nodes[i] = f.streams[i].n;

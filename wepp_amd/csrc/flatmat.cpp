@@ -22,6 +22,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 
 namespace wepp {
 
@@ -309,7 +310,8 @@ int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::
 }
 
 // a crown (or the whole tree): the ancestor-closed node subset `sel` (sorted global DFS indices, sel[0] == 0)
-int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err) {
+int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err,
+                 uint32_t pos_lo = 0, uint32_t pos_hi = 0xFFFFFFFFu) {
     const uint32_t n = (uint32_t)sel.size();
     const uint32_t N = f.N;
     // number of selected nodes with global index <= g
@@ -323,6 +325,8 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
     }
     StreamElems el;
     el.g = sel;
+    el.pos_lo = pos_lo;          // (a window crown indexes the mutations of its window only)
+    el.pos_hi = pos_hi;
     el.nkey.resize(n); el.nstat.resize(n); el.cnt.assign(n, 1); el.min_all.resize(n); el.lend.resize(n); el.lpar.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t g = sel[i];
@@ -555,6 +559,17 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
     f.maxnest.assign((size_t)max_pos + 1, 0);
     std::vector<int32_t> D0(N, 0);
     std::vector<int32_t> base(N, 0);
+    // window crowns (flatmat.hpp): inw[w] = positions of window w at which the current path's genotype differs from
+    // the reference; cand[w] = the nodes with out_w <= root score + WC_MAX_DTAU, in DFS order, with their out_w
+    const uint32_t n_win = (!topology_only && max_pos + 1 > WIN_STRIDE) ? std::min<uint32_t>(MAX_WINDOWS, (max_pos + WIN_STRIDE) / WIN_STRIDE) : 0u;
+    std::vector<int32_t> inw(n_win, 0), inw_e(n_win, 0), inw_par(n_win, 0);
+    std::vector<std::vector<std::pair<uint32_t, int32_t>>> cand(n_win);
+    // the windows [w * WIN_STRIDE, w * WIN_STRIDE + WIN_SIZE) that hold position p
+    auto windows_of = [&](uint32_t p, auto&& fn) {
+        const uint32_t hi = std::min(n_win, p / WIN_STRIDE + 1);
+        const uint32_t lo = p + 1 > WIN_SIZE ? (p + 1 - WIN_SIZE + WIN_STRIDE - 1) / WIN_STRIDE : 0u;
+        for (uint32_t w = lo; w < hi; w++) fn(w);
+    };
     {
         std::vector<uint32_t> open;           // stack of open nodes (DFS idx)
         open.reserve(f.max_depth + 2);
@@ -564,8 +579,13 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
                 uint32_t x = open.back();
                 open.pop_back();
                 for (uint32_t w = f.node_woff[x + 1]; w > f.node_woff[x]; w--) {
-                    state[f.words[w - 1] & W_POS_MASK] = undo[w - 1];
-                    if (nest[f.words[w - 1] & W_POS_MASK] != 255) nest[f.words[w - 1] & W_POS_MASK]--;
+                    const uint32_t p = f.words[w - 1] & W_POS_MASK;
+                    if (n_win) {
+                        const int32_t dl = (int32_t)cost0(state[p], refm[p]) - (int32_t)cost0(undo[w - 1], refm[p]);
+                        if (dl) windows_of(p, [&](uint32_t wi) { inw[wi] -= dl; });
+                    }
+                    state[p] = undo[w - 1];
+                    if (nest[p] != 255) nest[p]--;
                 }
             }
             uint32_t id = f.dfs2id[d];
@@ -573,6 +593,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             int32_t dcur = dpar;
             uint32_t nback_cost = 0, ncommon0 = 0;
             uint32_t w = f.node_woff[d];
+            if (n_win) { inw_par = inw; inw_e = inw; }     // the parent genotype's counts; own back-mutations are taken off inw_e below
             for (uint32_t k = t.mut_off[id]; k < t.mut_off[id + 1]; k++) {
                 int32_t p = t.mut_pos[k];
                 if (p < 0) continue;
@@ -587,6 +608,11 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
                 f.maxnest[p] = std::max(f.maxnest[p], nest[p]);
                 dcur += (int32_t)cost0(mut, ref) - (int32_t)cost0(par, ref);
                 if (mut == ref) { ncommon0++; nback_cost += cost0(par, ref); }
+                if (n_win) {
+                    const int32_t dl = (int32_t)cost0(mut, ref) - (int32_t)cost0(par, ref);
+                    const bool back = mut == ref && cost0(par, ref);
+                    if (dl || back) windows_of((uint32_t)p, [&](uint32_t wi) { inw[wi] += dl; if (back) inw_e[wi]--; });
+                }
                 w++;
             }
             D0[d] = dcur;
@@ -607,6 +633,15 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
                 else elig0 = (ncommon0 > 0) || (ncommon0 == nmut);
             }
             f.nstat[d] = st | (nmut & NS_CNT_MASK) | ((ncommon0 & NS_CNT_MASK) << 14) | (elig0 ? NS_ELIG0 : 0);
+            if (n_win && d) {
+                // out_w(d) = base(d) minus the window's share of it (a masked node is scored on its parent's genotype
+                // as it stands: none of its back-mutations counts, inside or outside the window)
+                const int32_t lim = base[0] + (int32_t)WC_MAX_DTAU;
+                for (uint32_t wi = 0; wi < n_win; wi++) {
+                    const int32_t out = base[d] - (masked ? inw_par[wi] : inw_e[wi]);
+                    if (out <= lim) cand[wi].emplace_back(d, out);
+                }
+            }
             open.push_back(d);
         }
     }
@@ -643,7 +678,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
         size_t prev = 0;
         for (int32_t dtau : dtaus) {
             const int32_t tau = f.root_base + dtau;
-            if (f.streams.size() + 1 >= MAX_STREAMS) break;
+            if (f.streams.size() + 2 >= MAX_STREAMS) break;     // (the last slot belongs to the window crowns)
             for (uint32_t d = 0; d < N; d++) keep[d] = base[d] <= tau;
             keep[0] = 1;
             for (uint32_t d = N; d-- > 1;)
@@ -676,6 +711,58 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             int rc = build_window_stream(f, wi * WIN_STRIDE, wi * WIN_STRIDE + WIN_SIZE, f.wstreams[wi], err);
             if (rc != WEPP_OK) return rc;
         }
+    }
+
+    // ---- window crowns (flatmat.hpp): per genome window, the nodes with out_w <= tau and their ancestors --------
+    if (n_win) {
+        f.wcrowns.assign(n_win, {});
+        std::vector<std::string> errs(n_win);
+        std::vector<int> rcs(n_win, WEPP_OK);
+        auto build_window = [&](uint32_t wi, std::vector<uint8_t>& mark) {
+            // the crowns of a window nest: the marks stay from one tau to the next
+            std::vector<uint32_t> sel(1, 0u);
+            mark[0] = 1;
+            size_t prev = 0, at = 0;
+            const auto& cw = cand[wi];
+            std::vector<std::pair<int32_t, uint32_t>> by_out(cw.size());
+            for (size_t i = 0; i < cw.size(); i++) by_out[i] = {cw[i].second, cw[i].first};
+            std::sort(by_out.begin(), by_out.end());
+            for (uint32_t dt = 0; dt <= WC_MAX_DTAU && f.wcrowns[wi].size() < WC_MAX; dt++) {
+                const int32_t tau = f.root_base + (int32_t)dt;
+                for (; at < by_out.size() && by_out[at].first <= tau; at++)
+                    for (uint32_t d = by_out[at].second; !mark[d]; d = f.parent_dfs[d]) { mark[d] = 1; sel.push_back(d); }
+                if (sel.size() > WC_MAX_NODES || sel.size() * 4 > N) break;         // (the tree-wide crowns take over)
+                if (prev && sel.size() < prev + prev / 4 && dt < WC_MAX_DTAU) continue;   // too close to the previous one
+                std::sort(sel.begin(), sel.end());
+                f.wcrowns[wi].emplace_back();
+                Stream& st = f.wcrowns[wi].back();
+                st.tau = tau;
+                rcs[wi] = build_stream(f, sel, st, errs[wi], wi * WIN_STRIDE, wi * WIN_STRIDE + WIN_SIZE);
+                if (rcs[wi] != WEPP_OK) break;
+                prev = sel.size();
+            }
+            for (uint32_t d : sel) mark[d] = 0;
+        };
+        const uint32_t nthr = std::max(1u, std::min<uint32_t>({n_win, 8u, std::thread::hardware_concurrency()}));
+        std::atomic<uint32_t> next{0};
+        auto worker = [&]() {
+            uint32_t wi = 0;
+            try {
+                std::vector<uint8_t> mark(N, 0);
+                for (; (wi = next.fetch_add(1)) < n_win;) build_window(wi, mark);
+            } catch (const std::bad_alloc&) {          // (an exception must not leave a worker thread)
+                if (wi < n_win) { rcs[wi] = WEPP_ENOMEM; errs[wi] = "out of host memory while building the window crowns"; }
+                else { rcs[0] = WEPP_ENOMEM; errs[0] = "out of host memory while building the window crowns"; }
+            }
+        };
+        if (nthr == 1) worker();
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t i = 0; i < nthr; i++) th.emplace_back(worker);
+            for (auto& x : th) x.join();
+        }
+        for (uint32_t wi = 0; wi < n_win; wi++)
+            if (rcs[wi] != WEPP_OK) { err = errs[wi]; return rcs[wi]; }
     }
 
     // ---- EPP event stream (see flatmat.hpp) -----------------------------------------

@@ -174,6 +174,16 @@ struct FlatMAT {
     std::vector<Stream> streams;
     // wstreams[w] = the whole tree as the reads of genome window [w * WIN_STRIDE, w * WIN_STRIDE + WIN_SIZE) see it
     std::vector<Stream> wstreams;
+    // wcrowns[w] = WINDOW CROWNS of genome window w, increasing tau (at most WC_MAX): the nodes n whose score for ANY
+    // read confined to the window is at least out_w(n) <= tau -- out_w(n) = the positions OUTSIDE the window at which
+    // the genotype n is scored against (its parent's, with n's own back-mutations applied) differs from the
+    // reference: a read that lists nothing there pays one for each, whatever it lists inside the window -- plus
+    // their ancestors.  A read of the window whose root score is r can only be placed on a node with out_w <= r, so
+    // the crown with tau >= r holds every node that can win or tie: the bound is r itself, not r + |S| as for the
+    // tree-wide crowns above (every listed position may lower a score by one there) -- an N-rich read, whose Ns cost
+    // it nothing at the root, walks a crown of a few hundred nodes instead of one of a million.  Only the walk index
+    // of these streams is used (positions of the window only); node indices are local, ranks global, as in `streams`.
+    std::vector<std::vector<Stream>> wcrowns;
     // EPP event stream (epp_kernels.hip): every non-masked mutation twice, in the order a
     // pre-order walk applies and retracts it -- enter words when its node is entered, the same
     // words with W_EXIT once the node's subtree is done.  epp_node[i] = number of nodes
@@ -189,6 +199,10 @@ struct FlatMAT {
 // amplicon) lies inside the window that starts at its first position rounded down to the stride
 constexpr uint32_t WIN_SIZE = 2560, WIN_STRIDE = 1024, MAX_WINDOWS = 32;
 constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of wepp_mat_stats
+// window crowns: at most WC_MAX per window, tau = root score + 0 .. WC_MAX_DTAU, none larger than WC_MAX_NODES nodes;
+// in plan ids and diagnostics they all share ONE stream slot, the last one (the tree-wide streams use at most
+// MAX_STREAMS - 1 slots): which window crown a read walks is a per-read value (k_route)
+constexpr uint32_t WC_MAX = 6, WC_MAX_DTAU = 5, WC_MAX_NODES = 1u << 19, WC_SLOT = MAX_STREAMS - 1;
 
 // flatten_tree calls of this process that built the full image (not topology_only): lets a test see that a
 // multi-device run flattened once
@@ -204,4 +218,6 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& out, std::string& err, bool t
 // of devices (wepp_mat_upload) and inspected by the CPU tests (wepp_flat_get)
 struct wepp_flat {
     wepp::FlatMAT f;
+    std::vector<int32_t> wc_tau;       // (wepp_flat_get "wc_tau" / "wc_nodes": filled at the first request)
+    std::vector<uint32_t> wc_nodes;
 };

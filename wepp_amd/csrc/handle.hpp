@@ -22,6 +22,8 @@ struct wepp_mat {
     DevMAT dev{};
     std::vector<DevStream> streams;
     std::vector<DevWalk> walks;       // position index + range-query structures of every stream (k_walk)
+    uint64_t wc_nodes = 0;            // nodes of all window crowns (the arena of slot WC_SLOT)
+    uint32_t wc_count = 0;            // window crowns built
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
     uint32_t job_events[2] = {WALK_JOB_EVENTS, WALK_JOB_EVENTS};   // events per job of the chunked classes in the next call
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
@@ -66,6 +68,7 @@ struct wepp_mat {
     size_t pin_out_bytes = 0;
     // plan id of every read of the most recent placement call (k_route writes it; wepp_mat_last_tiers / _plans read it);
     // grow-only, outside the workspace so that the sub-batches of one host call add up to the whole call's picture
+    uint32_t* d_wsid_of = nullptr;    // window crown (index into DevMAT::wc_info) of the reads routed to slot WC_SLOT, same sizing
     uint8_t* d_plan_of = nullptr;
     size_t plan_of_bytes = 0;
     // grow-only workspace: tier of each read, read list, routing counters, partial results

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           uint32_t* __restrict__ blk_counts,
                                                           uint32_t* __restrict__ tier_info,
                                                           uint32_t* __restrict__ slot_in_blk,
-                                                          uint32_t* __restrict__ tier_info_next) {
+                                                          uint32_t* __restrict__ tier_info_next,
+                                                          uint32_t* __restrict__ wsid) {
     __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
@@ -253,10 +254,10 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         // A walk runs a read's events one after the other: reads with many events in their stream (a
         // frequently mutated position) are left to the sweeps, whose cost does not depend on it.
         uint32_t cls = PLAN_SWEEP;
-        if (walk_max_events && k <= WALK16_K) {
+        // how a read with at most WALK16_K entries would walk a stream whose position index starts at (ix_head,
+        // ix_nest): plain, cut into jobs, or not at all (more open intervals than a walk's stack holds)
+        auto classify = [&](const IxHead* ix_head, const uint8_t* ix_nest, uint32_t& nj_out, uint32_t& open_out, uint32_t& ev_out) -> uint32_t {
             uint32_t open_max = 0, events = 0, longest = 0;
-            const IxHead* ix_head = m.walks[t].ix_head;
-            const uint8_t* ix_nest = m.walks[t].ix_nest;
             for (uint32_t j = 0; j < k; j++) {
                 const uint32_t p = w_pos(j < 2 ? fw[u][j] : read_word[so + j]);
                 if (p <= m.max_pos) {
@@ -266,19 +267,53 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                     longest = max(longest, len);
                 }
             }
+            open_out = open_max;
+            ev_out = events;
+            nj_out = 0;
             // (stack8 <= WALK8_STACK, stack16 <= WALK16_STACK: the stack rows the walks' workgroups get; the few
             // reads that could hold more intervals open are left to the sweeps)
             if (events <= walk_max_events) {
-                if (k <= WALK8_K && open_max <= stack8) cls = PLAN_WALK8;
-                else if (open_max <= stack16) cls = PLAN_WALK16;
+                if (k <= WALK8_K && open_max <= stack8) return PLAN_WALK8;
+                if (open_max <= stack16) return PLAN_WALK16;
+                return PLAN_SWEEP;
+            }
+            if (open_max > stack16) return PLAN_SWEEP;
+            // many events: jobs of about `job_events`, cut at quantiles of the longest list
+            const uint32_t small = (k <= WALK8_K && open_max <= stack8) ? 1u : 0u;
+            const uint32_t je = small ? (job_events & 0xFFFFu) : (job_events >> 16);   // (per class, capi.cpp)
+            nj_out = min((events + je - 1) / je, longest);
+            return small ? PLAN_WALKC8 : PLAN_WALKC16;
+        };
+        if (walk_max_events && k <= WALK16_K) {
+            uint32_t nj = 0, open_max = 0, events = 0;
+            // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
+            // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
+            uint32_t sid = NONE;
+            if (use_crowns && k > 0 && m.wc_windows) {
+                const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
+                const uint32_t wi = p_lo / WIN_STRIDE;
+                if (wi < m.wc_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) {
+                    const int rs = m.root_base + c;
+                    for (uint32_t i = 0; i < WC_MAX; i++) {
+                        const WcInfo* q = m.wc_info + wi * WC_MAX + i;
+                        const uint32_t qn = q->n;
+                        if (!qn) break;
+                        if (rs <= q->tau) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
+                    }
+                }
+            }
+            if (sid != NONE) {
+                const WcInfo* q = m.wc_info + sid;
+                const DevWalk& ar = m.walks[WC_SLOT];
+                cls = classify(ar.ix_head + q->head_off, ar.ix_nest + q->nest_off, nj, open_max, events);
+                if (cls != PLAN_SWEEP) { wsid[r] = sid; t = WC_SLOT; }
+            }
+            if (cls == PLAN_SWEEP) cls = classify(m.walks[t].ix_head, m.walks[t].ix_nest, nj, open_max, events);
+            if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
                 // the deepest stack a walk of the class can need in this call: its kernel's LDS request
-                if (cls != PLAN_SWEEP) atomicMax(&open_of[cls], open_max);
-            } else if (open_max <= stack16) {
-                // many events: jobs of about `job_events`, cut at quantiles of the longest list
-                const uint32_t small = (k <= WALK8_K && open_max <= stack8) ? 1u : 0u;
-                cls = small ? PLAN_WALKC8 : PLAN_WALKC16;
-                const uint32_t je = small ? (job_events & 0xFFFFu) : (job_events >> 16);   // (per class, capi.cpp)
-                const uint32_t nj = min((events + je - 1) / je, longest);
+                atomicMax(&open_of[cls], open_max);
+            } else if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
+                const uint32_t small = cls == PLAN_WALKC8 ? 1u : 0u;
                 job_n[r] = nj;
                 atomicAdd(&events_of[small ? 0 : 1], events);
                 atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
@@ -1301,7 +1336,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                                               const uint32_t* __restrict__ read_word,
                                               const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
                                               int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best,
-                                              uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter) {
+                                              uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter,
+                                              const uint32_t* __restrict__ wsid) {
     // wave-private LDS: the allele fields of the read words, 16 bits each [KW / 2][64]; the list cursors [KW][64];
     // the interval stack [sd_rows][64] -- sd_rows = the deepest stack a read of this launch can need (k_route's
     // maximum of open_max over the class, <= SD).  The walk waits on memory: what it gains from a wave more
@@ -1309,7 +1345,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     extern __shared__ uint32_t lds_all[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t* S16 = lds_all + wv * (KW / 2 + KW + sd_rows + 2 * WALK_QUEUE) * 64;
+    uint32_t* S16 = lds_all + wv * (KW / 2 + KW + sd_rows) * 64;
     uint32_t* cur_l = S16 + (KW / 2) * 64;
     uint32_t* stk = cur_l + KW * 64;
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
@@ -1383,6 +1419,18 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     const uint32_t so = have ? read_off[rd] : 0u;
     const uint32_t k = have ? read_off[rd + 1] - so : 0u;
     const int root_sc = have ? root_score[rd] : 0;
+    // The stream's numbers, per LANE: the plans of slot WC_SLOT hold reads of different window crowns (k_route picked
+    // one per read: wsid), whose structures are slices of the arena the slot's DevWalk points at (device_mat.hpp:
+    // WcInfo); on every other plan the offsets are zero and the numbers the plan's own.
+    uint32_t L_n = ix.n, L_rqb = ix.rq_blocks, L_last = ix.last_ent, L_pre = ix.has_pre, L_node = 0, L_head = 0, L_dst = 0;
+    size_t L_sp = 0;
+    SegNode L_whole = ix.whole;
+    if (q.tier == WC_SLOT && have) {
+        const WcInfo wi = m.wc_info[wsid[rd]];
+        L_n = wi.n; L_rqb = wi.rq_blocks; L_last = wi.last_ent; L_pre = wi.has_pre; L_node = wi.node_off; L_head = wi.head_off;
+        L_dst = wi.dst_off; L_sp = (size_t)wi.sp_off; L_whole = wi.whole;
+        lane_bytes += 4 + 64;
+    }
     // list entry, two offsets, root score; per listed position its word and list head (chunked: also the next head)
     if (have) lane_bytes += (CHUNKED ? 0u : 4u) + 8u + 4u + k * (CHUNKED ? 20u : 12u);
 
@@ -1399,13 +1447,13 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             const uint32_t w = read_word[so + j];
             const uint32_t p = w_pos(w);
             // a position beyond the tree's last mutated one has no list: the last sentinel stands in
-            IxHead h{ix.last_ent, NONE};
-            if (p <= m.max_pos) h = ix.ix_head[p];
+            IxHead h{L_last, NONE};
+            if (p <= m.max_pos) h = ix.ix_head[L_head + p];
             const uint32_t e = h.off;
             s9 = (w >> 20) & 0x1FFu;
             cur_l[j * 64 + lane] = e;
             if (CHUNKED) {
-                const uint32_t len = p <= m.max_pos ? ix.ix_head[p + 1].off - e - 1u : 0u;
+                const uint32_t len = p <= m.max_pos ? ix.ix_head[L_head + p + 1].off - e - 1u : 0u;
                 if (len > long_len) { long_len = len; long_off = e; }
             } else {
                 head[j] = h.first_node;
@@ -1416,7 +1464,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
         else s_pair = s9;
     }
     WALK_STAMP(2);          // words and list heads staged
-    uint32_t n = ix.n;              // one past the last node this lane looks at
+    uint32_t n = L_n;               // one past the last node this lane looks at
     uint32_t pos = 0;               // next node nobody has looked at
     uint32_t sp = 0;                // open intervals on the stack
     uint32_t top_end = NONE;
@@ -1440,7 +1488,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                 if (j0 + u < k && mid_stream) {
                     const uint32_t p = w_pos(read_word[so + j0 + u]);
                     lo[u] = cur_l[(j0 + u) * 64 + lane];
-                    hi[u] = p <= m.max_pos ? ix.ix_head[p + 1].off - 1u : lo[u];       // (the sentinel stays out)
+                    hi[u] = p <= m.max_pos ? ix.ix_head[L_head + p + 1].off - 1u : lo[u];       // (the sentinel stays out)
                     lane_bytes += 4 + 4;
                 }
             }
@@ -1523,84 +1571,18 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
 #pragma unroll
         for (int j = 1; j < KW; j++) any = min(any, head[j]);
         if (pos < n && any == NONE) {
-            if (ix.whole.cnt && ix.whole.base + c <= bs) take(ix.whole.base + c, ix.whole.rank, ix.whole.cnt, ix.whole.hu);
+            if (L_whole.cnt && L_whole.base + c <= bs) take(L_whole.base + c, L_whole.rank, L_whole.cnt, L_whole.hu);
             pos = n;
         }
     }
 
-    // ---- the loop: one iteration per NODE EVENT ----
-    // A lane's next stop is the next node that carries one of its listed positions (or the end of its node range).
-    // The intervals that end on the way are not stops of their own: [pos, stop) is pre-tested ONCE, with the lowest
-    // c any of its nodes sees (c_low: the running minimum over the pops), against a byte that stands for a superset
-    // of the range -- the fetched entry's own pre-test byte (the minimum static score of the eligible nodes since its
-    // list's previous entry; flatmat.hpp: ix_pre) or, where there is none, the sparse table's.  Nearly every range
-    // fails it and costs nothing more; one that passes is cut at the interval ends into sub-ranges of constant c,
-    // which go to a per-lane QUEUE in LDS.  The queue is drained -- table byte, then the exact aggregate of the
-    // sub-ranges that still pass (four independent 16-byte loads), `take` -- when some lane's queue is full and at
-    // the end of the walk: the rare, divergent part of an iteration runs with many lanes at once instead of with two
-    // or three in every iteration.  A candidate taken late only delays a tighter `bs` (more sub-ranges queued, never
-    // a different result: `take` is commutative).
-    uint32_t* que = stk + sd_rows * 64;        // [WALK_QUEUE][2][64]: (a | c + bias in the top bits), b
-    uint32_t qn = 0;
+    // small streams: nearly every range between two events holds a node that can tie the best (a crown is
+    // made of low-score nodes), so the exact query is issued at once, with the other loads of the iteration;
+    // large ones ask the sparse table first (there nearly every range fails it)
+    const bool eager = L_n <= m.walk_eager_nodes;
 #ifdef WEPP_WALK_STATS
     uint32_t st_live = 0, st_pass = 0;
 #endif
-    auto drain = [&]() {
-        while (__ballot(qn > 0)) {
-            if (qn > 0) {
-                qn--;
-                const uint32_t qa = que[(qn * 2) * 64 + lane], b = que[(qn * 2 + 1) * 64 + lane];
-                const uint32_t a = qa & ((1u << (32 - WALK_DELTA_BITS)) - 1u);
-                const int cq = (int)(qa >> (32 - WALK_DELTA_BITS)) - (int)WALK_DELTA_BIAS;
-                // the table byte of [a, b): the minimum over [a, a + 2^lvl), the first level that reaches b
-                const uint32_t len = b - a;
-                const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
-                const uint32_t mn = ix.sp[(size_t)lvl * ix.n + a];
-                lane_bytes += 1;
-                if (mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + cq <= bs)) {
-#ifdef WEPP_WALK_STATS
-                    st_pass++;
-#endif
-                    // exact aggregate of the statically eligible nodes of [a, b): suffix of the first node's block,
-                    // disjoint sparse table over the whole blocks in between, prefix of the last node's block
-                    const uint32_t last = b - 1;
-                    const uint32_t ba = a / RQ_BLK, bl = last / RQ_BLK;
-                    SegNode ag{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
-                    auto join = [&](const SegNode x) {
-                        if (x.base < ag.base) ag = x;
-                        else if (x.base == ag.base) { ag.cnt += x.cnt; if (x.rank < ag.rank) { ag.rank = x.rank; ag.hu = x.hu; } }
-                    };
-                    if (ba == bl) {
-                        // inside one block: its prefix up to the last node, unless the range starts behind the
-                        // block's first node -- then node by node
-                        lane_bytes += 16;
-                        if (a == ba * RQ_BLK) join(ix.rq_pre[last]);
-                        else if (b == ix.n || b == (ba + 1) * RQ_BLK) join(ix.rq_suf[a]);
-                        else
-                            for (uint32_t i = a; i < b; i++) {
-                                if (i > a) lane_bytes += 16;
-                                const NodeRec x = ix.nrec[i];
-                                if (x.nstat & NS_ELIG0_DEV) {
-                                    const uint32_t hu = (x.nstat & NS_ROOT_DEV) ? 0u : (x.nstat & NS_MASKED_DEV) ? 1u :
-                                                        (((x.nstat >> 14) & NS_CNT_MASK_DEV) < (x.nstat & NS_CNT_MASK_DEV) ? 1u : 0u);
-                                    join(SegNode{x.base, x.rank, 1u, hu});
-                                }
-                            }
-                    } else {
-                        const uint32_t lo = ba + 1, hi = bl - 1;
-                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
-                        const uint32_t L = lo < hi ? 31u - (uint32_t)__builtin_clz(lo ^ hi) : 0u;
-                        const SegNode* trow = ix.rq_dst + (size_t)L * ix.rq_blocks;
-                        const SegNode s1 = ix.rq_suf[a], s2 = ix.rq_pre[last];
-                        const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
-                        join(s1); join(s2); join(s3); join(s4);
-                        lane_bytes += 32 + (lo <= hi ? 16 : 0) + (lo < hi ? 16 : 0);
-                    }
-                    if (ag.cnt && ag.base + cq <= bs) take(ag.base + cq, ag.rank, ag.cnt, ag.hu);
-                }
-            }
-        }
-    };
     while (__ballot(pos < n)) {
         iters++;
 #ifdef WEPP_WALK_STATS
@@ -1610,8 +1592,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
 #pragma unroll
         for (int j = 1; j < KW; j++) i_next = min(i_next, head[j]);
         const bool live = pos < n;
-        const uint32_t stop = min(i_next, n);
-        const bool at_node = live && i_next < n;
+        const uint32_t stop = min(min(i_next, top_end), n);
+        const bool at_node = live && i_next < top_end && i_next < n;
         const unsigned long long b_at = __ballot(at_node);
         n_ent += (uint32_t)__popcll(b_at);
         // ---- everything this iteration reads from memory is requested here, together ----
@@ -1626,71 +1608,88 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             ecur = cur_l[js * 64 + lane];
             ent = ix.ix_ent[ecur];             // 32 bytes: the mutation, the list's next node and the node's own record
         }
-        // a range without an entry byte (the stream carries none, or the range runs to the end of the lane's nodes)
-        // asks the sparse table: requested here, with the entry, not behind it
+        // the sparse-table byte of [pos, stop): the minimum over [pos, pos + 2^lvl), the first level that reaches
+        // `stop`.  A lane whose range ends at the fetched entry's node asks that entry's byte first (use_pre);
+        // every other lane's table byte is requested here, with the entry, not behind it
         const bool ranged = live && stop > pos;
-        const bool by_table = ranged && !(ix.has_pre && at_node);
-        uint32_t mn = SP_NONE;
-        if (by_table) {
+        const bool use_pre = ranged && !eager && L_pre && at_node && k >= IX_PRE_MIN_LISTS;
+        size_t sp_at = 0;
+        uint32_t mn_early = SP_NONE;
+        if (ranged && !eager) {
             const uint32_t len = stop - pos;
             const uint32_t lvl = len > 1 ? 32u - (uint32_t)__builtin_clz(len - 1) : 0u;
-            mn = ix.sp[(size_t)lvl * ix.n + pos];
+            sp_at = L_sp + (size_t)lvl * L_n + pos;
+            if (!use_pre) mn_early = ix.sp[sp_at];
         }
-        n_spb += (uint32_t)__popcll(__ballot(by_table));
-        // ---- the intervals that end before the stop: the lowest c on the way ----
-        int c_run = c, c_low = c;
-        uint32_t t = sp;
-        {
-            uint32_t te = top_end;
-            int td = top_d;
-            while (__ballot(live && t > 0 && te <= stop)) {
-                if (live && t > 0 && te <= stop) {
-                    c_run -= td;
-                    c_low = min(c_low, c_run);
-                    t--;
-                    if (t) {
-                        const uint32_t e = stk[(t - 1) * 64 + lane];
-                        te = e >> WALK_DELTA_BITS;
-                        td = (int)(e & ((1u << WALK_DELTA_BITS) - 1u)) - (int)WALK_DELTA_BIAS;
+        n_spb += (uint32_t)__popcll(__ballot(ranged && !eager && !use_pre));
+        // ---- the nodes [pos, stop): none of them carries a listed position, c is constant ----
+        if (live && stop > pos) {
+            const uint32_t last = stop - 1;
+            const uint32_t ba = pos / RQ_BLK, bl = last / RQ_BLK;
+            bool pass = true;
+            if (!eager) {
+                // the range ends at the node of the entry fetched above: that entry's byte is the minimum of a
+                // superset (everything since its list's previous entry), no table byte needed unless it passes
+                // (a read with one or two lists gains nothing: its ranges ARE the ranges between its list's entries, and
+                // when such a range cannot be skipped the table byte would be fetched after the entry instead of with it)
+                bool by_entry = false;
+                uint32_t mn = mn_early;
+                if (use_pre) {
+                    const uint32_t pb = ent.rank >> IX_RANK_BITS;
+                    by_entry = pb == SP_NONE || (pb < SP_CLAMP && (int)pb + c > bs);
+                    if (!by_entry) { mn = ix.sp[sp_at]; lane_bytes += 1; }   // (rare on the large streams: the byte of the table after all)
+                }
+                pass = !by_entry && mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c <= bs);
+            }
+#ifdef WEPP_WALK_STATS
+            st_pass += (uint32_t)__popcll(__ballot(pass));
+#endif
+            if (__ballot(pass)) {
+                if (pass) {
+                    // exact aggregate of the statically eligible nodes of [pos, stop): suffix of the first node's
+                    // block, disjoint sparse table over the whole blocks in between, prefix of the last node's
+                    // block -- four independent 16-byte loads (flatmat.hpp)
+                    SegNode ag{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
+                    auto join = [&](const SegNode x) {
+                        if (x.base < ag.base) ag = x;
+                        else if (x.base == ag.base) { ag.cnt += x.cnt; if (x.rank < ag.rank) { ag.rank = x.rank; ag.hu = x.hu; } }
+                    };
+                    if (ba == bl) {
+                        // inside one block: its prefix up to the last node, unless the range starts behind the
+                        // block's first node -- then node by node
+                        lane_bytes += 16;
+                        if (pos == ba * RQ_BLK) join(ix.rq_pre[L_node + last]);
+                        else if (stop == L_n || stop == (ba + 1) * RQ_BLK) join(ix.rq_suf[L_node + pos]);
+                        else
+                            for (uint32_t i = pos; i < stop; i++) {
+                                if (i > pos) lane_bytes += 16;
+                                const NodeRec x = ix.nrec[L_node + i];
+                                if (x.nstat & NS_ELIG0_DEV) {
+                                    const uint32_t hu = (x.nstat & NS_ROOT_DEV) ? 0u : (x.nstat & NS_MASKED_DEV) ? 1u :
+                                                        (((x.nstat >> 14) & NS_CNT_MASK_DEV) < (x.nstat & NS_CNT_MASK_DEV) ? 1u : 0u);
+                                    join(SegNode{x.base, x.rank, 1u, hu});
+                                }
+                            }
+                    } else {
+                        const uint32_t lo = ba + 1, hi = bl - 1;
+                        const SegNode none{SCORE_INF_DEV, 0xFFFFFFFFu, 0u, 0u};
+                        const uint32_t L = lo < hi ? 31u - (uint32_t)__builtin_clz(lo ^ hi) : 0u;
+                        const SegNode* trow = ix.rq_dst + L_dst + (size_t)L * L_rqb;
+                        const SegNode s1 = ix.rq_suf[L_node + pos], s2 = ix.rq_pre[L_node + last];
+                        const SegNode s3 = lo <= hi ? trow[lo] : none, s4 = lo < hi ? trow[hi] : none;
+                        join(s1); join(s2); join(s3); join(s4);
+                        lane_bytes += 32 + (lo <= hi ? 16 : 0) + (lo < hi ? 16 : 0);
                     }
+                    if (ag.cnt && ag.base + c <= bs) take(ag.base + c, ag.rank, ag.cnt, ag.hu);
                 }
             }
-        }
-        // ---- the nodes [pos, stop): none of them carries a listed position ----
-        if (ranged) {
-            if (!by_table) mn = ent.rank >> IX_RANK_BITS;      // the entry's byte: everything since its list's previous entry
-            const bool look = mn != SP_NONE && (mn >= SP_CLAMP || (int)mn + c_low <= bs);
-            // the sub-ranges of constant c, innermost interval first, into the queue (drained first when a lane is short of room)
-            uint32_t a = pos, tq = sp;
-            int cc = c;
-            bool more_q = look;
-            while (__ballot(more_q)) {
-                if (__ballot(more_q && qn == WALK_QUEUE)) drain();
-                if (more_q) {
-                    uint32_t b = stop;
-                    int d = 0;
-                    if (tq > t) {
-                        const uint32_t e = stk[(tq - 1) * 64 + lane];
-                        b = e >> WALK_DELTA_BITS;
-                        d = (int)(e & ((1u << WALK_DELTA_BITS) - 1u)) - (int)WALK_DELTA_BIAS;
-                        tq--;
-                    } else more_q = false;
-                    if (b > a) {
-                        que[(qn * 2) * 64 + lane] = a | ((uint32_t)(cc + (int)WALK_DELTA_BIAS) << (32 - WALK_DELTA_BITS));
-                        que[(qn * 2 + 1) * 64 + lane] = b;
-                        qn++;
-                        a = b;
-                    }
-                    cc -= d;
-                }
-            }
-        }
-        if (live) {
-            // the pops take effect
-            c = c_run;
             pos = stop;
-            if (t != sp) {
-                sp = t;
+        }
+        if (live && pos < n) {
+            if (!at_node) {
+                // the innermost open interval ends here: its nodes are behind us
+                c -= top_d;
+                sp--;
                 if (sp) {
                     const uint32_t e = stk[(sp - 1) * 64 + lane];
                     top_end = e >> WALK_DELTA_BITS;
@@ -1739,7 +1738,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                     elig = leaf ? (ncom > 0) : (ncom > 0 || ncom == (int)nmut);     // usher_mapper.cpp:455-456
                     hu = ncom < (int)nmut ? 1u : 0u;                                // :184,199,262
                 }
-                if (elig && sc <= bs) take(sc, ix.has_pre ? ent.rank & IX_RANK_MASK : ent.rank, 1u, hu);
+                if (elig && sc <= bs) take(sc, L_pre ? ent.rank & IX_RANK_MASK : ent.rank, 1u, hu);
                 if (dsum != 0 && end > node + 1) {
                     // k_route admits a read only if its open intervals always fit (sum of ix_nest <= SD)
                     stk[sp * 64 + lane] = (end << WALK_DELTA_BITS) | (uint32_t)(dsum + (int)WALK_DELTA_BIAS);
@@ -1752,7 +1751,6 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
             }
         }
     }
-    drain();
     WALK_STAMP(4);          // walked
     if (have) {
         if (CHUNKED) {
@@ -2154,10 +2152,10 @@ hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint3
                         int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
                         uint32_t* job_n, uint8_t* tier_of,
                         int32_t* root_score, uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk,
-                        uint32_t* tier_info_next, hipStream_t stream) {
+                        uint32_t* tier_info_next, uint32_t* wsid, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
                        n_reads, use_crowns, walk_max_events, job_events, std::min(stack8, WALK8_STACK), std::min(stack16, WALK16_STACK),
-                       job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next);
+                       job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next, wsid);
     return hipGetLastError();
 }
 
@@ -2242,15 +2240,15 @@ hipError_t launch_finalize(const DevMAT& m, const uint32_t* d_read_off, const ui
 }
 
 // LDS of a walk workgroup: WALK_WAVES waves, each KW / 2 rows of read alleles + KW rows of cursors + sd_rows of
-// stack + 2 * WALK_QUEUE rows of queued sub-ranges (64 lanes x 4 bytes a row)
-static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVES * (kw / 2 + kw + sd_rows + 2 * WALK_QUEUE) * 256; }
+// stack (64 lanes x 4 bytes a row)
+static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVES * (kw / 2 + kw + sd_rows) * 256; }
 // stack rows of a launch: the deepest stack its reads can need (k_route), at least one row for the job decode's
 // scratch, never more than the class admits
 static uint32_t walk_stack_rows(uint32_t open_max, uint32_t sd) { return std::min(sd, std::max(open_max, 2u)); }
 
 hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
                        const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, hipStream_t stream) {
+                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
     const uint32_t waves = pl.p[pl.n - 1].wave_end;
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
@@ -2258,11 +2256,11 @@ hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint3
     if (cls == PLAN_WALK8) {
         const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl,
-                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     } else {
         const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl,
-                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     }
     return hipGetLastError();
 }
@@ -2275,7 +2273,7 @@ hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint3
 
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb,
                             const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score,
-                            unsigned long long* work_counter, hipStream_t stream) {
+                            unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
     if (pl.n == 0) return hipSuccess;
     const uint32_t waves = pl.p[pl.n - 1].wave_end;
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
@@ -2283,12 +2281,12 @@ hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, 
         const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
                            sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, work_counter);
+                           (uint32_t*)nullptr, work_counter, wsid);
     } else {
         const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
                            sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, work_counter);
+                           (uint32_t*)nullptr, work_counter, wsid);
     }
     return hipGetLastError();
 }

@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -90,17 +92,21 @@ Node* Tree::create_node(std::string const& identifier, float branch_length) {
 }
 
 Node* Tree::create_node(std::string const& identifier, Node* par, float branch_length) {
-    if (all_nodes.count(identifier)) throw mat_error("Error: " + identifier + " already in the tree!");
     if (!par) throw mat_error("create_node: null parent for " + identifier);
+    // (one hash lookup: the slot is taken first, the node made only when the name is new)
+    auto slot = all_nodes.try_emplace(identifier, nullptr);
+    if (!slot.second) throw mat_error("Error: " + identifier + " already in the tree!");
     Node* n = new Node();
     n->identifier = identifier;
     n->branch_length = branch_length;
     n->parent = par;
     n->level = par->level + 1;
-    all_nodes[identifier] = n;
+    slot.first->second = n;
     par->children.push_back(n);
     return n;
 }
+
+void Tree::reserve(size_t n_nodes) { all_nodes.reserve(n_nodes); }
 
 Node* Tree::create_node(std::string const& identifier, std::string const& parent_id, float branch_length) {
     return create_node(identifier, get_node(parent_id), branch_length);
@@ -221,6 +227,13 @@ Tree create_tree_from_newick_string(std::string const& nw) {
             }
         }
     };
+    {
+        // every node but the root follows a '(' or a ',': the name table is sized once (at 16 M nodes the rehashes of a
+        // growing table were a third of the parse)
+        size_t nodes = 1;
+        for (char ch : nw) nodes += (ch == '(' || ch == ',') ? 1 : 0;
+        T.reserve(nodes);
+    }
     bool any = false;
     while (i < n) {
         char ch = nw[i];
@@ -306,7 +319,18 @@ PbMut parse_mut(Wire w) {
 }  // namespace
 
 Tree load_mutation_annotated_tree(std::string const& filename) {
+    // WEPP_LOAD_TIMING=1: seconds per phase to stderr (read + inflate, message scan, Newick, mutation lists)
+    const bool timing = getenv("WEPP_LOAD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double t = now();
+        fprintf(stderr, "[load] %s %.2f s\n", what, t - t_last);
+        t_last = t;
+    };
     std::string raw = slurp(filename, "mutation-annotated tree");
+    lap("read + inflate");
     Wire top{(const uint8_t*)raw.data(), (const uint8_t*)raw.data() + raw.size()};
     std::string newick;
     std::vector<Wire> node_lists;
@@ -328,7 +352,9 @@ Tree load_mutation_annotated_tree(std::string const& filename) {
             condensed.push_back(std::move(cn));
         } else top.skip(wt);
     }
+    lap("message scan");
     Tree tree = create_tree_from_newick_string(newick);
+    lap("Newick");
     auto dfs = tree.depth_first_expansion();
     if (node_lists.size() < dfs.size())
         throw mat_error("ERROR: .pb holds " + std::to_string(node_lists.size()) + " mutation lists for " +
@@ -361,6 +387,7 @@ Tree load_mutation_annotated_tree(std::string const& filename) {
             std::sort(node->mutations.begin(), node->mutations.end());
         }
     }
+    lap("mutation lists");
     for (auto& cn : condensed) {
         for (auto& l : cn.second) tree.condensed_leaves.insert(l);
         tree.condensed_nodes[cn.first] = std::move(cn.second);

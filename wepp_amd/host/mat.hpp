@@ -75,6 +75,7 @@ class Tree {   // mutation_annotated_tree.hpp:104-152
     std::vector<Node*> breadth_first_expansion(std::string nid = "") const;
     std::vector<Node*> depth_first_expansion(Node* node = nullptr) const;   // also sets dfs_idx / dfs_end_idx
     size_t size() const { return all_nodes.size(); }
+    void reserve(size_t n_nodes);          // room in the name table for n_nodes nodes (no rehash while they are created)
     // condensed identical-sequence leaves back into separate leaves (mutation_annotated_tree.cpp:1224-1272)
     void uncondense_leaves();
 

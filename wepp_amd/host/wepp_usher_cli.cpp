@@ -24,7 +24,7 @@ static void usage() {
 int main(int argc, char** argv) {
     std::string pb, vcf, outdir = ".";
     bool print_scores = false, dump = false, sort1 = false, sort2 = false, sort3 = false, reverse_sort = false;
-    bool no_add = false, report = false;
+    bool no_add = false, report = false, load_only = false;
     std::vector<int> devices;
     uint32_t max_uncertainty = 1000000, max_parsimony = 1000000;   // usher.cpp:77-80 defaults
     int device = 0;
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
         }
         else if (a == "--dump") dump = true;
         else if (a == "--report") report = true;
+        else if (a == "--load-only") load_only = true;
         else { usage(); return 1; }
     }
     if (pb.empty() || vcf.empty()) { usage(); return 1; }
@@ -61,6 +62,13 @@ int main(int argc, char** argv) {
         std::vector<Missing_Sample> missing_samples;
         MAT::read_vcf(&T, vcf, missing_samples);
         const double t_vcf = now() - t0 - t_load;
+        if (load_only) {          // the loaders alone (no GPU needed): what a 16 M-node .pb.gz costs before the first kernel
+            struct rusage ru{};
+            getrusage(RUSAGE_SELF, &ru);
+            printf("{\"nodes\": %zu, \"samples\": %zu, \"load_pb_s\": %.3f, \"read_vcf_s\": %.3f, \"peak_rss_mb\": %.1f}\n", T.size(),
+                   missing_samples.size(), t_load, t_vcf, ru.ru_maxrss / 1024.0);
+            return 0;
+        }
         if (dump) {
             auto bfs = T.breadth_first_expansion();
             printf("nodes %zu\n", bfs.size());
