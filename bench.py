@@ -376,10 +376,12 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
             tr = mat.last_tiers(rd.n_reads)
+            pc, _ = mat.last_plans(rd.n_reads)
             sens.append({"reads": label, "n_reads": rd.n_reads, "mean_entries": b.nw / rd.n_reads,
                          "reads_per_s": rd.n_reads / dt, "ms_per_step": dt * 1e3,
                          "share_on_whole_tree_stream": float((tr == st.n_streams - 1).mean()),
-                         "median_stream_nodes": int(st.stream_nodes[int(np.median(tr))])})
+                         "share_on_window_crowns": float((tr == w.WINDOW_CROWN_SLOT).mean()),
+                         "reads_by_plan_class": {w.PLAN_NAMES[c]: int(k) for c, k in enumerate(np.bincount(pc, minlength=6)) if k}})
 
         n_s = min(R, 1_000_000)
         for pn in ((0.005, 0.02, 0.05) if not long_reads else (0.02, 0.05)):
@@ -400,7 +402,7 @@ def main():
                  f"N rate {p_n}; {args.batches} batches in rotation from seed {seed0}); BASELINE.json configs[4] shape on one GPU" if long_reads else
                  f"{R} synthetic ARTIC-like {args.read_len} bp reads per GPU per step (0.1 % substitutions, N rate {p_n}; "
                  f"{args.batches} distinct batches in rotation, seeds {seed0}..{seed0 + args.batches - 1}); BASELINE.json configs[2]")
-        counts = np.bincount(tiers, minlength=st.n_streams)
+        counts = np.bincount(tiers, minlength=16)
         out = {
             "metric": "reads placed/sec on SARS-CoV-2 MAT (~16M nodes)",
             "value": value,
@@ -444,6 +446,11 @@ def main():
                      "reads_by_plan_class": {w.PLAN_NAMES[c]: int(n) for c, n in enumerate(np.bincount(pcls, minlength=6)) if n}},
             "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]), "bytes": int(st.stream_bytes_of[i]),
                          "reads_routed": int(counts[i])} for i in range(st.n_streams)],
+            "window_crowns": {"what": "per genome window (2560 positions every 1024) the nodes a read confined to the window can be "
+                                      "placed on given its ROOT score: the bound of a read's search without the + |S| slack of the "
+                                      "tree-wide streams above (DESIGN.md 4.2c)",
+                              "crowns": int(st.n_window_crowns), "nodes_in_all": int(st.window_crown_nodes),
+                              "reads_routed": int(counts[w.WINDOW_CROWN_SLOT])},
         }
         if whole is not None:
             wr, wc = sweep_roofline("whole_tree", R, whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],

@@ -72,7 +72,7 @@ def main():
         # ... and the chunked classes in strength: they are what these batches spend their time in
         for c in (w.PLAN_WALKC8, w.PLAN_WALKC16):
             pick.extend(np.nonzero(pcls == c)[0][:2500].tolist())
-        step = max(1, rd.n_reads // 3000)
+        step = max(1, rd.n_reads // 6000)
         pick = np.array(sorted(set(pick) | set(range(0, rd.n_reads, step))))
         assert len(pick) >= min(5000, rd.n_reads), len(pick)
         t1 = time.perf_counter()

@@ -564,6 +564,44 @@ def test_full_size_nrich_and_long_shard():
     print("full-size N-rich / long-shard report:", json.dumps(rep))
 
 
+def test_window_crowns_walks_and_sweeps_vs_oracle(oracle):
+    """Window crowns (include/wepp_place.h: wepp_mat_last_crowns): reads confined to a genome window are placed on the
+    crown of their window that their ROOT score admits -- by a walk when they list at most 16 positions, by a one-wave
+    sweep of the crown when they list more (N-rich reads: 10 % and 20 % N) -- with the oracle's results; with the walks
+    off every such read sweeps its crown; with work skipping off none does.  Crowns of several levels are reached."""
+    g = w.generate_tree(81, 150_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
+    batches = [g.reads(82, 3000, p_substitution=0.004, p_n=0.02, p_iupac=0.1), g.reads(83, 1500, p_n=0.10),
+               g.reads(84, 1500, p_substitution=0.01, p_n=0.20)]
+    reads = Reads(np.concatenate([[0]] + [b.read_off[1:].astype(np.int64) + sum(int(x.read_off[-1]) for x in batches[:i])
+                                          for i, b in enumerate(batches)]).astype(np.uint32),
+                  np.concatenate([b.read_word for b in batches]))
+    want = oracle.OracleTree(g.tree).incremental().place_batch(reads, nthreads=os.cpu_count() or 1)
+    mat = w.Mat(g.tree)
+    assert mat.stats.n_window_crowns >= 30 and mat.stats.window_crown_nodes > 0
+
+    def check(res):
+        assert (res.score == want["score"]).all() and (res.best_bfs_j == want["best_j"]).all()
+        assert (res.num_best == want["num_best"]).all() and (res.has_unique == want["has_unique"]).all()
+
+    check(mat.place_batch(reads))
+    pcls, pst = mat.last_plans(reads.n_reads)
+    win, crown = mat.last_crowns(reads.n_reads)
+    on_crown = pst == w.WINDOW_CROWN_SLOT
+    assert on_crown.mean() > 0.6 and len(np.unique(crown[on_crown])) >= 3 and len(np.unique(win[on_crown])) >= 20
+    k = np.diff(reads.read_off.astype(np.int64))
+    assert ((pcls == w.PLAN_SWEEP) & on_crown).sum() > 500 and (k[(pcls == w.PLAN_SWEEP) & on_crown] > 16).all()
+    assert ((pcls == w.PLAN_WALK8) & on_crown).sum() > 1000 and ((pcls == w.PLAN_WALK16) & on_crown).sum() > 100
+    mat.set_use_walk(False)
+    check(mat.place_batch(reads))
+    pcls2, pst2 = mat.last_plans(reads.n_reads)
+    assert ((pst2 == w.WINDOW_CROWN_SLOT) == on_crown).all() and (pcls2[on_crown] == w.PLAN_SWEEP).all()
+    mat.set_use_walk(True)
+    mat.set_use_crowns(False)
+    check(mat.place_batch(reads))
+    assert (mat.last_plans(reads.n_reads)[1] != w.WINDOW_CROWN_SLOT).all()
+    mat.close()
+
+
 def test_pipeline_equals_unsplit_call(oracle):
     """wepp_place_batch cuts a large batch into sub-batches that overlap staging, H2D, kernels and D2H
     (include/wepp_place.h): whatever the split -- 1, 2, 3, 4 or 8 sub-batches --, with pageable buffers or with

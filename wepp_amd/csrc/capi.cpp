@@ -208,6 +208,52 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
                 h->wc_nodes += st.n;
                 h->wc_count++;
             }
+        // ... and their sweep streams, for the reads that cannot walk (k_sweep_arena): the same kind of arena; every
+        // stream keeps its own tail padding (the sweep loads past a block's events and prefetches summaries)
+        {
+            std::vector<int64_t> s_nkey;
+            std::vector<uint32_t> s_nstat, s_node0, s_eoff, s_evw, s_cpo, s_cpw;
+            std::vector<uint8_t> s_meta, s_lb;
+            std::vector<BlkSum> s_sum;
+            struct Off { size_t nkey, node0, eoff, sum, ev, cpo, cpw; };
+            std::vector<Off> offs;
+            for (const auto& wc : f.wcrowns)
+                for (const Stream& st : wc) {
+                    offs.push_back(Off{s_nkey.size(), s_node0.size(), s_eoff.size(), s_sum.size(), s_evw.size(), s_cpo.size(), s_cpw.size()});
+                    s_nkey.insert(s_nkey.end(), st.nkey.begin(), st.nkey.end());
+                    s_nstat.insert(s_nstat.end(), st.nstat.begin(), st.nstat.end());
+                    s_node0.insert(s_node0.end(), st.blk_node0.begin(), st.blk_node0.end());
+                    s_eoff.insert(s_eoff.end(), st.blk_eoff.begin(), st.blk_eoff.end());
+                    s_sum.insert(s_sum.end(), st.blk_sum.begin(), st.blk_sum.end());
+                    s_sum.resize(s_sum.size() + SUM_TAIL_PAD, st.blk_sum.empty() ? BlkSum{} : st.blk_sum.back());
+                    s_evw.insert(s_evw.end(), st.ev_word.begin(), st.ev_word.end());
+                    s_evw.resize(s_evw.size() + EV_TAIL_PAD, W_PAD);
+                    s_meta.insert(s_meta.end(), st.ev_meta.begin(), st.ev_meta.end());
+                    s_meta.resize(s_meta.size() + EV_TAIL_PAD, 0);
+                    s_lb.insert(s_lb.end(), st.ev_lb.begin(), st.ev_lb.end());
+                    s_lb.resize(s_lb.size() + EV_TAIL_PAD, 255);
+                    s_cpo.insert(s_cpo.end(), st.cp_off.begin(), st.cp_off.end());
+                    s_cpw.insert(s_cpw.end(), st.cp_word.begin(), st.cp_word.end());
+                }
+            const int64_t* d_nkey; const uint32_t *d_nstat, *d_node0, *d_eoff, *d_evw, *d_cpo, *d_cpw;
+            const uint8_t *d_meta, *d_lb; const BlkSum* d_sum;
+            UP(d_nkey, s_nkey) UP(d_nstat, s_nstat) UP(d_node0, s_node0) UP(d_eoff, s_eoff) UP(d_sum, s_sum) UP(d_evw, s_evw)
+            UP(d_meta, s_meta) UP(d_lb, s_lb) UP(d_cpo, s_cpo) UP(d_cpw, s_cpw)
+            std::vector<DevStream> ws(f.wcrowns.size() * WC_MAX, DevStream{});
+            size_t k = 0;
+            for (size_t w = 0; w < f.wcrowns.size(); w++)
+                for (size_t i = 0; i < f.wcrowns[w].size(); i++, k++) {
+                    const Stream& st = f.wcrowns[w][i];
+                    DevStream& ds = ws[w * WC_MAX + i];
+                    ds.n = st.n; ds.NB = st.NB; ds.cp_stride = st.cp_stride; ds.ncp = (uint32_t)st.cp_off.size() - 1;
+                    ds.eager = 1u; ds.tier = WC_SLOT; ds.e_pad = (uint32_t)st.E;
+                    ds.nkey = d_nkey + offs[k].nkey; ds.nstat = d_nstat + offs[k].nkey;
+                    ds.blk_node0 = d_node0 + offs[k].node0; ds.blk_eoff = d_eoff + offs[k].eoff; ds.blk_sum = d_sum + offs[k].sum;
+                    ds.ev_word = d_evw + offs[k].ev; ds.ev_meta = d_meta + offs[k].ev; ds.ev_lb = d_lb + offs[k].ev;
+                    ds.cp_off = d_cpo + offs[k].cpo; ds.cp_word = d_cpw + offs[k].cpw;
+                }
+            UP(d.wc_streams, ws)
+        }
         DevWalk arena{};                           // (n = 0: never a stream of its own)
         UP(arena.ix_head, a_head) UP(arena.ix_ent, a_ent) UP(arena.ix_nest, a_nest) UP(arena.nrec, a_nrec)
         UP(arena.rq_pre, a_pre) UP(arena.rq_suf, a_suf) UP(arena.rq_dst, a_dst) UP(arena.sp, a_sp)
@@ -445,14 +491,15 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     uint32_t walk_off[2][MAX_STREAMS] = {}, walkc_off[2] = {0, 0};   // list offsets of the walk plans
     uint64_t walk_reads = 0, n_jobs[2] = {0, 0};
     uint32_t walkc_reads[2] = {0, 0};
+    uint32_t arena_n = 0, arena_off = 0, arena_maxk = 1;
+    size_t arena_part = 0;
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
         const uint32_t t = plan_index(id), cls = plan_class(id);
         {
             // (slot WC_SLOT of a walk class = the window crowns: one plan, a crown per read)
-            const bool walk_cls = cls == PLAN_WALK8 || cls == PLAN_WALK16 || cls == PLAN_WALKC8 || cls == PLAN_WALKC16;
-            if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : (t >= ns && !(walk_cls && t == WC_SLOT && mat->dev.wc_windows))))
+            if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : (t >= ns && !(t == WC_SLOT && mat->dev.wc_windows))))
                 return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
         }
         if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
@@ -483,6 +530,15 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             d.wave_end = (wp.n ? wp.p[wp.n - 1].wave_end : 0u) + walk_plan_waves(count);
             wp.n++;
             walk_reads += count;
+            continue;
+        }
+        if (cls == PLAN_SWEEP && t == WC_SLOT) {
+            // the reads that sweep their window crown, one wave each (k_sweep_arena); one partial per read
+            arena_n = count;
+            arena_off = info[TI_OFF + id];
+            arena_maxk = std::max<uint32_t>(1, info[TI_MAXK + id]);
+            arena_part = part_total;
+            part_total += (size_t)count * 12;
             continue;
         }
         Plan& p = plans[np++];
@@ -603,7 +659,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
     const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
-    const bool fork = !unfused && (n_other + n_walk_chains > 0) && (n_plain > 0 || n_other + n_walk_chains > 1);
+    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
+    const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
     if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
@@ -728,6 +785,25 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             HIP_TRY(hipEventRecord(mat->join_ev[k % OTHER_SIDE_STREAMS], q));
             joins[n_joins++] = k % OTHER_SIDE_STREAMS;
         }
+    }
+    if (arena_n) {
+        if (arena_maxk > MAX_TILE_ENTRIES) return set_error(WEPP_ELIMIT, "a read inside one genome window lists more than 8192 positions");
+        const uint32_t cap = (arena_maxk + 63) & ~63u;
+        hipStream_t q = fork ? mat->side[OTHER_SIDE_STREAMS - 1] : stream;      // (the last of the sweeps' side streams)
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        int32_t* ps = (int32_t*)(part_base + arena_part);
+        uint32_t *pr = (uint32_t*)(ps + arena_n), *pc = pr + arena_n;
+        HIP_TRY(launch_sweep_arena(mat->dev, mat->dev.wc_streams, wsid, d_read_off, d_read_word, root_score, list + arena_off, arena_n, cap,
+                                   sweep_lds_bytes(mat->dev.bm_words, cap, 0, false), ps, pr, pc, q));
+        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + arena_off, arena_n, 1, ps, pr, pc, d_best_bfs_j, d_score, d_num_best,
+                                d_flags, q));
+        if (fork) {
+            HIP_TRY(hipEventRecord(mat->join_ev[OTHER_SIDE_STREAMS - 1], q));
+            bool listed = false;
+            for (uint32_t i = 0; i < n_joins; i++) listed = listed || joins[i] == OTHER_SIDE_STREAMS - 1;
+            if (!listed) joins[n_joins++] = OTHER_SIDE_STREAMS - 1;
+        }
+        passes += arena_n;
     }
     if (n_plain) {
         SweepPlans pl{};
@@ -1309,6 +1385,7 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     // window stream folds runs of nodes into pseudo-nodes: nothing to list there)
     DevMAT dm = mat->dev;
     dm.n_windows = 0;
+    dm.wc_windows = 0;            // (and no window crowns: the list is made on the tree-wide streams)
     uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
     uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
     uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;

@@ -86,6 +86,7 @@ struct DevMAT {
     const uint8_t* maxnest;       // [max_pos + 1] most mutations at one position along a root path
     const DevWalk* walks;         // [MAX_STREAMS] device array: the streams' walk structures; [WC_SLOT] = the window crowns' arena
     const WcInfo* wc_info;        // [wc_windows * WC_MAX] the window crowns of every genome window, increasing tau
+    const DevStream* wc_streams;  // [wc_windows * WC_MAX] their sweep streams (k_sweep_arena)
     uint32_t wc_windows;          // 0: none built
 };
 
@@ -248,6 +249,10 @@ inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t ke
 constexpr uint32_t MAX_TILE_ENTRIES = 8192;
 constexpr uint32_t DENSE_MAX_POS = (1u << 19) - 1;
 constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep the sorted position index
+hipError_t launch_sweep_arena(const DevMAT& m, const DevStream* wc_streams, const uint32_t* wsid, const uint32_t* d_read_off,
+                              const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list, uint32_t n_list,
+                              uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
+                              hipStream_t stream);
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                               const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
                               hipStream_t stream);

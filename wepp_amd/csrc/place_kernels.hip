@@ -284,24 +284,24 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             nj_out = min((events + je - 1) / je, longest);
             return small ? PLAN_WALKC8 : PLAN_WALKC16;
         };
-        if (walk_max_events && k <= WALK16_K) {
-            uint32_t nj = 0, open_max = 0, events = 0;
-            // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
-            // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
-            uint32_t sid = NONE;
-            if (use_crowns && k > 0 && m.wc_windows) {
-                const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
-                const uint32_t wi = p_lo / WIN_STRIDE;
-                if (wi < m.wc_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) {
-                    const int rs = m.root_base + c;
-                    for (uint32_t i = 0; i < WC_MAX; i++) {
-                        const WcInfo* q = m.wc_info + wi * WC_MAX + i;
-                        const uint32_t qn = q->n;
-                        if (!qn) break;
-                        if (rs <= q->tau) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
-                    }
+        // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
+        // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
+        uint32_t sid = NONE;
+        if (use_crowns && k > 0 && m.wc_windows) {
+            const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
+            const uint32_t wi = p_lo / WIN_STRIDE;
+            if (wi < m.wc_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) {
+                const int rs = m.root_base + c;
+                for (uint32_t i = 0; i < WC_MAX; i++) {
+                    const WcInfo* q = m.wc_info + wi * WC_MAX + i;
+                    const uint32_t qn = q->n;
+                    if (!qn) break;
+                    if (rs <= q->tau) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
                 }
             }
+        }
+        if (walk_max_events && k <= WALK16_K) {
+            uint32_t nj = 0, open_max = 0, events = 0;
             if (sid != NONE) {
                 const WcInfo* q = m.wc_info + sid;
                 const DevWalk& ar = m.walks[WC_SLOT];
@@ -320,7 +320,12 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 atomicMax(&open_of[small ? 2 : 3], open_max);
             }
         }
-        if (cls == PLAN_SWEEP && use_crowns && k > 0 && t + 1 == m.n_streams && m.n_windows) {
+        if (cls == PLAN_SWEEP && sid != NONE) {
+            // it cannot walk (more than WALK16_K entries or too deep a stack): one wave sweeps its window crown (k_sweep_arena)
+            wsid[r] = sid;
+            t = WC_SLOT;
+        }
+        if (cls == PLAN_SWEEP && t != WC_SLOT && use_crowns && k > 0 && t + 1 == m.n_streams && m.n_windows) {
             // many entries, whole tree: if they all lie inside one genome window, that window's stream will do
             const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
             const uint32_t wi = p_lo / WIN_STRIDE;
@@ -1169,6 +1174,22 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
     uint32_t* __restrict__ part_cnt) {
     sweep_tile<S_IN_LDS, DENSE, WIN>(m, blockIdx.x, 0u, bm_words, max_pos, ent_cap, key_cap, read_off, read_word, root_score,
                                      list, n_list, T, ntiles, blocks_per_chunk, part_score, part_rank, part_cnt);
+}
+
+// the reads that cannot walk (more than WALK16_K entries, or too many open intervals) but lie inside one genome
+// window and have a low root score: one wave per read sweeps the read's WINDOW CROWN (wsid: a few hundred to a few
+// hundred thousand nodes) instead of a 64-read tile sweeping the tree-wide stream of theta = root score + |S|
+__global__ __launch_bounds__(64) void k_sweep_arena(const DevStream* __restrict__ wc_streams, const uint32_t* __restrict__ wsid,
+                                                    uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
+                                                    const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                                                    const int32_t* __restrict__ root_score, const uint32_t* __restrict__ list,
+                                                    int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
+                                                    uint32_t* __restrict__ part_cnt) {
+    const uint32_t i = blockIdx.x;
+    const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsid[list[i]]);
+    const DevStream st = wc_streams[sid];
+    sweep_tile<true, false>(st, 0u, 0u, bm_words, max_pos, ent_cap, 0u, read_off, read_word, root_score, list + i, 1u, 1u, 1u,
+                            st.NB, part_score + i, part_rank + i, part_cnt + i);
 }
 
 // all the plain (short-read) plans of one placement call in ONE launch: the sweeps of the
@@ -2202,6 +2223,16 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
     return hipGetLastError();
 }
 
+hipError_t launch_sweep_arena(const DevMAT& m, const DevStream* wc_streams, const uint32_t* wsid, const uint32_t* d_read_off,
+                              const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list, uint32_t n_list,
+                              uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
+                              hipStream_t stream) {
+    if (n_list == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sweep_arena, dim3(n_list), dim3(64), lds_bytes, stream, wc_streams, wsid, m.bm_words, m.max_pos, ent_cap,
+                       d_read_off, d_read_word, root_score, list, part_score, part_rank, part_cnt);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                               const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
                               hipStream_t stream) {
@@ -2364,6 +2395,8 @@ hipError_t sweep_set_max_lds(uint32_t bytes) {
     e = hipFuncSetAttribute((const void*)k_sweep<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_sweep<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_sweep_arena, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_sweep_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
