@@ -5,6 +5,7 @@
 #   alltests    pytest tests -m gpu                               -> gpurun_out/session/pytest_gpu.log
 #   bench       python bench.py (the driver's command)            -> gpurun_out/session/bench_default.json
 #   probe       tools/walk_probe.py (PROBE_* from the environment) -> gpurun_out/session/probe.log
+#   pcie        tools/pcie_rate.py: wepp_place_batch with host buffers, every pipeline depth   -> gpurun_out/session/pcie.log
 #   probe@<v>   the same on variants/<v>/libwepp_place.so (tools/build_variant.sh)   -> gpurun_out/session/probe_<v>.log
 #   probestats  the same on the -DWEPP_WALK_STATS build (variants/walkstats) with the walks' phase counters
 set -u
@@ -20,6 +21,7 @@ for step in "$@"; do
     probe)    timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe${PROBE_TAG:-}.log" 2>&1; rc=$?; cut -c1-330 "$OUT/probe${PROBE_TAG:-}.log";;
     probe0)   WEPP_WALK_SORT=0 timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe_nosort.log" 2>&1; rc=$?; cut -c1-330 "$OUT/probe_nosort.log";;
     probestats) WEPP_PLACE_LIB=$REPO/variants/walkstats/libwepp_place.so WEPP_WALK_DEBUG=1 timeout -k 10 900 python tools/walk_probe.py > "$OUT/probestats.log" 2>&1; rc=$?; cut -c1-400 "$OUT/probestats.log";;
+    pcie)     timeout -k 10 600 python tools/pcie_rate.py > "$OUT/pcie.log" 2>&1; rc=$?; grep -v amdgpu "$OUT/pcie.log" | cut -c1-200;;
     probe@*)  v=${step#probe@}; WEPP_PLACE_LIB=$REPO/variants/$v/libwepp_place.so timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe_$v.log" 2>&1; rc=$?; cut -c1-200 "$OUT/probe_$v.log";;
     *) echo "unknown step $step"; rc=1;;
   esac

@@ -26,24 +26,26 @@ void release(wepp_mat* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
-    if (h->ws) (void)hipFree(h->ws);
+    for (PlaceLane& L : h->lane) {
+        if (L.ws) (void)hipFree(L.ws);
+        if (L.ws2) (void)hipFree(L.ws2);
+        if (L.d_info) (void)hipFree(L.d_info);
+        if (L.h_info) (void)hipHostFree(L.h_info);
+        for (uint32_t i = 0; i < MAX_STREAMS; i++) {
+            if (L.side[i]) (void)hipStreamDestroy(L.side[i]);
+            if (L.join_ev[i]) (void)hipEventDestroy(L.join_ev[i]);
+        }
+        if (L.fork_ev) (void)hipEventDestroy(L.fork_ev);
+    }
     if (h->io_in) (void)hipFree(h->io_in);
     if (h->io_out) (void)hipFree(h->io_out);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->epp_ws) (void)hipFree(h->epp_ws);
-    if (h->d_info) (void)hipFree(h->d_info);
     if (h->d_work) (void)hipFree(h->d_work);
-    if (h->ws2) (void)hipFree(h->ws2);
-    if (h->h_info) (void)hipHostFree(h->h_info);
     for (uint32_t i = 0; i < wepp_mat::kRing; i++) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
         if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
     }
-    for (uint32_t i = 0; i < MAX_STREAMS; i++) {
-        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
-        if (h->join_ev[i]) (void)hipEventDestroy(h->join_ev[i]);
-    }
-    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     for (uint32_t i = 0; i < wepp_mat::kPipeMax; i++) {
         if (h->pipe_up[i]) (void)hipEventDestroy(h->pipe_up[i]);
         if (h->pipe_done[i]) (void)hipEventDestroy(h->pipe_done[i]);
@@ -51,7 +53,8 @@ void release(wepp_mat* h) {
     }
     if (h->pipe_h2d) (void)hipStreamDestroy(h->pipe_h2d);
     if (h->pipe_d2h) (void)hipStreamDestroy(h->pipe_d2h);
-    if (h->pipe_compute) (void)hipStreamDestroy(h->pipe_compute);
+    for (hipStream_t st : h->pipe_compute)
+        if (st) (void)hipStreamDestroy(st);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->d_plan_of) (void)hipFree(h->d_plan_of);
     if (h->d_wsid_of) (void)hipFree(h->d_wsid_of);
@@ -279,18 +282,20 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
     e = hipMalloc((void**)&h->d_work, 2 * WALK_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_work, 0, 2 * WALK_COUNTERS * sizeof(unsigned long long));
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
-    e = hipMalloc((void**)&h->d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_PLANS) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(h->d_info, 0, 2 * TI_WORDS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_info, TI_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    for (PlaceLane& L : h->lane) {
+        if (e == hipSuccess) e = hipMalloc((void**)&L.d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_PLANS) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(L.d_info, 0, 2 * TI_WORDS * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_info, TI_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+        for (uint32_t i = 0; i < MAX_STREAMS && e == hipSuccess; i++) {
+            e = hipStreamCreateWithFlags(&L.side[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&L.join_ev[i], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming);
+    }
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
-    for (uint32_t i = 0; i < MAX_STREAMS && e == hipSuccess; i++) {
-        e = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = sweep_set_max_lds(160 * 1024);
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     *out = h;
@@ -371,7 +376,8 @@ namespace {
 // direct wepp_place_batch_device call is the whole: base 0, total n_reads) -- where its plan ids go in d_plan_of.
 int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                  uint32_t* d_best_bfs_j, int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags, hipStream_t stream,
-                 uint32_t plan_base, uint32_t plan_total) {
+                 uint32_t plan_base, uint32_t plan_total, uint32_t lane_idx = 0) {
+    PlaceLane& L = mat->lane[lane_idx];
     if (plan_total > mat->plan_of_bytes) {
         // (only ever at the first sub-batch of a call: plan_total is the whole call's)
         if (mat->d_plan_of) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->d_plan_of); mat->d_plan_of = nullptr; mat->plan_of_bytes = 0; }
@@ -389,12 +395,12 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // The partials are sized for the worst case once the per-tier counts are known.
     bool ws_moved = false;
     auto grow = [&](size_t need) -> int {
-        if (need <= mat->ws_bytes) return WEPP_OK;
-        if (mat->ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(mat->ws); mat->ws = nullptr; mat->ws_bytes = 0; }
+        if (need <= L.ws_bytes) return WEPP_OK;
+        if (L.ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(L.ws); L.ws = nullptr; L.ws_bytes = 0; }
         need += need / 4;
-        hipError_t e = hipMalloc(&mat->ws, need);
+        hipError_t e = hipMalloc(&L.ws, need);
         if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
-        mat->ws_bytes = need;
+        L.ws_bytes = need;
         ws_moved = true;
         return WEPP_OK;
     };
@@ -421,7 +427,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     int32_t* root_score = nullptr;
     void* sort_tmp = nullptr;
     auto carve = [&]() {
-        char* p = (char*)mat->ws;
+        char* p = (char*)L.ws;
         tier_of = mat->d_plan_of + plan_base;
         list = (uint32_t*)p; p += list_bytes;
         root_score = (int32_t*)p; p += list_bytes;
@@ -436,8 +442,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         }
     };
     carve();
-    uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
-    uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
+    uint32_t* tier_info = L.d_info + L.info_idx * TI_WORDS;
+    uint32_t* blk_counts = L.d_info + 2 * TI_WORDS;
 
     // events per job of the two chunked classes: WEPP_WALK_JOB_EVENTS fixes them, else they follow the handle's
     // traffic (device_mat.hpp: WALK_TARGET_JOBS)
@@ -450,11 +456,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
-        tier_info = mat->d_info + mat->info_idx * TI_WORDS;
-        uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
+        tier_info = L.d_info + L.info_idx * TI_WORDS;
+        uint32_t* tier_info_next = L.d_info + (L.info_idx ^ 1u) * TI_WORDS;
         HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, stack8, stack16, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, wsid, stream));
-        mat->info_idx ^= 1u;
+        L.info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
         return WEPP_OK;
     };
@@ -462,7 +468,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         int rc = route();
         if (rc != WEPP_OK) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     // the host sizes the launches from the counters, and the GPU idles until it has: poll for them (a
     // blocking wait adds its wake-up, ~15 us per call, to that idle time); after ~0.1 s of polling -- a long
     // queue in front of this call -- wait blocking
@@ -472,7 +478,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         (void)hipGetLastError();   // "not ready" is not an error: keep it out of the launchers' hipGetLastError()
         if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
     }
-    const uint32_t* info = mat->h_info;
+    const uint32_t* info = L.h_info;
     for (uint32_t cc = 0; cc < 2; cc++) {
         const uint64_t ev = (uint64_t)info[TI_EVENTS + cc] << 6;
         const uint32_t je = (uint32_t)std::min<uint64_t>(WALK_JOB_EVENTS_MAX, std::max<uint64_t>(WALK_JOB_EVENTS, ev / WALK_TARGET_JOBS));
@@ -607,7 +613,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             if (rc != WEPP_OK) return rc;
         }
     }
-    char* part_base = (char*)mat->ws + fixed_bytes;
+    char* part_base = (char*)L.ws + fixed_bytes;
     // (the workspace may have moved above: every pointer into it is taken from here on)
     for (uint32_t cls = 0; cls < 2; cls++)
         for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = list + walk_off[cls][k];
@@ -661,7 +667,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
     const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
     const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
-    if (fork) HIP_TRY(hipEventRecord(mat->fork_ev, stream));
+    if (fork) HIP_TRY(hipEventRecord(L.fork_ev, stream));
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
     uint32_t joins[MAX_STREAMS], n_joins = 0;
@@ -687,8 +693,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     if (walks) {
         // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
         // sweeps run side by side (the walks wait on memory most of the time)
-        hipStream_t q = fork ? mat->side[MAX_STREAMS - 1] : stream;
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        hipStream_t q = fork ? L.side[MAX_STREAMS - 1] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         for (uint32_t cls = 0; cls < 2; cls++) {
             if (!walk[cls].n) continue;
             // (the plain classes keep the caller's order unless WEPP_WALK_SORT_PLAIN=1: their reads have at most 16
@@ -705,7 +711,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                                 d_num_best, d_flags, mat->d_work, wsid, q));
         }
         if (fork) {
-            HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 1], q));
+            HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
             joins[n_joins++] = MAX_STREAMS - 1;
         }
         if (walkc[0].n || walkc[1].n) {
@@ -720,22 +726,22 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 base[cc] = need;
                 need += 2 * pad((size_t)walkc_reads[cc] * 4) + pad(scan_temp[cc]) + 3 * pad((size_t)n_jobs[cc] * 4);
             }
-            if (need > mat->ws2_bytes) {
-                if (mat->ws2) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->ws2); mat->ws2 = nullptr; mat->ws2_bytes = 0; }
-                hipError_t e2 = hipMalloc(&mat->ws2, need + need / 4);
+            if (need > L.ws2_bytes) {
+                if (L.ws2) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(L.ws2); L.ws2 = nullptr; L.ws2_bytes = 0; }
+                hipError_t e2 = hipMalloc(&L.ws2, need + need / 4);
                 if (e2 != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc walk workspace: ") + hipGetErrorString(e2));
-                mat->ws2_bytes = need + need / 4;
+                L.ws2_bytes = need + need / 4;
             }
             for (uint32_t cc = 0; cc < 2; cc++) {
                 if (!walkc[cc].n) continue;
                 // each class on a side stream of its own: a chain of short, latency-bound launches
                 if (fork) {
-                    q = mat->side[MAX_STREAMS - 2 - cc];
-                    HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+                    q = L.side[MAX_STREAMS - 2 - cc];
+                    HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
                 }
                 const uint32_t R3 = walkc_reads[cc], J = (uint32_t)n_jobs[cc];
                 const size_t b_cnt = pad((size_t)R3 * 4), b_tmp = pad(scan_temp[cc]), b_job = pad((size_t)J * 4);
-                char* w2 = (char*)mat->ws2 + base[cc];
+                char* w2 = (char*)L.ws2 + base[cc];
                 uint32_t* jcnt = (uint32_t*)w2; w2 += b_cnt;
                 uint32_t* joff = (uint32_t*)w2; w2 += b_cnt;
                 void* jtmp = w2; w2 += b_tmp;
@@ -763,7 +769,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 HIP_TRY(launch_finalize_jobs(mat->dev, list3, R3, jb, d_read_off, d_read_word, d_best_bfs_j, d_score,
                                              d_num_best, d_flags, q));
                 if (fork) {
-                    HIP_TRY(hipEventRecord(mat->join_ev[MAX_STREAMS - 2 - cc], q));
+                    HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 2 - cc], q));
                     joins[n_joins++] = MAX_STREAMS - 2 - cc;
                 }
             }
@@ -771,8 +777,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     }
     for (uint32_t k = 0; k < n_other; k++) {
         const Plan& p = plans[others[k]];
-        hipStream_t q = fork ? mat->side[k % OTHER_SIDE_STREAMS] : stream;
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        hipStream_t q = fork ? L.side[k % OTHER_SIDE_STREAMS] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
         HIP_TRY(launch_sweep(mat->dev, *p.st, d_read_off, d_read_word, root_score, p.lst, p.count, p.T,
@@ -782,15 +788,15 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                                 d_best_bfs_j, d_score, d_num_best, d_flags, q));
         if (fork && (k + OTHER_SIDE_STREAMS >= n_other)) {
             // the last launch on every side stream joins the caller's stream
-            HIP_TRY(hipEventRecord(mat->join_ev[k % OTHER_SIDE_STREAMS], q));
+            HIP_TRY(hipEventRecord(L.join_ev[k % OTHER_SIDE_STREAMS], q));
             joins[n_joins++] = k % OTHER_SIDE_STREAMS;
         }
     }
     if (arena_n) {
         if (arena_maxk > MAX_TILE_ENTRIES) return set_error(WEPP_ELIMIT, "a read inside one genome window lists more than 8192 positions");
         const uint32_t cap = (arena_maxk + 63) & ~63u;
-        hipStream_t q = fork ? mat->side[OTHER_SIDE_STREAMS - 1] : stream;      // (the last of the sweeps' side streams)
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, mat->fork_ev, 0));
+        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 1] : stream;      // (the last of the sweeps' side streams)
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         int32_t* ps = (int32_t*)(part_base + arena_part);
         uint32_t *pr = (uint32_t*)(ps + arena_n), *pc = pr + arena_n;
         HIP_TRY(launch_sweep_arena(mat->dev, mat->dev.wc_streams, wsid, d_read_off, d_read_word, root_score, list + arena_off, arena_n, cap,
@@ -798,7 +804,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + arena_off, arena_n, 1, ps, pr, pc, d_best_bfs_j, d_score, d_num_best,
                                 d_flags, q));
         if (fork) {
-            HIP_TRY(hipEventRecord(mat->join_ev[OTHER_SIDE_STREAMS - 1], q));
+            HIP_TRY(hipEventRecord(L.join_ev[OTHER_SIDE_STREAMS - 1], q));
             bool listed = false;
             for (uint32_t i = 0; i < n_joins; i++) listed = listed || joins[i] == OTHER_SIDE_STREAMS - 1;
             if (!listed) joins[n_joins++] = OTHER_SIDE_STREAMS - 1;
@@ -831,7 +837,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
                                       stream));
     }
-    for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(stream, mat->join_ev[joins[i]], 0));
+    for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[joins[i]], 0));
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
     mat->n_timed++;
     mat->last_passes = passes;
@@ -929,9 +935,10 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 
     hipError_t e = hipSuccess;
-    if (!mat->pipe_compute) {
-        e = hipStreamCreateWithFlags(&mat->pipe_compute, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mat->pipe_h2d, hipStreamNonBlocking);
+    if (!mat->pipe_h2d) {
+        e = hipStreamCreateWithFlags(&mat->pipe_h2d, hipStreamNonBlocking);
+        for (hipStream_t& st : mat->pipe_compute)
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&mat->pipe_d2h, hipStreamNonBlocking);
         for (uint32_t i = 0; i < wepp_mat::kPipeMax && e == hipSuccess; i++) {
             e = hipEventCreateWithFlags(&mat->pipe_up[i], hipEventDisableTiming);
@@ -1092,14 +1099,16 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
             hipError_t he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(hi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
             if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
             if (he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d);
-            if (he == hipSuccess) he = hipStreamWaitEvent(mat->pipe_compute, mat->pipe_up[k], 0);
+            const uint32_t ln = k % wepp_mat::kLanes;             // (sub-batches alternate between the handle's two lanes)
+            hipStream_t cs = mat->pipe_compute[ln];
+            if (he == hipSuccess) he = hipStreamWaitEvent(cs, mat->pipe_up[k], 0);
             if (he == hipSuccess) {
                 // (the offsets of a sub-batch index the whole call's word array: no rebasing)
                 const int prc = place_device(mat, d_off + lo, d_word, hi - lo, d_out + lo, (int32_t*)(d_out + n_reads) + lo,
-                                             d_out + 2 * (size_t)n_reads + lo, d_out + 3 * (size_t)n_reads + lo, mat->pipe_compute, lo, n_reads);
+                                             d_out + 2 * (size_t)n_reads + lo, d_out + 3 * (size_t)n_reads + lo, cs, lo, n_reads, ln);
                 if (prc != WEPP_OK) { rc = prc; rc_msg = wepp_last_error(); launched[k].store(-1, std::memory_order_release); continue; }
             }
-            if (he == hipSuccess) he = hipEventRecord(mat->pipe_done[k], mat->pipe_compute);
+            if (he == hipSuccess) he = hipEventRecord(mat->pipe_done[k], cs);
             if (he == hipSuccess) he = hipStreamWaitEvent(mat->pipe_d2h, mat->pipe_done[k], 0);
             for (int i = 0; i < 4 && he == hipSuccess; i++) {
                 if (!dst[i]) continue;
@@ -1129,8 +1138,9 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     // everything this call put on the handle's streams has finished before it returns -- also after an error, and
     // when no result array was asked for (the staging buffers belong to the next call then)
     {
-        hipError_t s1 = hipStreamSynchronize(mat->pipe_d2h), s2 = hipStreamSynchronize(mat->pipe_compute), s3 = hipStreamSynchronize(mat->pipe_h2d);
-        const hipError_t se = s1 != hipSuccess ? s1 : s2 != hipSuccess ? s2 : s3;
+        hipError_t s1 = hipStreamSynchronize(mat->pipe_d2h), s2 = hipStreamSynchronize(mat->pipe_compute[0]), s3 = hipStreamSynchronize(mat->pipe_h2d);
+        const hipError_t s4 = hipStreamSynchronize(mat->pipe_compute[1]);
+        const hipError_t se = s1 != hipSuccess ? s1 : s2 != hipSuccess ? s2 : s3 != hipSuccess ? s3 : s4;
         if (se != hipSuccess && rc == WEPP_OK) { rc = hip_fail(se, "placement kernels / copies"); rc_msg = wepp_last_error(); }
     }
     for (uint32_t t = 0; t < n_stage; t++) {
@@ -1148,7 +1158,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         const size_t nb = (size_t)n_reads * mat->dev.N * sizeof(int32_t);
         e = hipMalloc((void**)&d_pns, nb);
         if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc per_node_scores: ") + hipGetErrorString(e));
-        e = launch_scores(mat->dev, mat->streams.back(), d_off, d_word, n_reads, d_pns, nullptr);
+        e = launch_scores(mat->dev, mat->streams.back(), d_off, d_word, n_reads, d_pns, nullptr);   // (everything above has been synchronised)
         if (e == hipSuccess) e = hipMemcpy(per_node_scores, d_pns, nb, hipMemcpyDeviceToHost);
         (void)hipFree(d_pns);
         if (e != hipSuccess) return hip_fail(e, "per-node score kernel");
@@ -1386,15 +1396,15 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     DevMAT dm = mat->dev;
     dm.n_windows = 0;
     dm.wc_windows = 0;            // (and no window crowns: the list is made on the tree-wide streams)
-    uint32_t* tier_info = mat->d_info + mat->info_idx * TI_WORDS;
-    uint32_t* tier_info_next = mat->d_info + (mat->info_idx ^ 1u) * TI_WORDS;
-    uint32_t* blk_counts = mat->d_info + 2 * TI_WORDS;
+    uint32_t* tier_info = mat->lane[0].d_info + mat->lane[0].info_idx * TI_WORDS;
+    uint32_t* tier_info_next = mat->lane[0].d_info + (mat->lane[0].info_idx ^ 1u) * TI_WORDS;
+    uint32_t* blk_counts = mat->lane[0].d_info + 2 * TI_WORDS;
     HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
                          d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, nullptr));
-    mat->info_idx ^= 1u;
+    mat->lane[0].info_idx ^= 1u;
     HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
-    HIP_TRY(hipMemcpy(mat->h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const uint32_t* info = mat->h_info;
+    HIP_TRY(hipMemcpy(mat->lane[0].h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t* info = mat->lane[0].h_info;
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;

@@ -17,7 +17,26 @@
 
 using namespace wepp;
 
+// What ONE placement call in flight needs of its own: workspace, routing counters, the side streams its launch
+// chains run on.  A handle has two: the sub-batches of wepp_place_batch alternate between them, so that the routing
+// of sub-batch k+1 (kernels, a device-to-host copy, the host's poll) overlaps the walks of sub-batch k, each lane's
+// work ordered on the lane's own compute stream.  wepp_place_batch_device uses lane 0.
+struct PlaceLane {
+    // grow-only workspace: read list, routing arrays, partial results
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    void* ws2 = nullptr;              // grow-only workspace of the chunked walks (job tables, partials)
+    size_t ws2_bytes = 0;
+    uint32_t* d_info = nullptr;       // two sets of tier_info (TI_WORDS each, used alternately: k_route clears the other one) followed by blk_counts
+    uint32_t info_idx = 0;            // the set the next call uses (zero: cleared at creation or by the previous call's k_route)
+    uint32_t* h_info = nullptr;       // pinned copy of tier_info
+    // the launch chains of a call are independent: they run concurrently on side streams
+    hipStream_t side[MAX_STREAMS] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
+};
+
 struct wepp_mat {
+    static constexpr uint32_t kLanes = 2;
     int device = 0;
     DevMAT dev{};
     std::vector<DevStream> streams;
@@ -62,7 +81,7 @@ struct wepp_mat {
     // pipe_compute and the results of k-2 come down on pipe_d2h; one event per sub-batch and stage
     static constexpr uint32_t kPipeMax = 8;
     uint32_t pipe_sub_batches = 0;    // 0: chosen per call (4 from 262 144 reads, 2 from 65 536, else 1)
-    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_compute = nullptr;
+    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_compute[kLanes] = {};
     hipEvent_t pipe_up[kPipeMax] = {}, pipe_done[kPipeMax] = {}, pipe_out[kPipeMax] = {};
     void* pin_out = nullptr;          // pinned staging of the results (the reads' staging is `pin`)
     size_t pin_out_bytes = 0;
@@ -71,17 +90,7 @@ struct wepp_mat {
     uint32_t* d_wsid_of = nullptr;    // window crown (index into DevMAT::wc_info) of the reads routed to slot WC_SLOT, same sizing
     uint8_t* d_plan_of = nullptr;
     size_t plan_of_bytes = 0;
-    // grow-only workspace: tier of each read, read list, routing counters, partial results
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
-    void* ws2 = nullptr;              // grow-only workspace of the chunked walks (job tables, partials)
-    size_t ws2_bytes = 0;
-    uint32_t* d_info = nullptr;       // two sets of tier_info (TI_WORDS each, used alternately: k_route clears the other one) followed by blk_counts
-    uint32_t info_idx = 0;            // the set the next call uses (zero: cleared at creation or by the previous call's k_route)
-    uint32_t* h_info = nullptr;       // pinned copy of tier_info
-    // the sweeps of different streams are independent: they run concurrently on side streams
-    hipStream_t side[MAX_STREAMS] = {};
-    hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
+    PlaceLane lane[2];
     static constexpr uint32_t kRing = 64;
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_timed = 0;             // placement calls since the last timing reset
