@@ -49,8 +49,9 @@ void release(wepp_mat* h) {
     for (uint32_t i = 0; i < wepp_mat::kPipeMax; i++) {
         if (h->pipe_up[i]) (void)hipEventDestroy(h->pipe_up[i]);
         if (h->pipe_done[i]) (void)hipEventDestroy(h->pipe_done[i]);
-        if (h->pipe_out[i]) (void)hipEventDestroy(h->pipe_out[i]);
     }
+    for (uint32_t i = 0; i < 4 * wepp_mat::kPipeMax; i++)
+        if (h->pipe_out[i]) (void)hipEventDestroy(h->pipe_out[i]);
     if (h->pipe_h2d) (void)hipStreamDestroy(h->pipe_h2d);
     if (h->pipe_d2h) (void)hipStreamDestroy(h->pipe_d2h);
     for (hipStream_t st : h->pipe_compute)
@@ -943,8 +944,9 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         for (uint32_t i = 0; i < wepp_mat::kPipeMax && e == hipSuccess; i++) {
             e = hipEventCreateWithFlags(&mat->pipe_up[i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&mat->pipe_done[i], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&mat->pipe_out[i], hipEventDisableTiming);
         }
+        for (uint32_t i = 0; i < 4 * wepp_mat::kPipeMax && e == hipSuccess; i++)
+            e = hipEventCreateWithFlags(&mat->pipe_out[i], hipEventDisableTiming);
         if (e != hipSuccess) return hip_fail(e, "pipeline streams / events");
     }
     // ---- buffers: grow-only, on the handle (no hipMalloc / hipFree per call) ----
@@ -991,13 +993,21 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     }
     static const uint32_t pipe_env = getenv("WEPP_PIPE_SUBBATCHES") ? (uint32_t)std::max(1, atoi(getenv("WEPP_PIPE_SUBBATCHES"))) : 0u;
     const uint32_t pipe_knob = mat->pipe_sub_batches ? mat->pipe_sub_batches : pipe_env;
-    uint32_t S = !big || per_node_scores ? 1u : pipe_knob ? pipe_knob : (n_reads >= (1u << 18) ? 4u : 2u);
+    // S sub-batches = device calls.  A device call is a chain of ~20 short launches with a host round trip in the
+    // middle (routing counters): ~0.3 ms whatever its size up to a million short reads, most of it the HOST's share,
+    // which two calls cannot overlap -- so a batch is only cut into several calls when each keeps >= 2 M reads
+    // (measured, profiles/r3_experiments/pcie_pipeline.txt: 1 M reads in 2 / 4 / 8 calls 1.41 / 1.98 / 3.07 ms against
+    // 1.28 in one).  C copy chunks >= S: the reads are checked, staged and sent up chunk by chunk, whatever S.
+    uint32_t S = !big || per_node_scores ? 1u : pipe_knob ? pipe_knob : std::max<uint32_t>(1u, n_reads >> 21);
     S = std::min<uint32_t>(S, wepp_mat::kPipeMax);
+    const uint32_t C = big ? S * ((4 + S - 1) / S) : 1;                        // copy chunks (a multiple of S, >= 4)
+    const uint32_t CPS = C / S;                                                // chunks per sub-batch
     const uint32_t threads = big ? mat->pool->workers() + 1 : 1;
-    const uint32_t PS = big ? std::max(1u, (4 * threads + S - 1) / S) : 1;     // staging parts per sub-batch
+    const uint32_t PS = big ? std::max(1u, (4 * threads + C - 1) / C) : 1;     // staging parts per chunk
     const uint32_t PO = big ? 4 : 1;                                           // copy-out parts per (sub-batch, array)
-    auto sub_lo = [&](uint32_t k) { return (uint32_t)((uint64_t)n_reads * k / S); };
-    const uint32_t n_stage = S * PS, n_copy = any_staged_out ? S * 4 * PO : 0;
+    auto chunk_lo = [&](uint32_t c) { return (uint32_t)((uint64_t)n_reads * c / C); };
+    auto sub_lo = [&](uint32_t k) { return chunk_lo(k * CPS); };
+    const uint32_t n_stage = C * PS, n_copy = any_staged_out ? S * 4 * PO : 0;
 
     // preconditions of the reference's merge (usher_mapper.cpp:205-243): sorted, unique positions.  Checked by the
     // staging tasks, each moving its reads into the pinned staging buffer as it goes (one pass over the input); the
@@ -1049,16 +1059,17 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     };
     std::vector<uint32_t> bad(n_stage, 0xFFFFFFFFu);
     std::vector<int> what(n_stage, 0);
-    std::vector<std::atomic<uint32_t>> staged(S);          // staging parts of a sub-batch that are done
+    std::vector<std::atomic<uint32_t>> staged(C);          // staging parts of a chunk that are done
     std::vector<std::atomic<int>> launched(S);             // 0: not yet; 1: its D2H is enqueued (pipe_out[k] recorded); -1: never will be
-    for (uint32_t k = 0; k < S; k++) { staged[k].store(0); launched[k].store(0); }
+    for (uint32_t c = 0; c < C; c++) staged[c].store(0);
+    for (uint32_t k = 0; k < S; k++) launched[k].store(0);
     std::vector<hipError_t> copy_err(std::max<uint32_t>(n_copy, 1), hipSuccess);
     auto stage_task = [&](uint32_t t) {
-        const uint32_t k = t / PS, part = t % PS;
-        const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
+        const uint32_t ck = t / PS, part = t % PS;
+        const uint32_t lo = chunk_lo(ck), hi = chunk_lo(ck + 1);
         const uint32_t a = lo + (uint32_t)((uint64_t)(hi - lo) * part / PS), b = lo + (uint32_t)((uint64_t)(hi - lo) * (part + 1) / PS);
         if (b > a) check(a, b, bad[t], what[t]);
-        staged[k].fetch_add(1, std::memory_order_release);
+        staged[ck].fetch_add(1, std::memory_order_release);
     };
     auto copy_task = [&](uint32_t t) {          // t in [0, n_copy): (sub-batch, array, part)
         const uint32_t k = t / (4 * PO), i = (t / PO) % 4, part = t % PO;
@@ -1067,7 +1078,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         while ((st = launched[k].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
         if (st < 0) return;
         (void)hipSetDevice(mat->device);                              // (a worker thread starts on device 0)
-        copy_err[t] = hipEventSynchronize(mat->pipe_out[k]);          // the sub-batch's four arrays have landed
+        copy_err[t] = hipEventSynchronize(mat->pipe_out[k * 4 + i]);  // this array of the sub-batch has landed (the next one is on the bus)
         if (copy_err[t] != hipSuccess) return;
         const size_t lo = sub_lo(k), hi = sub_lo(k + 1);
         const size_t a = lo + (hi - lo) * part / PO, b = lo + (hi - lo) * (part + 1) / PO;
@@ -1082,22 +1093,28 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     bool rejected = false;
     auto launch_all = [&]() {
         for (uint32_t k = 0; k < S; k++) {
-            while (staged[k].load(std::memory_order_acquire) < PS) std::this_thread::yield();
+            const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
+            const uint32_t* src_off = in_pinned ? read_off : pin_off;
+            const uint32_t* src_word = in_pinned ? read_word : pin_word;
+            hipError_t he = hipSuccess;
             bool ok = rc == WEPP_OK && !rejected;
-            for (uint32_t t = k * PS; t < (k + 1) * PS && ok; t++) ok = bad[t] == 0xFFFFFFFFu;
+            // the sub-batch's chunks go up one by one, each as soon as its reads are checked and staged
+            for (uint32_t ck = k * CPS; ck < (k + 1) * CPS && ok && he == hipSuccess; ck++) {
+                while (staged[ck].load(std::memory_order_acquire) < PS) std::this_thread::yield();
+                for (uint32_t t = ck * PS; t < (ck + 1) * PS && ok; t++) ok = bad[t] == 0xFFFFFFFFu;
+                if (!ok) break;
+                const uint32_t clo = chunk_lo(ck), chi = chunk_lo(ck + 1);
+                const uint32_t w0 = read_off[clo], w1 = read_off[chi];
+                // (offset `clo` went up with the chunk before: the kernels of the sub-batch before may be reading it)
+                const uint32_t o0 = ck ? clo + 1 : clo;
+                he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(chi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+                if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+            }
             if (!ok) {       // nothing of a rejected batch reaches a kernel, and nothing behind it is worth placing
                 rejected = true;
                 launched[k].store(-1, std::memory_order_release);
                 continue;
             }
-            const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
-            const uint32_t w0 = read_off[lo], w1 = read_off[hi];
-            const uint32_t* src_off = in_pinned ? read_off : pin_off;
-            const uint32_t* src_word = in_pinned ? read_word : pin_word;
-            // (offset `lo` went up with the sub-batch before: the kernels of k-1 may be reading it)
-            const uint32_t o0 = k ? lo + 1 : lo;
-            hipError_t he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(hi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
-            if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
             if (he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d);
             const uint32_t ln = k % wepp_mat::kLanes;             // (sub-batches alternate between the handle's two lanes)
             hipStream_t cs = mat->pipe_compute[ln];
@@ -1114,8 +1131,8 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
                 if (!dst[i]) continue;
                 uint32_t* to = out_pinned[i] ? (uint32_t*)dst[i] : po + (size_t)i * n_reads;
                 he = hipMemcpyAsync(to + lo, d_out + (size_t)i * n_reads + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, mat->pipe_d2h);
+                if (he == hipSuccess) he = hipEventRecord(mat->pipe_out[k * 4 + i], mat->pipe_d2h);   // an array is moved out while the next one comes down
             }
-            if (he == hipSuccess) he = hipEventRecord(mat->pipe_out[k], mat->pipe_d2h);
             if (he != hipSuccess) {
                 rc = hip_fail(he, "H2D / kernels / D2H of a sub-batch");
                 rc_msg = wepp_last_error();

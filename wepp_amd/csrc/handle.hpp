@@ -80,9 +80,9 @@ struct wepp_mat {
     // wepp_place_batch as a pipeline: sub-batch k's reads go up on pipe_h2d while the kernels of k-1 run on
     // pipe_compute and the results of k-2 come down on pipe_d2h; one event per sub-batch and stage
     static constexpr uint32_t kPipeMax = 8;
-    uint32_t pipe_sub_batches = 0;    // 0: chosen per call (4 from 262 144 reads, 2 from 65 536, else 1)
+    uint32_t pipe_sub_batches = 0;    // 0: chosen per call (one device call per 2 M reads, at most 8)
     hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_compute[kLanes] = {};
-    hipEvent_t pipe_up[kPipeMax] = {}, pipe_done[kPipeMax] = {}, pipe_out[kPipeMax] = {};
+    hipEvent_t pipe_up[kPipeMax] = {}, pipe_done[kPipeMax] = {}, pipe_out[4 * kPipeMax] = {};   // (pipe_out: one per sub-batch and result array)
     void* pin_out = nullptr;          // pinned staging of the results (the reads' staging is `pin`)
     size_t pin_out_bytes = 0;
     // plan id of every read of the most recent placement call (k_route writes it; wepp_mat_last_tiers / _plans read it);
