@@ -36,6 +36,8 @@ void release(wepp_mat* h) {
             if (L.join_ev[i]) (void)hipEventDestroy(L.join_ev[i]);
         }
         if (L.fork_ev) (void)hipEventDestroy(L.fork_ev);
+        if (L.info_ev) (void)hipEventDestroy(L.info_ev);
+        if (L.d_wplans) (void)hipFree(L.d_wplans);
     }
     if (h->io_in) (void)hipFree(h->io_in);
     if (h->io_out) (void)hipFree(h->io_out);
@@ -292,6 +294,9 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&L.join_ev[i], hipEventDisableTiming);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L.info_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void**)&L.d_wplans, 2 * sizeof(WalkPlans));
+        if (e == hipSuccess) e = hipMemset(L.d_wplans, 0, 2 * sizeof(WalkPlans));
     }
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
         e = hipEventCreate(&h->ev0[i]);
@@ -469,15 +474,30 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         int rc = route();
         if (rc != WEPP_OK) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    // the host sizes the launches from the counters, and the GPU idles until it has: poll for them (a
-    // blocking wait adds its wake-up, ~15 us per call, to that idle time); after ~0.1 s of polling -- a long
-    // queue in front of this call -- wait blocking
+    // ---- the plain walks start at once; the host's round trip for the counters overlaps them ----------------
+    // Nearly every short read is placed by a plain walk (4.2 / 4.2c).  Their plans are made on the device
+    // (k_plan_walks, behind k_scatter) and both classes are launched NOW, with grids that cover every read: the GPU
+    // does not idle while the counters travel to the host, are polled for and the rarer launch chains (chunked
+    // walks, sweeps) are sized from them -- those fork from the point before the walks and run beside them.
+    const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
+    HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
+    if (mat->use_walk) HIP_TRY(launch_plan_walks(tier_info, list, L.d_wplans, stream));
+    HIP_TRY(hipEventRecord(L.fork_ev, stream));
+    if (mat->use_walk)
+        HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, n_reads, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score, d_num_best,
+                                 d_flags, mat->d_work, wsid, stream));
+    // the counters come over a side stream (the caller's stream is busy with the walks), signalled by an event the
+    // host polls (a blocking wait adds its wake-up, ~15 us per call); after ~0.1 s of polling -- a long queue in
+    // front of this call -- wait blocking
     {
+        hipStream_t qi = L.side[MAX_STREAMS - 1];
+        HIP_TRY(hipStreamWaitEvent(qi, L.fork_ev, 0));
+        HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, qi));
+        HIP_TRY(hipEventRecord(L.info_ev, qi));
         hipError_t q = hipErrorNotReady;
-        for (int spin = 0; spin < 200000 && (q = hipStreamQuery(stream)) == hipErrorNotReady; spin++) {}
+        for (int spin = 0; spin < 200000 && (q = hipEventQuery(L.info_ev)) == hipErrorNotReady; spin++) {}
         (void)hipGetLastError();   // "not ready" is not an error: keep it out of the launchers' hipGetLastError()
-        if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
+        if (q != hipSuccess) HIP_TRY(hipEventSynchronize(L.info_ev));
     }
     const uint32_t* info = L.h_info;
     for (uint32_t cc = 0; cc < 2; cc++) {
@@ -640,8 +660,6 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // The plain (short-read) plans are fused into ONE launch, longest chunks first; dense
     // and out-of-LDS plans get their own launch on a side stream forked from / joined into
     // `stream`.  Every plan's finalize follows its sweep.
-    const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
-    HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
     uint64_t passes = 0, bytes = 0;
     auto parts = [&](const Plan& p, int32_t*& ps, uint32_t*& pr, uint32_t*& pc) {
         ps = (int32_t*)(part_base + p.part_off);
@@ -665,10 +683,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         if (walk[cls].n) passes += walk[cls].p[walk[cls].n - 1].wave_end;   // a walk "pass" = one wave of 64 reads
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
-    const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
-    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
-    const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
-    if (fork) HIP_TRY(hipEventRecord(L.fork_ev, stream));
+    // (the plain walks are on the caller's stream already; every other chain forks from the point before them)
+    const uint32_t n_chains = n_other + ((walkc[0].n || walkc[1].n) ? 1u : 0u) + (arena_n ? 1u : 0u);
+    const bool fork = !unfused && (n_chains > 0 || n_plain > 0);
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
     uint32_t joins[MAX_STREAMS], n_joins = 0;
@@ -692,29 +709,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         return WEPP_OK;
     };
     if (walks) {
-        // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
-        // sweeps run side by side (the walks wait on memory most of the time)
-        hipStream_t q = fork ? L.side[MAX_STREAMS - 1] : stream;
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
-        for (uint32_t cls = 0; cls < 2; cls++) {
-            if (!walk[cls].n) continue;
-            // (the plain classes keep the caller's order unless WEPP_WALK_SORT_PLAIN=1: their reads have at most 16
-            // events each, mostly on streams the L2s hold anyway, and a sort of 1 M reads costs 0.15 ms of a 0.3 ms step)
-            static const bool sort_plain = getenv("WEPP_WALK_SORT_PLAIN") && getenv("WEPP_WALK_SORT_PLAIN")[0] == '1';
-            bool sorted = false;
-            if (sort_plain) {
-                int rc = sort_class(cls, 1 + cls, q, sorted);
-                if (rc != WEPP_OK) return rc;
-            }
-            if (sorted)
-                for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = val_in + walk_off[cls][k];
-            HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
-                                d_num_best, d_flags, mat->d_work, wsid, q));
-        }
-        if (fork) {
-            HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
-            joins[n_joins++] = MAX_STREAMS - 1;
-        }
+        hipStream_t q = stream;
         if (walkc[0].n || walkc[1].n) {
             // chunked walks, per class: jobs per read in list order -> exclusive scan -> the walk (a partial per
             // job; a job finds its read by bisection in the scanned offsets) -> one combination per read.
@@ -834,9 +829,18 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             lds_max = std::max(lds_max, p.lds_bytes);
         }
         pl.n = n_plain;
-        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, stream));
-        HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
-                                      stream));
+        // (beside the plain walks, which hold the caller's stream)
+        constexpr uint32_t SW = OTHER_SIDE_STREAMS - 2;
+        hipStream_t q = fork ? L.side[SW] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
+        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, q));
+        HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags, q));
+        if (fork) {
+            HIP_TRY(hipEventRecord(L.join_ev[SW], q));
+            bool listed = false;
+            for (uint32_t i = 0; i < n_joins; i++) listed = listed || joins[i] == SW;
+            if (!listed) joins[n_joins++] = SW;
+        }
     }
     for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[joins[i]], 0));
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));

@@ -126,7 +126,7 @@ constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of 
 // waves of a walk plan are padded to a multiple of this, so that every plan starts at a workgroup index that is a
 // multiple of the XCD count and its waves can be dealt to the XCDs in contiguous runs (k_walk)
 constexpr uint32_t WALK_PLAN_ALIGN = WALK_XCDS * WALK_WAVES;
-inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
+__host__ __device__ inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
@@ -154,10 +154,12 @@ struct WalkPlans {
     uint32_t n;
     WalkPlanDev p[MAX_STREAMS];
 };
-// cls = 0 / 1: the plans of one class in ONE launch, a wave = 64 reads; writes the final per-read results
-hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
-                       const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
+// the plain walks of a call, both classes, launched before the host has seen the routing counters: plans in device
+// memory (launch_plan_walks behind k_scatter), a grid that covers every read; they write the final per-read results
+hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, WalkPlans* d_plans, hipStream_t stream);
+hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t n_reads, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
+                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,

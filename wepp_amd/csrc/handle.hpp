@@ -33,6 +33,8 @@ struct PlaceLane {
     // the launch chains of a call are independent: they run concurrently on side streams
     hipStream_t side[MAX_STREAMS] = {};
     hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
+    hipEvent_t info_ev = nullptr;     // the routing counters have reached h_info (polled by the host)
+    WalkPlans* d_wplans = nullptr;    // [2] the plain walk plans of the call, written on the device (k_plan_walks)
 };
 
 struct wepp_mat {

@@ -1352,7 +1352,7 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
 // whole tree for a read with three entries.  Same results (tests/walk_model.py is the CPU model).
 // -----------------------------------------------------------------------------
 template <int KW, int SD, bool CHUNKED>
-__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, uint32_t sd_rows,
+__device__ __forceinline__ void walk_body(const DevMAT& m, const WalkPlans& pl, const WalkJobs& jb, uint32_t sd_rows,
                                               const uint32_t* __restrict__ read_off,
                                               const uint32_t* __restrict__ read_word,
                                               const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
     auto sword = [&](int j) -> uint32_t { return ((S16[(j >> 1) * 64 + lane] >> ((j & 1) * 16)) & 0x1FFu) << 20; };
     const uint32_t unit = blockIdx.x * WALK_WAVES + wv;
-    if (unit >= pl.p[pl.n - 1].wave_end) return;
+    if (pl.n == 0 || unit >= pl.p[pl.n - 1].wave_end) return;
 #ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
     unsigned long long ts_[6];
     ts_[0] = __builtin_amdgcn_s_memtime();
@@ -1815,6 +1815,47 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
         }
     }
 #endif
+}
+
+// the chunked walks: plans and job tables from the host (kernel arguments), launched once the routing counters are known
+template <int KW, int SD>
+__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, uint32_t sd_rows,
+                                              const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                                              const int32_t* __restrict__ root_score, unsigned long long* __restrict__ work_counter,
+                                              const uint32_t* __restrict__ wsid) {
+    walk_body<KW, SD, true>(m, pl, jb, sd_rows, read_off, read_word, root_score, nullptr, nullptr, nullptr, nullptr, work_counter, wsid);
+}
+// the plain walks: launched BEFORE the host has seen the routing counters, with a grid that covers every read -- the
+// plans come from device memory (k_plan_walks wrote them behind k_scatter), the waves beyond the class's reads leave at
+// once.  The host's round trip for the counters (which sizes the rarer launch chains) overlaps these walks.
+template <int KW, int SD>
+__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_spec(DevMAT m, const WalkPlans* __restrict__ pl, uint32_t sd_rows,
+                                              const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                                              const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
+                                              int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best,
+                                              uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter,
+                                              const uint32_t* __restrict__ wsid) {
+    const WalkJobs none{};
+    walk_body<KW, SD, false>(m, *pl, none, sd_rows, read_off, read_word, root_score, best_bfs_j, score_out, num_best, flags, work_counter, wsid);
+}
+// the plain walk plans of a call, on the device: out[cls] = the (class, stream) plans with reads, their lists and waves
+__global__ void k_plan_walks(const uint32_t* __restrict__ tier_info, const uint32_t* __restrict__ list, WalkPlans* __restrict__ out) {
+    const uint32_t cls = threadIdx.x;
+    if (cls >= 2) return;
+    WalkPlans& wp = out[cls];
+    uint32_t n = 0, wave_end = 0;
+    for (uint32_t t = 0; t < MAX_STREAMS; t++) {
+        const uint32_t id = plan_id(cls, t), count = tier_info[TI_COUNT + id];
+        if (!count) continue;
+        wave_end += walk_plan_waves(count);
+        wp.p[n].tier = t;
+        wp.p[n].n_list = count;
+        wp.p[n].wave_end = wave_end;
+        wp.p[n].job0 = 0;
+        wp.p[n].list = list + tier_info[TI_OFF + id];
+        n++;
+    }
+    wp.n = n;
 }
 
 // job counts in list order (the input of the scan)
@@ -2277,22 +2318,24 @@ static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVE
 // scratch, never more than the class admits
 static uint32_t walk_stack_rows(uint32_t open_max, uint32_t sd) { return std::min(sd, std::max(open_max, 2u)); }
 
-hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
-                       const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
-    if (pl.n == 0) return hipSuccess;
-    const uint32_t waves = pl.p[pl.n - 1].wave_end;
+hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, WalkPlans* d_plans, hipStream_t stream) {
+    hipLaunchKernelGGL(k_plan_walks, dim3(1), dim3(64), 0, stream, tier_info, list, d_plans);
+    return hipGetLastError();
+}
+
+// the plain walks of both classes for a call of n_reads reads, plans in device memory (d_plans[2], k_plan_walks)
+hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t n_reads, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
+                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
+    // every read could be in either class, every plan is padded to WALK_PLAN_ALIGN waves
+    const uint32_t waves = (n_reads + 63) / 64 + MAX_STREAMS * WALK_PLAN_ALIGN;
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
-    const WalkJobs none{};
-    if (cls == PLAN_WALK8) {
-        const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
-        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl,
-                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
-    } else {
-        const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
-        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl,
-                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
-    }
+    hipLaunchKernelGGL((k_walk_spec<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, WALK8_STACK), stream, m, d_plans,
+                       WALK8_STACK, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, WALK16_STACK), stream, m, d_plans + 1,
+                       WALK16_STACK, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     return hipGetLastError();
 }
 
@@ -2310,14 +2353,12 @@ hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, 
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
     if (cls == PLAN_WALKC8) {
         const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
-        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
-                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, work_counter, wsid);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, work_counter, wsid);
     } else {
         const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
-        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
-                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, work_counter, wsid);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, work_counter, wsid);
     }
     return hipGetLastError();
 }
