@@ -456,8 +456,15 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     static const uint32_t job_events_env = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::min(0xFFFF, std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS")))) : 0u;
     const uint32_t job_events = job_events_env ? (job_events_env | (job_events_env << 16)) : (mat->job_events[0] | (mat->job_events[1] << 16));
     static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
-    static const uint32_t stack8 = getenv("WEPP_WALK_STACK8") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK8")) : WALK8_ROWS;
-    static const uint32_t stack16 = getenv("WEPP_WALK_STACK16") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK16")) : WALK16_ROWS;
+    // Stack rows of the walks = the LDS of their workgroups = how many waves a CU holds (the walks wait on memory).  The
+    // plain walks are launched before the host knows what this call's reads need, so the rows are what the handle's
+    // LAST call asked for (TI_WANT: the deepest stack of any read short enough to walk; the class's full depth on the
+    // first call) and k_route is given the same numbers as limits: a read that needs more sweeps its window crown
+    // instead, and raises the rows of the next call.  WEPP_WALK_STACK8 / 16 fix them.
+    static const uint32_t stack8_env = getenv("WEPP_WALK_STACK8") ? (uint32_t)std::max(0, atoi(getenv("WEPP_WALK_STACK8"))) : 0u;
+    static const uint32_t stack16_env = getenv("WEPP_WALK_STACK16") ? (uint32_t)std::max(0, atoi(getenv("WEPP_WALK_STACK16"))) : 0u;
+    const uint32_t stack8 = std::min<uint32_t>(WALK8_ROWS, stack8_env ? stack8_env : mat->walk_rows[0]);
+    const uint32_t stack16 = std::min<uint32_t>(WALK16_ROWS, stack16_env ? stack16_env : mat->walk_rows[1]);
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
@@ -485,7 +492,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     HIP_TRY(hipEventRecord(L.fork_ev, stream));
     if (mat->use_walk)
         HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, n_reads, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score, d_num_best,
-                                 d_flags, mat->d_work, wsid, stream));
+                                 d_flags, mat->d_work, wsid, stack8, stack16, stream));
     // the counters come over a side stream (the caller's stream is busy with the walks), signalled by an event the
     // host polls (a blocking wait adds its wake-up, ~15 us per call); after ~0.1 s of polling -- a long queue in
     // front of this call -- wait blocking
@@ -504,6 +511,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         const uint64_t ev = (uint64_t)info[TI_EVENTS + cc] << 6;
         const uint32_t je = (uint32_t)std::min<uint64_t>(WALK_JOB_EVENTS_MAX, std::max<uint64_t>(WALK_JOB_EVENTS, ev / WALK_TARGET_JOBS));
         mat->job_events[cc] = (je + 15u) & ~15u;       // (what the NEXT call's k_route cuts this class's walks into)
+        // ... and the stack rows its walks get: what this call's reads asked for, two to spare
+        mat->walk_rows[cc] = std::min<uint32_t>(cc ? WALK16_ROWS : WALK8_ROWS, std::max<uint32_t>(4u, info[TI_WANT + cc] + 2u));
     }
 
     // ---- plan the launches ---------------------------------------------------------
@@ -632,6 +641,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             carve();
             rc = route();
             if (rc != WEPP_OK) return rc;
+            // (the launch chains below fork from HERE now: their lists are the ones this second routing writes; the
+            // plain walks have run on the first one's -- grow() waited for them before it let the old buffer go)
+            HIP_TRY(hipEventRecord(L.fork_ev, stream));
         }
     }
     char* part_base = (char*)L.ws + fixed_bytes;

@@ -159,7 +159,8 @@ struct WalkPlans {
 hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, WalkPlans* d_plans, hipStream_t stream);
 hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t n_reads, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
+                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
+                            uint32_t rows8, uint32_t rows16, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,
@@ -296,6 +297,7 @@ hipError_t sweep_set_max_lds(uint32_t bytes);
 constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
                    TI_OPEN = TI_JOBS + 2 * MAX_STREAMS,      // [4] deepest stack of the walk classes (WALK8, WALK16, WALKC8, WALKC16)
                    TI_EVENTS = TI_OPEN + 4,                  // [2] events (in units of 64) of the reads of the two chunked classes
-                   TI_WORDS = TI_EVENTS + 2;
+                   TI_WANT = TI_EVENTS + 2,                  // [2] deepest stack any read of up to WALK8_K / WALK16_K entries asked for, walked or not
+                   TI_WORDS = TI_WANT + 2;
 
 }  // namespace wepp

@@ -46,6 +46,7 @@ struct wepp_mat {
     uint64_t wc_nodes = 0;            // nodes of all window crowns (the arena of slot WC_SLOT)
     uint32_t wc_count = 0;            // window crowns built
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
+    uint32_t walk_rows[2] = {WALK8_ROWS, WALK16_ROWS};             // stack rows of the walks (and k_route's limits) in the next call
     uint32_t job_events[2] = {WALK_JOB_EVENTS, WALK_JOB_EVENTS};   // events per job of the chunked classes in the next call
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
     unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset

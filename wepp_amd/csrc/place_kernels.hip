@@ -203,13 +203,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next,
                                                           uint32_t* __restrict__ wsid) {
-    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2];
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2], want_of[2];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
     if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
     if (threadIdx.x < 4) open_of[threadIdx.x] = 0;
-    if (threadIdx.x < 2) events_of[threadIdx.x] = 0;
+    if (threadIdx.x < 2) { events_of[threadIdx.x] = 0; want_of[threadIdx.x] = 0; }
     if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
@@ -270,6 +270,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             open_out = open_max;
             ev_out = events;
             nj_out = 0;
+            // (what the host sizes the NEXT call's stacks from: the deepest stack asked for, granted or not)
+            atomicMax(&want_of[k <= WALK8_K ? 0 : 1], min(open_max, k <= WALK8_K ? WALK8_STACK : WALK16_STACK));
             // (stack8 <= WALK8_STACK, stack16 <= WALK16_STACK: the stack rows the walks' workgroups get; the few
             // reads that could hold more intervals open are left to the sweeps)
             if (events <= walk_max_events) {
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
     if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
     if (threadIdx.x < 2 && events_of[threadIdx.x]) atomicAdd(&tier_info[TI_EVENTS + threadIdx.x], (events_of[threadIdx.x] + 63) >> 6);
+    if (threadIdx.x < 2 && want_of[threadIdx.x]) atomicMax(&tier_info[TI_WANT + threadIdx.x], want_of[threadIdx.x]);
 }
 
 // -----------------------------------------------------------------------------
@@ -2326,16 +2329,20 @@ hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, Wa
 // the plain walks of both classes for a call of n_reads reads, plans in device memory (d_plans[2], k_plan_walks)
 hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t n_reads, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
+                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
+                            uint32_t rows8, uint32_t rows16, hipStream_t stream) {
+    // rows8 / rows16: the stack rows of the two launches = the limits this call's k_route was given
+    rows8 = walk_stack_rows(rows8, WALK8_STACK);
+    rows16 = walk_stack_rows(rows16, WALK16_STACK);
     // every read could be in either class, every plan is padded to WALK_PLAN_ALIGN waves
     const uint32_t waves = (n_reads + 63) / 64 + MAX_STREAMS * WALK_PLAN_ALIGN;
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
-    hipLaunchKernelGGL((k_walk_spec<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, WALK8_STACK), stream, m, d_plans,
-                       WALK8_STACK, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+    hipLaunchKernelGGL((k_walk_spec<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, rows8), stream, m, d_plans,
+                       rows8, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, WALK16_STACK), stream, m, d_plans + 1,
-                       WALK16_STACK, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+    hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, rows16), stream, m, d_plans + 1,
+                       rows16, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     return hipGetLastError();
 }
 
