@@ -512,7 +512,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         const uint32_t je = (uint32_t)std::min<uint64_t>(WALK_JOB_EVENTS_MAX, std::max<uint64_t>(WALK_JOB_EVENTS, ev / WALK_TARGET_JOBS));
         mat->job_events[cc] = (je + 15u) & ~15u;       // (what the NEXT call's k_route cuts this class's walks into)
         // ... and the stack rows its walks get: what this call's reads asked for, two to spare
-        mat->walk_rows[cc] = std::min<uint32_t>(cc ? WALK16_ROWS : WALK8_ROWS, std::max<uint32_t>(4u, info[TI_WANT + cc] + 2u));
+        // (shrinking one row per call: a batch without deep reads between two with them does not send those to the sweeps)
+        mat->walk_rows[cc] = std::min<uint32_t>(cc ? WALK16_ROWS : WALK8_ROWS,
+                                                std::max<uint32_t>({4u, info[TI_WANT + cc] + 2u, mat->walk_rows[cc] ? mat->walk_rows[cc] - 1u : 0u}));
     }
 
     // ---- plan the launches ---------------------------------------------------------
@@ -574,7 +576,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             arena_off = info[TI_OFF + id];
             arena_maxk = std::max<uint32_t>(1, info[TI_MAXK + id]);
             arena_part = part_total;
-            part_total += (size_t)count * 12;
+            part_total += (size_t)count * 12 * ARENA_CHUNKS;
+            if ((uint64_t)count * ARENA_CHUNKS >= (1ull << 31)) return set_error(WEPP_ELIMIT, "too many window-crown sweeps in one call; split the batch");
             continue;
         }
         Plan& p = plans[np++];
@@ -806,11 +809,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 1] : stream;      // (the last of the sweeps' side streams)
         if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         int32_t* ps = (int32_t*)(part_base + arena_part);
-        uint32_t *pr = (uint32_t*)(ps + arena_n), *pc = pr + arena_n;
+        uint32_t *pr = (uint32_t*)(ps + (size_t)arena_n * ARENA_CHUNKS), *pc = pr + (size_t)arena_n * ARENA_CHUNKS;
         HIP_TRY(launch_sweep_arena(mat->dev, mat->dev.wc_streams, wsid, d_read_off, d_read_word, root_score, list + arena_off, arena_n, cap,
                                    sweep_lds_bytes(mat->dev.bm_words, cap, 0, false), ps, pr, pc, q));
-        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + arena_off, arena_n, 1, ps, pr, pc, d_best_bfs_j, d_score, d_num_best,
-                                d_flags, q));
+        HIP_TRY(launch_finalize(mat->dev, d_read_off, d_read_word, list + arena_off, arena_n, ARENA_CHUNKS, ps, pr, pc, d_best_bfs_j, d_score,
+                                d_num_best, d_flags, q));
         if (fork) {
             HIP_TRY(hipEventRecord(L.join_ev[OTHER_SIDE_STREAMS - 1], q));
             bool listed = false;

@@ -252,6 +252,7 @@ inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t ke
 constexpr uint32_t MAX_TILE_ENTRIES = 8192;
 constexpr uint32_t DENSE_MAX_POS = (1u << 19) - 1;
 constexpr uint32_t DENSE_MIN_READ_WORDS = 16; // tiles of reads this long keep the sorted position index
+constexpr uint32_t ARENA_CHUNKS = 16;      // waves (chunks of its window crown) per read of k_sweep_arena
 hipError_t launch_sweep_arena(const DevMAT& m, const DevStream* wc_streams, const uint32_t* wsid, const uint32_t* d_read_off,
                               const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list, uint32_t n_list,
                               uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,

@@ -271,7 +271,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             ev_out = events;
             nj_out = 0;
             // (what the host sizes the NEXT call's stacks from: the deepest stack asked for, granted or not)
-            atomicMax(&want_of[k <= WALK8_K ? 0 : 1], min(open_max, k <= WALK8_K ? WALK8_STACK : WALK16_STACK));
+            // (a read of the first class whose stack outgrows it walks in the second: that one hears of every read)
+            if (k <= WALK8_K && open_max <= WALK8_STACK) atomicMax(&want_of[0], open_max);
+            else atomicMax(&want_of[1], min(open_max, WALK16_STACK));
             // (stack8 <= WALK8_STACK, stack16 <= WALK16_STACK: the stack rows the walks' workgroups get; the few
             // reads that could hold more intervals open are left to the sweeps)
             if (events <= walk_max_events) {
@@ -1186,13 +1188,25 @@ __global__ __launch_bounds__(64) void k_sweep_arena(const DevStream* __restrict_
                                                     uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
                                                     const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
                                                     const int32_t* __restrict__ root_score, const uint32_t* __restrict__ list,
-                                                    int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
+                                                    uint32_t n_list, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
                                                     uint32_t* __restrict__ part_cnt) {
-    const uint32_t i = blockIdx.x;
+    // a wave per (read, chunk of its crown): ARENA_CHUNKS chunks cut at the crown's checkpoints, chunk-major like
+    // every sweep launch; a crown with fewer checkpoints leaves its last chunks empty (a partial that counts nothing)
+    const uint32_t i = blockIdx.x % n_list, chunk = blockIdx.x / n_list;
     const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsid[list[i]]);
     const DevStream st = wc_streams[sid];
-    sweep_tile<true, false>(st, 0u, 0u, bm_words, max_pos, ent_cap, 0u, read_off, read_word, root_score, list + i, 1u, 1u, 1u,
-                            st.NB, part_score + i, part_rank + i, part_cnt + i);
+    const uint32_t bpc = ((st.ncp + ARENA_CHUNKS - 1) / ARENA_CHUNKS) * st.cp_stride;
+    if (chunk * bpc >= st.NB) {
+        if (threadIdx.x == 0) {
+            const size_t o = (size_t)chunk * n_list + i;
+            part_score[o] = SCORE_INF_DEV;
+            part_rank[o] = 0xFFFFFFFFu;
+            part_cnt[o] = 0;
+        }
+        return;
+    }
+    sweep_tile<true, false>(st, blockIdx.x, 0u, bm_words, max_pos, ent_cap, 0u, read_off, read_word, root_score, list, n_list, 1u, n_list,
+                            bpc, part_score, part_rank, part_cnt);
 }
 
 // all the plain (short-read) plans of one placement call in ONE launch: the sweeps of the
@@ -2272,8 +2286,8 @@ hipError_t launch_sweep_arena(const DevMAT& m, const DevStream* wc_streams, cons
                               uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
                               hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sweep_arena, dim3(n_list), dim3(64), lds_bytes, stream, wc_streams, wsid, m.bm_words, m.max_pos, ent_cap,
-                       d_read_off, d_read_word, root_score, list, part_score, part_rank, part_cnt);
+    hipLaunchKernelGGL(k_sweep_arena, dim3(n_list * ARENA_CHUNKS), dim3(64), lds_bytes, stream, wc_streams, wsid, m.bm_words, m.max_pos, ent_cap,
+                       d_read_off, d_read_word, root_score, list, n_list, part_score, part_rank, part_cnt);
     return hipGetLastError();
 }
 
