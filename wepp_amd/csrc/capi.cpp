@@ -490,9 +490,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
     if (mat->use_walk) HIP_TRY(launch_plan_walks(tier_info, list, L.d_wplans, stream));
     HIP_TRY(hipEventRecord(L.fork_ev, stream));
+    // (the first class only: it holds nearly every short read; a second blind launch would be a grid of empty waves
+    // behind the first -- the second class is launched below with its own size, like the chunked ones)
     if (mat->use_walk)
-        HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, n_reads, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score, d_num_best,
-                                 d_flags, mat->d_work, wsid, stack8, stack16, stream));
+        HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, PLAN_WALK8, n_reads, 0, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
+                                 d_num_best, d_flags, mat->d_work, wsid, stack8, stream));
     // the counters come over a side stream (the caller's stream is busy with the walks), signalled by an event the
     // host polls (a blocking wait adds its wake-up, ~15 us per call); after ~0.1 s of polling -- a long queue in
     // front of this call -- wait blocking
@@ -699,11 +701,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
     // (the plain walks are on the caller's stream already; every other chain forks from the point before them)
-    const uint32_t n_chains = n_other + ((walkc[0].n || walkc[1].n) ? 1u : 0u) + (arena_n ? 1u : 0u);
+    const uint32_t n_chains = n_other + ((walkc[0].n || walkc[1].n) ? 1u : 0u) + (arena_n ? 1u : 0u) + (walk[1].n ? 1u : 0u);
     const bool fork = !unfused && (n_chains > 0 || n_plain > 0);
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
-    uint32_t joins[MAX_STREAMS], n_joins = 0;
+    uint32_t joins[2 * MAX_STREAMS], n_joins = 0;     // (a stream may be listed twice: waiting twice for its event is harmless)
     // side streams of the sweeps that are launched on their own (dense / window / out-of-LDS plans); the last
     // three belong to the walks
     constexpr uint32_t OTHER_SIDE_STREAMS = MAX_STREAMS - 3;
@@ -723,6 +725,18 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         sorted = true;
         return WEPP_OK;
     };
+    if (walk[1].n) {
+        // the second plain class (9 .. 16 entries), sized from the counters, beside the first
+        constexpr uint32_t W16 = OTHER_SIDE_STREAMS - 3;
+        hipStream_t q = fork ? L.side[W16] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
+        HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, PLAN_WALK16, n_reads, walk[1].p[walk[1].n - 1].wave_end, d_read_off, d_read_word, root_score,
+                                 d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work, wsid, stack16, q));
+        if (fork) {
+            HIP_TRY(hipEventRecord(L.join_ev[W16], q));
+            joins[n_joins++] = W16;
+        }
+    }
     if (walks) {
         hipStream_t q = stream;
         if (walkc[0].n || walkc[1].n) {

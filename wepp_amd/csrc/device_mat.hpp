@@ -157,10 +157,10 @@ struct WalkPlans {
 // the plain walks of a call, both classes, launched before the host has seen the routing counters: plans in device
 // memory (launch_plan_walks behind k_scatter), a grid that covers every read; they write the final per-read results
 hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, WalkPlans* d_plans, hipStream_t stream);
-hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t n_reads, const uint32_t* d_read_off,
-                            const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
-                            uint32_t rows8, uint32_t rows16, hipStream_t stream);
+hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t cls, uint32_t n_reads, uint32_t n_waves,
+                            const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j,
+                            int32_t* score, uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
+                            uint32_t rows, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,

@@ -2340,23 +2340,24 @@ hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, Wa
     return hipGetLastError();
 }
 
-// the plain walks of both classes for a call of n_reads reads, plans in device memory (d_plans[2], k_plan_walks)
-hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t n_reads, const uint32_t* d_read_off,
-                            const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
-                            uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
-                            uint32_t rows8, uint32_t rows16, hipStream_t stream) {
-    // rows8 / rows16: the stack rows of the two launches = the limits this call's k_route was given
-    rows8 = walk_stack_rows(rows8, WALK8_STACK);
-    rows16 = walk_stack_rows(rows16, WALK16_STACK);
-    // every read could be in either class, every plan is padded to WALK_PLAN_ALIGN waves
-    const uint32_t waves = (n_reads + 63) / 64 + MAX_STREAMS * WALK_PLAN_ALIGN;
+// The plain walks of one class, plans in device memory (d_plans[cls], k_plan_walks).  n_waves = 0: the grid covers every
+// read of the call (the launch that does not wait for the routing counters); else the class's own number of waves.
+hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t cls, uint32_t n_reads, uint32_t n_waves,
+                            const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j,
+                            int32_t* score, uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
+                            uint32_t rows, hipStream_t stream) {
+    // (every plan is padded to WALK_PLAN_ALIGN waves)
+    const uint32_t waves = n_waves ? n_waves : (n_reads + 63) / 64 + MAX_STREAMS * WALK_PLAN_ALIGN;
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
-    hipLaunchKernelGGL((k_walk_spec<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, rows8), stream, m, d_plans,
-                       rows8, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, rows16), stream, m, d_plans + 1,
-                       rows16, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+    if (cls == PLAN_WALK8) {
+        rows = walk_stack_rows(rows, WALK8_STACK);
+        hipLaunchKernelGGL((k_walk_spec<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, rows), stream, m, d_plans,
+                           rows, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+    } else {
+        rows = walk_stack_rows(rows, WALK16_STACK);
+        hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, rows), stream, m, d_plans + 1,
+                           rows, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+    }
     return hipGetLastError();
 }
 
