@@ -512,7 +512,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     for (uint32_t cc = 0; cc < 2; cc++) {
         const uint64_t ev = (uint64_t)info[TI_EVENTS + cc] << 6;
         const uint32_t je = (uint32_t)std::min<uint64_t>(WALK_JOB_EVENTS_MAX, std::max<uint64_t>(WALK_JOB_EVENTS, ev / WALK_TARGET_JOBS));
-        mat->job_events[cc] = (je + 15u) & ~15u;       // (what the NEXT call's k_route cuts this class's walks into)
+        mat->job_events[cc] = je <= WALK_JOB_EVENTS ? je : ((je + 15u) & ~15u);       // (what the NEXT call's k_route cuts this class's walks into)
         // ... and the stack rows its walks get: what this call's reads asked for, two to spare
         // (shrinking one row per call: a batch without deep reads between two with them does not send those to the sweeps)
         mat->walk_rows[cc] = std::min<uint32_t>(cc ? WALK16_ROWS : WALK8_ROWS,

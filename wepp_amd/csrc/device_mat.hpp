@@ -109,11 +109,13 @@ __host__ __device__ inline uint32_t plan_index(uint32_t id) { return id >= PLAN_
 // independent JOBS of about WALK_JOB_EVENTS events each -- node ranges cut at quantiles of its longest list;
 // a job finds the state of a sequential walk at its first node by binary searches in the read's lists and
 // the chains of enclosing entries (ix_up) -- whose (score, rank, count) partials k_finalize_jobs combines.
-constexpr uint32_t WALK_JOB_EVENTS = 32;
+constexpr uint32_t WALK_JOB_EVENTS = 8;
 // ... by default; a handle follows its traffic: the events per job of a chunked class in the NEXT call are the class's
-// events in this call over WALK_TARGET_JOBS, within [WALK_JOB_EVENTS, WALK_JOB_EVENTS_MAX] -- few long chains when a
-// class holds a few thousand reads (the default batch), long jobs, whose start state (a third of a short job's
-// cycles and bytes) is amortised, when it holds 10^8 events (N-rich batches).  Speed only: results never depend on it.
+// events in this call over WALK_TARGET_JOBS, within [WALK_JOB_EVENTS, WALK_JOB_EVENTS_MAX] -- MANY SHORT chains when a
+// class holds a few thousand reads (the default batch: 1 400 reads cut into jobs of 32 events made 66 waves of 32+
+// dependent iterations each, 171 us -- the longest kernel of a 0.3 ms step; jobs of 8 events: 4x the waves, a quarter
+// of the chain), long jobs, whose start state (a third of a short job's cycles and bytes) is amortised, when it holds
+// 10^8 events (tree-wide walks of N-rich batches).  Speed only: results never depend on it.
 constexpr uint32_t WALK_JOB_EVENTS_MAX = 256, WALK_TARGET_JOBS = 1u << 20;
 // most stack rows a walk workgroup gets (<= WALK8_STACK / WALK16_STACK, what the kernels take; WEPP_WALK_STACK8 /
 // WEPP_WALK_STACK16 lower them): a read that could hold more intervals open at once (sum of ix_nest over its
