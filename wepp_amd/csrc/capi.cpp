@@ -646,8 +646,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             carve();
             rc = route();
             if (rc != WEPP_OK) return rc;
-            // (the launch chains below fork from HERE now: their lists are the ones this second routing writes; the
-            // plain walks have run on the first one's -- grow() waited for them before it let the old buffer go)
+            // (the launch chains below fork from HERE now: their lists are the ones this second routing writes -- also
+            // the device-side plans of the second plain class, which is launched below: they must point into the new
+            // buffer; the first class has run on the first routing's lists -- grow() waited for it before it let the
+            // old buffer go)
+            if (mat->use_walk) HIP_TRY(launch_plan_walks(tier_info, list, L.d_wplans, stream));
             HIP_TRY(hipEventRecord(L.fork_ev, stream));
         }
     }
