@@ -765,8 +765,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             // general path below takes two chains of six.  The classes' lists follow one another in `list` (their
             // plan ids are consecutive), jobs are numbered across both.
             const uint32_t R3all = walkc_reads[0] + walkc_reads[1];
-            static const int small_mode = getenv("WEPP_SMALL_CHAIN") ? atoi(getenv("WEPP_SMALL_CHAIN")) : 2;    // (A/B aid: 0 off, 1 one stream, 2 the walks side by side)
-            const bool small_chain = small_mode && R3all <= JOBS_SMALL_MAX && (!walkc[0].n || !walkc[1].n || walkc_off[1] == walkc_off[0] + walkc_reads[0]);
+            const bool small_chain = R3all <= JOBS_SMALL_MAX && (!walkc[0].n || !walkc[1].n || walkc_off[1] == walkc_off[0] + walkc_reads[0]);
             if (small_chain) {
                 if (fork) {
                     q = L.side[MAX_STREAMS - 2];
@@ -785,13 +784,6 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 const uint32_t* list_all = list + (walkc[0].n ? walkc_off[0] : walkc_off[1]);
                 bytes += (uint64_t)R3all * (12 + 8 + 12 + 16) + (uint64_t)J * 12;
                 HIP_TRY(launch_job_offsets_small(list_all, R3all, job_n, joff, q));
-                // (the second class's walk beside the first's, on the neighbouring side stream, when both exist)
-                const bool two = fork && small_mode == 2 && walkc[0].n && walkc[1].n;
-                hipStream_t q2 = two ? L.side[MAX_STREAMS - 3] : q;
-                if (two) {
-                    HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 3], q));          // (borrowed: the offsets are there)
-                    HIP_TRY(hipStreamWaitEvent(q2, L.join_ev[MAX_STREAMS - 3], 0));
-                }
                 for (uint32_t cc = 0; cc < 2; cc++) {
                     if (!walkc[cc].n) continue;
                     const uint32_t first = cc && walkc[0].n ? walkc_reads[0] : 0u;      // the class's slice of the chain's list
@@ -799,11 +791,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                     jb.n_list = walkc_reads[cc];
                     jb.job_off = joff + first;
                     HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, info[TI_OPEN + 2 + cc], jb, d_read_off, d_read_word, root_score,
-                                             mat->d_work, wsid, cc ? q2 : q));
-                }
-                if (two) {
-                    HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 3], q2));
-                    HIP_TRY(hipStreamWaitEvent(q, L.join_ev[MAX_STREAMS - 3], 0));
+                                             mat->d_work, wsid, q));
                 }
                 jb.n_list = R3all;
                 jb.job_off = joff;
