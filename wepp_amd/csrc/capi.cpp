@@ -760,48 +760,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 if (e2 != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc walk workspace: ") + hipGetErrorString(e2));
                 L.ws2_bytes = need + need / 4;
             }
-            // A SMALL chain (a few thousand reads in both classes together -- every batch since the window crowns): one
-            // launch for all job offsets, the two walks, one combination -- 4 launches on one side stream where the
-            // general path below takes two chains of six.  The classes' lists follow one another in `list` (their
-            // plan ids are consecutive), jobs are numbered across both.
-            const uint32_t R3all = walkc_reads[0] + walkc_reads[1];
-            const bool small_chain = R3all <= JOBS_SMALL_MAX && (!walkc[0].n || !walkc[1].n || walkc_off[1] == walkc_off[0] + walkc_reads[0]);
-            if (small_chain) {
-                if (fork) {
-                    q = L.side[MAX_STREAMS - 2];
-                    HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
-                }
-                const uint32_t J = (uint32_t)(n_jobs[0] + n_jobs[1]);
-                const size_t b_cnt = pad((size_t)R3all * 4), b_job = pad((size_t)J * 4);
-                if (b_cnt + 3 * b_job > L.ws2_bytes) return set_error(WEPP_EDEVICE, "walk workspace too small");      // (sized above, generously)
-                char* w2 = (char*)L.ws2;
-                uint32_t* joff = (uint32_t*)w2; w2 += b_cnt;
-                WalkJobs jb{};
-                jb.job_n = job_n;
-                jb.part_score = (int32_t*)w2; w2 += b_job;
-                jb.part_rank = (uint32_t*)w2; w2 += b_job;
-                jb.part_cnt = (uint32_t*)w2;
-                const uint32_t* list_all = list + (walkc[0].n ? walkc_off[0] : walkc_off[1]);
-                bytes += (uint64_t)R3all * (12 + 8 + 12 + 16) + (uint64_t)J * 12;
-                HIP_TRY(launch_job_offsets_small(list_all, R3all, job_n, joff, q));
-                for (uint32_t cc = 0; cc < 2; cc++) {
-                    if (!walkc[cc].n) continue;
-                    const uint32_t first = cc && walkc[0].n ? walkc_reads[0] : 0u;      // the class's slice of the chain's list
-                    for (uint32_t k = 0; k < walkc[cc].n; k++) walkc[cc].p[k].job0 += cc ? (uint32_t)n_jobs[0] : 0u;
-                    jb.n_list = walkc_reads[cc];
-                    jb.job_off = joff + first;
-                    HIP_TRY(launch_walk_jobs(mat->dev, walkc[cc], PLAN_WALKC8 + cc, info[TI_OPEN + 2 + cc], jb, d_read_off, d_read_word, root_score,
-                                             mat->d_work, wsid, q));
-                }
-                jb.n_list = R3all;
-                jb.job_off = joff;
-                HIP_TRY(launch_finalize_jobs(mat->dev, list_all, R3all, jb, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags, q));
-                if (fork) {
-                    HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 2], q));
-                    joins[n_joins++] = MAX_STREAMS - 2;
-                }
-            }
-            for (uint32_t cc = 0; cc < 2 && !small_chain; cc++) {
+            for (uint32_t cc = 0; cc < 2; cc++) {
                 if (!walkc[cc].n) continue;
                 // each class on a side stream of its own: a chain of short, latency-bound launches
                 if (fork) {

@@ -165,9 +165,6 @@ hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t 
                             uint32_t rows, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
-// a chain of at most JOBS_SMALL_MAX reads (both chunked classes together): gather + scan in ONE single-workgroup launch
-constexpr uint32_t JOBS_SMALL_MAX = 16384;
-hipError_t launch_job_offsets_small(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* job_off, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,
                             const uint32_t* d_read_word, const int32_t* root_score, unsigned long long* work_counter,
                             const uint32_t* wsid, hipStream_t stream);

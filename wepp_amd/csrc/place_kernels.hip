@@ -1875,35 +1875,6 @@ __global__ void k_plan_walks(const uint32_t* __restrict__ tier_info, const uint3
     wp.n = n;
 }
 
-// The job offsets of a SMALL chunked chain in one launch: counts gathered in list order and scanned by one workgroup
-// (n <= JOBS_SMALL_MAX reads: 1024 threads x 16).  Replaces k_gather_jobs + rocPRIM's three launches, for both chunked
-// classes at once -- the default batch's 1 400 such reads paid two chains of six short launches for them.
-__global__ __launch_bounds__(1024) void k_job_offsets_small(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ job_n,
-                                                            uint32_t* __restrict__ job_off) {
-    __shared__ uint32_t wsum[16];
-    constexpr uint32_t PER = JOBS_SMALL_MAX / 1024;
-    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) {
-        const uint32_t i = t * PER + j;
-        v[j] = i < n ? job_n[list[i]] : 0u;
-        sum += v[j];
-    }
-    const uint32_t incl = wave_scan_add_u32(sum);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t k = 0; k < wv; k++) before += wsum[k];
-    uint32_t run = before + incl - sum;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) {
-        const uint32_t i = t * PER + j;
-        if (i < n) job_off[i] = run;
-        run += v[j];
-    }
-}
-
 // job counts in list order (the input of the scan)
 __global__ void k_gather_jobs(const uint32_t* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ job_n,
                               uint32_t* __restrict__ out) {
@@ -2387,13 +2358,6 @@ hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t 
         hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, rows), stream, m, d_plans + 1,
                            rows, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_job_offsets_small(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* job_off, hipStream_t stream) {
-    if (n_list == 0) return hipSuccess;
-    if (n_list > JOBS_SMALL_MAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_job_offsets_small, dim3(1), dim3(1024), 0, stream, list, n_list, job_n, job_off);
     return hipGetLastError();
 }
 
