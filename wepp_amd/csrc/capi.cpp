@@ -36,8 +36,6 @@ void release(wepp_mat* h) {
             if (L.join_ev[i]) (void)hipEventDestroy(L.join_ev[i]);
         }
         if (L.fork_ev) (void)hipEventDestroy(L.fork_ev);
-        if (L.info_ev) (void)hipEventDestroy(L.info_ev);
-        if (L.d_wplans) (void)hipFree(L.d_wplans);
     }
     if (h->io_in) (void)hipFree(h->io_in);
     if (h->io_out) (void)hipFree(h->io_out);
@@ -294,9 +292,6 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&L.join_ev[i], hipEventDisableTiming);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&L.info_ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc((void**)&L.d_wplans, 2 * sizeof(WalkPlans));
-        if (e == hipSuccess) e = hipMemset(L.d_wplans, 0, 2 * sizeof(WalkPlans));
     }
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
         e = hipEventCreate(&h->ev0[i]);
@@ -456,15 +451,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     static const uint32_t job_events_env = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::min(0xFFFF, std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS")))) : 0u;
     const uint32_t job_events = job_events_env ? (job_events_env | (job_events_env << 16)) : (mat->job_events[0] | (mat->job_events[1] << 16));
     static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
-    // Stack rows of the walks = the LDS of their workgroups = how many waves a CU holds (the walks wait on memory).  The
-    // plain walks are launched before the host knows what this call's reads need, so the rows are what the handle's
-    // LAST call asked for (TI_WANT: the deepest stack of any read short enough to walk; the class's full depth on the
-    // first call) and k_route is given the same numbers as limits: a read that needs more sweeps its window crown
-    // instead, and raises the rows of the next call.  WEPP_WALK_STACK8 / 16 fix them.
-    static const uint32_t stack8_env = getenv("WEPP_WALK_STACK8") ? (uint32_t)std::max(0, atoi(getenv("WEPP_WALK_STACK8"))) : 0u;
-    static const uint32_t stack16_env = getenv("WEPP_WALK_STACK16") ? (uint32_t)std::max(0, atoi(getenv("WEPP_WALK_STACK16"))) : 0u;
-    const uint32_t stack8 = std::min<uint32_t>(WALK8_ROWS, stack8_env ? stack8_env : mat->walk_rows[0]);
-    const uint32_t stack16 = std::min<uint32_t>(WALK16_ROWS, stack16_env ? stack16_env : mat->walk_rows[1]);
+    static const uint32_t stack8 = getenv("WEPP_WALK_STACK8") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK8")) : WALK8_ROWS;
+    static const uint32_t stack16 = getenv("WEPP_WALK_STACK16") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK16")) : WALK16_ROWS;
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
@@ -481,42 +469,21 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         int rc = route();
         if (rc != WEPP_OK) return rc;
     }
-    // ---- the plain walks start at once; the host's round trip for the counters overlaps them ----------------
-    // Nearly every short read is placed by a plain walk (4.2 / 4.2c).  Their plans are made on the device
-    // (k_plan_walks, behind k_scatter) and both classes are launched NOW, with grids that cover every read: the GPU
-    // does not idle while the counters travel to the host, are polled for and the rarer launch chains (chunked
-    // walks, sweeps) are sized from them -- those fork from the point before the walks and run beside them.
-    const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
-    HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
-    if (mat->use_walk) HIP_TRY(launch_plan_walks(tier_info, list, L.d_wplans, stream));
-    HIP_TRY(hipEventRecord(L.fork_ev, stream));
-    // (the first class only: it holds nearly every short read; a second blind launch would be a grid of empty waves
-    // behind the first -- the second class is launched below with its own size, like the chunked ones)
-    if (mat->use_walk)
-        HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, PLAN_WALK8, n_reads, 0, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
-                                 d_num_best, d_flags, mat->d_work, wsid, stack8, stream));
-    // the counters come over a side stream (the caller's stream is busy with the walks), signalled by an event the
-    // host polls (a blocking wait adds its wake-up, ~15 us per call); after ~0.1 s of polling -- a long queue in
-    // front of this call -- wait blocking
+    HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    // the host sizes the launches from the counters, and the GPU idles until it has: poll for them (a
+    // blocking wait adds its wake-up, ~15 us per call, to that idle time); after ~0.1 s of polling -- a long
+    // queue in front of this call -- wait blocking
     {
-        hipStream_t qi = L.side[MAX_STREAMS - 1];
-        HIP_TRY(hipStreamWaitEvent(qi, L.fork_ev, 0));
-        HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, qi));
-        HIP_TRY(hipEventRecord(L.info_ev, qi));
         hipError_t q = hipErrorNotReady;
-        for (int spin = 0; spin < 200000 && (q = hipEventQuery(L.info_ev)) == hipErrorNotReady; spin++) {}
+        for (int spin = 0; spin < 200000 && (q = hipStreamQuery(stream)) == hipErrorNotReady; spin++) {}
         (void)hipGetLastError();   // "not ready" is not an error: keep it out of the launchers' hipGetLastError()
-        if (q != hipSuccess) HIP_TRY(hipEventSynchronize(L.info_ev));
+        if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
     }
     const uint32_t* info = L.h_info;
     for (uint32_t cc = 0; cc < 2; cc++) {
         const uint64_t ev = (uint64_t)info[TI_EVENTS + cc] << 6;
         const uint32_t je = (uint32_t)std::min<uint64_t>(WALK_JOB_EVENTS_MAX, std::max<uint64_t>(WALK_JOB_EVENTS, ev / WALK_TARGET_JOBS));
         mat->job_events[cc] = je <= WALK_JOB_EVENTS ? je : ((je + 15u) & ~15u);       // (what the NEXT call's k_route cuts this class's walks into)
-        // ... and the stack rows its walks get: what this call's reads asked for, two to spare
-        // (shrinking one row per call: a batch without deep reads between two with them does not send those to the sweeps)
-        mat->walk_rows[cc] = std::min<uint32_t>(cc ? WALK16_ROWS : WALK8_ROWS,
-                                                std::max<uint32_t>({4u, info[TI_WANT + cc] + 2u, mat->walk_rows[cc] ? mat->walk_rows[cc] - 1u : 0u}));
     }
 
     // ---- plan the launches ---------------------------------------------------------
@@ -646,12 +613,6 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             carve();
             rc = route();
             if (rc != WEPP_OK) return rc;
-            // (the launch chains below fork from HERE now: their lists are the ones this second routing writes -- also
-            // the device-side plans of the second plain class, which is launched below: they must point into the new
-            // buffer; the first class has run on the first routing's lists -- grow() waited for it before it let the
-            // old buffer go)
-            if (mat->use_walk) HIP_TRY(launch_plan_walks(tier_info, list, L.d_wplans, stream));
-            HIP_TRY(hipEventRecord(L.fork_ev, stream));
         }
     }
     char* part_base = (char*)L.ws + fixed_bytes;
@@ -680,6 +641,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // The plain (short-read) plans are fused into ONE launch, longest chunks first; dense
     // and out-of-LDS plans get their own launch on a side stream forked from / joined into
     // `stream`.  Every plan's finalize follows its sweep.
+    const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
+    HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
     uint64_t passes = 0, bytes = 0;
     auto parts = [&](const Plan& p, int32_t*& ps, uint32_t*& pr, uint32_t*& pc) {
         ps = (int32_t*)(part_base + p.part_off);
@@ -703,9 +666,10 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         if (walk[cls].n) passes += walk[cls].p[walk[cls].n - 1].wave_end;   // a walk "pass" = one wave of 64 reads
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
-    // (the plain walks are on the caller's stream already; every other chain forks from the point before them)
-    const uint32_t n_chains = n_other + ((walkc[0].n || walkc[1].n) ? 1u : 0u) + (arena_n ? 1u : 0u) + (walk[1].n ? 1u : 0u);
-    const bool fork = !unfused && (n_chains > 0 || n_plain > 0);
+    const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
+    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
+    const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
+    if (fork) HIP_TRY(hipEventRecord(L.fork_ev, stream));
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
     uint32_t joins[2 * MAX_STREAMS], n_joins = 0;     // (a stream may be listed twice: waiting twice for its event is harmless)
@@ -728,20 +692,30 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         sorted = true;
         return WEPP_OK;
     };
-    if (walk[1].n) {
-        // the second plain class (9 .. 16 entries), sized from the counters, beside the first
-        constexpr uint32_t W16 = OTHER_SIDE_STREAMS - 3;
-        hipStream_t q = fork ? L.side[W16] : stream;
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
-        HIP_TRY(launch_walk_spec(mat->dev, L.d_wplans, PLAN_WALK16, n_reads, walk[1].p[walk[1].n - 1].wave_end, d_read_off, d_read_word, root_score,
-                                 d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work, wsid, stack16, q));
-        if (fork) {
-            HIP_TRY(hipEventRecord(L.join_ev[W16], q));
-            joins[n_joins++] = W16;
-        }
-    }
     if (walks) {
-        hipStream_t q = stream;
+        // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
+        // sweeps run side by side (the walks wait on memory most of the time)
+        hipStream_t q = fork ? L.side[MAX_STREAMS - 1] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
+        for (uint32_t cls = 0; cls < 2; cls++) {
+            if (!walk[cls].n) continue;
+            // (the plain classes keep the caller's order unless WEPP_WALK_SORT_PLAIN=1: their reads have at most 16
+            // events each, mostly on streams the L2s hold anyway, and a sort of 1 M reads costs 0.15 ms of a 0.3 ms step)
+            static const bool sort_plain = getenv("WEPP_WALK_SORT_PLAIN") && getenv("WEPP_WALK_SORT_PLAIN")[0] == '1';
+            bool sorted = false;
+            if (sort_plain) {
+                int rc = sort_class(cls, 1 + cls, q, sorted);
+                if (rc != WEPP_OK) return rc;
+            }
+            if (sorted)
+                for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = val_in + walk_off[cls][k];
+            HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
+                                d_num_best, d_flags, mat->d_work, wsid, q));
+        }
+        if (fork) {
+            HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
+            joins[n_joins++] = MAX_STREAMS - 1;
+        }
         if (walkc[0].n || walkc[1].n) {
             // chunked walks, per class: jobs per read in list order -> exclusive scan -> the walk (a partial per
             // job; a job finds its read by bisection in the scanned offsets) -> one combination per read.
@@ -861,18 +835,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             lds_max = std::max(lds_max, p.lds_bytes);
         }
         pl.n = n_plain;
-        // (beside the plain walks, which hold the caller's stream)
-        constexpr uint32_t SW = OTHER_SIDE_STREAMS - 2;
-        hipStream_t q = fork ? L.side[SW] : stream;
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
-        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, q));
-        HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags, q));
-        if (fork) {
-            HIP_TRY(hipEventRecord(L.join_ev[SW], q));
-            bool listed = false;
-            for (uint32_t i = 0; i < n_joins; i++) listed = listed || joins[i] == SW;
-            if (!listed) joins[n_joins++] = SW;
-        }
+        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, stream));
+        HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
+                                      stream));
     }
     for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[joins[i]], 0));
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));

@@ -113,9 +113,9 @@ constexpr uint32_t WALK_JOB_EVENTS = 8;
 // ... by default; a handle follows its traffic: the events per job of a chunked class in the NEXT call are the class's
 // events in this call over WALK_TARGET_JOBS, within [WALK_JOB_EVENTS, WALK_JOB_EVENTS_MAX] -- MANY SHORT chains when a
 // class holds a few thousand reads (the default batch: 1 400 reads cut into jobs of 32 events made 66 waves of 32+
-// dependent iterations each, 171 us -- the longest kernel of a 0.3 ms step; jobs of 8 events: 4x the waves, a quarter
-// of the chain), long jobs, whose start state (a third of a short job's cycles and bytes) is amortised, when it holds
-// 10^8 events (tree-wide walks of N-rich batches).  Speed only: results never depend on it.
+// dependent iterations each, 171 us -- the longest kernel of a 0.3 ms step; jobs of 8 events: 78 us), long jobs,
+// whose start state (a third of a short job's cycles and bytes) is amortised, when it holds 10^8 events (tree-wide
+// walks of N-rich batches).  Speed only: results never depend on it.
 constexpr uint32_t WALK_JOB_EVENTS_MAX = 256, WALK_TARGET_JOBS = 1u << 20;
 // most stack rows a walk workgroup gets (<= WALK8_STACK / WALK16_STACK, what the kernels take; WEPP_WALK_STACK8 /
 // WEPP_WALK_STACK16 lower them): a read that could hold more intervals open at once (sum of ix_nest over its
@@ -128,7 +128,7 @@ constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of 
 // waves of a walk plan are padded to a multiple of this, so that every plan starts at a workgroup index that is a
 // multiple of the XCD count and its waves can be dealt to the XCDs in contiguous runs (k_walk)
 constexpr uint32_t WALK_PLAN_ALIGN = WALK_XCDS * WALK_WAVES;
-__host__ __device__ inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
+inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
@@ -156,13 +156,10 @@ struct WalkPlans {
     uint32_t n;
     WalkPlanDev p[MAX_STREAMS];
 };
-// the plain walks of a call, both classes, launched before the host has seen the routing counters: plans in device
-// memory (launch_plan_walks behind k_scatter), a grid that covers every read; they write the final per-read results
-hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, WalkPlans* d_plans, hipStream_t stream);
-hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t cls, uint32_t n_reads, uint32_t n_waves,
-                            const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j,
-                            int32_t* score, uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
-                            uint32_t rows, hipStream_t stream);
+// cls = 0 / 1: the plans of one class in ONE launch, a wave = 64 reads; writes the final per-read results
+hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
+                       const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
+                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,
@@ -300,7 +297,6 @@ hipError_t sweep_set_max_lds(uint32_t bytes);
 constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
                    TI_OPEN = TI_JOBS + 2 * MAX_STREAMS,      // [4] deepest stack of the walk classes (WALK8, WALK16, WALKC8, WALKC16)
                    TI_EVENTS = TI_OPEN + 4,                  // [2] events (in units of 64) of the reads of the two chunked classes
-                   TI_WANT = TI_EVENTS + 2,                  // [2] deepest stack any read of up to WALK8_K / WALK16_K entries asked for, walked or not
-                   TI_WORDS = TI_WANT + 2;
+                   TI_WORDS = TI_EVENTS + 2;
 
 }  // namespace wepp

@@ -33,8 +33,6 @@ struct PlaceLane {
     // the launch chains of a call are independent: they run concurrently on side streams
     hipStream_t side[MAX_STREAMS] = {};
     hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
-    hipEvent_t info_ev = nullptr;     // the routing counters have reached h_info (polled by the host)
-    WalkPlans* d_wplans = nullptr;    // [2] the plain walk plans of the call, written on the device (k_plan_walks)
 };
 
 struct wepp_mat {
@@ -46,7 +44,6 @@ struct wepp_mat {
     uint64_t wc_nodes = 0;            // nodes of all window crowns (the arena of slot WC_SLOT)
     uint32_t wc_count = 0;            // window crowns built
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
-    uint32_t walk_rows[2] = {WALK8_ROWS, WALK16_ROWS};             // stack rows of the walks (and k_route's limits) in the next call
     uint32_t job_events[2] = {WALK_JOB_EVENTS, WALK_JOB_EVENTS};   // events per job of the chunked classes in the next call
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
     unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset

@@ -203,13 +203,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next,
                                                           uint32_t* __restrict__ wsid) {
-    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2], want_of[2];
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2];
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
     if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
     if (threadIdx.x < 4) open_of[threadIdx.x] = 0;
-    if (threadIdx.x < 2) { events_of[threadIdx.x] = 0; want_of[threadIdx.x] = 0; }
+    if (threadIdx.x < 2) events_of[threadIdx.x] = 0;
     if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
@@ -270,10 +270,6 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             open_out = open_max;
             ev_out = events;
             nj_out = 0;
-            // (what the host sizes the NEXT call's stacks from: the deepest stack asked for, granted or not)
-            // (a read of the first class whose stack outgrows it walks in the second: that one hears of every read)
-            if (k <= WALK8_K && open_max <= WALK8_STACK) atomicMax(&want_of[0], open_max);
-            else atomicMax(&want_of[1], min(open_max, WALK16_STACK));
             // (stack8 <= WALK8_STACK, stack16 <= WALK16_STACK: the stack rows the walks' workgroups get; the few
             // reads that could hold more intervals open are left to the sweeps)
             if (events <= walk_max_events) {
@@ -352,7 +348,6 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
     if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
     if (threadIdx.x < 2 && events_of[threadIdx.x]) atomicAdd(&tier_info[TI_EVENTS + threadIdx.x], (events_of[threadIdx.x] + 63) >> 6);
-    if (threadIdx.x < 2 && want_of[threadIdx.x]) atomicMax(&tier_info[TI_WANT + threadIdx.x], want_of[threadIdx.x]);
 }
 
 // -----------------------------------------------------------------------------
@@ -1191,7 +1186,8 @@ __global__ __launch_bounds__(64) void k_sweep_arena(const DevStream* __restrict_
                                                     uint32_t n_list, int32_t* __restrict__ part_score, uint32_t* __restrict__ part_rank,
                                                     uint32_t* __restrict__ part_cnt) {
     // a wave per (read, chunk of its crown): ARENA_CHUNKS chunks cut at the crown's checkpoints, chunk-major like
-    // every sweep launch; a crown with fewer checkpoints leaves its last chunks empty (a partial that counts nothing)
+    // every sweep launch; a crown with fewer checkpoints leaves its last chunks empty (a partial that counts nothing).
+    // (One wave per read took 0.7 ms for a read on a 100 K-node crown: the tail of a 0.3 ms step.)
     const uint32_t i = blockIdx.x % n_list, chunk = blockIdx.x / n_list;
     const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)wsid[list[i]]);
     const DevStream st = wc_streams[sid];
@@ -1369,7 +1365,7 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
 // whole tree for a read with three entries.  Same results (tests/walk_model.py is the CPU model).
 // -----------------------------------------------------------------------------
 template <int KW, int SD, bool CHUNKED>
-__device__ __forceinline__ void walk_body(const DevMAT& m, const WalkPlans& pl, const WalkJobs& jb, uint32_t sd_rows,
+__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, uint32_t sd_rows,
                                               const uint32_t* __restrict__ read_off,
                                               const uint32_t* __restrict__ read_word,
                                               const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
@@ -1389,7 +1385,7 @@ __device__ __forceinline__ void walk_body(const DevMAT& m, const WalkPlans& pl, 
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
     auto sword = [&](int j) -> uint32_t { return ((S16[(j >> 1) * 64 + lane] >> ((j & 1) * 16)) & 0x1FFu) << 20; };
     const uint32_t unit = blockIdx.x * WALK_WAVES + wv;
-    if (pl.n == 0 || unit >= pl.p[pl.n - 1].wave_end) return;
+    if (unit >= pl.p[pl.n - 1].wave_end) return;
 #ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
     unsigned long long ts_[6];
     ts_[0] = __builtin_amdgcn_s_memtime();
@@ -1832,47 +1828,6 @@ __device__ __forceinline__ void walk_body(const DevMAT& m, const WalkPlans& pl, 
         }
     }
 #endif
-}
-
-// the chunked walks: plans and job tables from the host (kernel arguments), launched once the routing counters are known
-template <int KW, int SD>
-__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl, WalkJobs jb, uint32_t sd_rows,
-                                              const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
-                                              const int32_t* __restrict__ root_score, unsigned long long* __restrict__ work_counter,
-                                              const uint32_t* __restrict__ wsid) {
-    walk_body<KW, SD, true>(m, pl, jb, sd_rows, read_off, read_word, root_score, nullptr, nullptr, nullptr, nullptr, work_counter, wsid);
-}
-// the plain walks: launched BEFORE the host has seen the routing counters, with a grid that covers every read -- the
-// plans come from device memory (k_plan_walks wrote them behind k_scatter), the waves beyond the class's reads leave at
-// once.  The host's round trip for the counters (which sizes the rarer launch chains) overlaps these walks.
-template <int KW, int SD>
-__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_spec(DevMAT m, const WalkPlans* __restrict__ pl, uint32_t sd_rows,
-                                              const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
-                                              const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
-                                              int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best,
-                                              uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter,
-                                              const uint32_t* __restrict__ wsid) {
-    const WalkJobs none{};
-    walk_body<KW, SD, false>(m, *pl, none, sd_rows, read_off, read_word, root_score, best_bfs_j, score_out, num_best, flags, work_counter, wsid);
-}
-// the plain walk plans of a call, on the device: out[cls] = the (class, stream) plans with reads, their lists and waves
-__global__ void k_plan_walks(const uint32_t* __restrict__ tier_info, const uint32_t* __restrict__ list, WalkPlans* __restrict__ out) {
-    const uint32_t cls = threadIdx.x;
-    if (cls >= 2) return;
-    WalkPlans& wp = out[cls];
-    uint32_t n = 0, wave_end = 0;
-    for (uint32_t t = 0; t < MAX_STREAMS; t++) {
-        const uint32_t id = plan_id(cls, t), count = tier_info[TI_COUNT + id];
-        if (!count) continue;
-        wave_end += walk_plan_waves(count);
-        wp.p[n].tier = t;
-        wp.p[n].n_list = count;
-        wp.p[n].wave_end = wave_end;
-        wp.p[n].job0 = 0;
-        wp.p[n].list = list + tier_info[TI_OFF + id];
-        n++;
-    }
-    wp.n = n;
 }
 
 // job counts in list order (the input of the scan)
@@ -2335,28 +2290,21 @@ static uint32_t walk_lds_bytes(uint32_t kw, uint32_t sd_rows) { return WALK_WAVE
 // scratch, never more than the class admits
 static uint32_t walk_stack_rows(uint32_t open_max, uint32_t sd) { return std::min(sd, std::max(open_max, 2u)); }
 
-hipError_t launch_plan_walks(const uint32_t* tier_info, const uint32_t* list, WalkPlans* d_plans, hipStream_t stream) {
-    hipLaunchKernelGGL(k_plan_walks, dim3(1), dim3(64), 0, stream, tier_info, list, d_plans);
-    return hipGetLastError();
-}
-
-// The plain walks of one class, plans in device memory (d_plans[cls], k_plan_walks).  n_waves = 0: the grid covers every
-// read of the call (the launch that does not wait for the routing counters); else the class's own number of waves.
-hipError_t launch_walk_spec(const DevMAT& m, const WalkPlans* d_plans, uint32_t cls, uint32_t n_reads, uint32_t n_waves,
-                            const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j,
-                            int32_t* score, uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
-                            uint32_t rows, hipStream_t stream) {
-    // (every plan is padded to WALK_PLAN_ALIGN waves)
-    const uint32_t waves = n_waves ? n_waves : (n_reads + 63) / 64 + MAX_STREAMS * WALK_PLAN_ALIGN;
+hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
+                       const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
+                       uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    const uint32_t waves = pl.p[pl.n - 1].wave_end;
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
+    const WalkJobs none{};
     if (cls == PLAN_WALK8) {
-        rows = walk_stack_rows(rows, WALK8_STACK);
-        hipLaunchKernelGGL((k_walk_spec<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, rows), stream, m, d_plans,
-                           rows, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+        const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl,
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     } else {
-        rows = walk_stack_rows(rows, WALK16_STACK);
-        hipLaunchKernelGGL((k_walk_spec<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, rows), stream, m, d_plans + 1,
-                           rows, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+        const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl,
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
     }
     return hipGetLastError();
 }
@@ -2375,12 +2323,14 @@ hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, 
     const dim3 grid((waves + WALK_WAVES - 1) / WALK_WAVES), block(64 * WALK_WAVES);
     if (cls == PLAN_WALKC8) {
         const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
-        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
-                           sd, d_read_off, d_read_word, root_score, work_counter, wsid);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, work_counter, wsid);
     } else {
         const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
-        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
-                           sd, d_read_off, d_read_word, root_score, work_counter, wsid);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, work_counter, wsid);
     }
     return hipGetLastError();
 }
