@@ -114,3 +114,43 @@ def test_two_rank_epp_allreduce_equals_unsharded_oracle(tmp_path, oracle):
     assert np.allclose(got["score"], want["score"], rtol=1e-12, atol=1e-15)
     assert (got["counts"] == want["counts"]).all()
     assert np.array_equal(got["divergence"], want["divergence"], equal_nan=True)
+
+
+def _gpu_worker(rank, world, port, out_path):
+    """Like _worker, with the HIP library placing the shard: each rank is its own process with its own handle on the
+    box's GPU (what `bench.py --gpus N` and the driver's scaling runs do on N GPUs)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from wepp_amd.sharding import gather_results, shard_reads
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = w.generate_tree(33, 60_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
+    reads = g.reads(34, 70_001, p_substitution=0.004, p_n=0.03, p_iupac=0.1)
+    mat = w.Mat(g.tree, device=0)
+    res = mat.place_batch(shard_reads(reads, rank, world))
+    full = gather_results(res, dist)
+    mat.close()
+    if rank == 0:
+        np.savez(out_path, **full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_on_the_gpu_equal_the_unsharded_oracle(tmp_path, oracle):
+    """The N>1 path with the HIP library in BOTH processes (the CPU tests above put a Python model in its place): two
+    ranks, each flattening the tree, holding its own handle on device 0 and placing its contiguous half of 70 001
+    reads; rank 0 concatenates -- equal to the oracle's unsharded run."""
+    out = str(tmp_path / "gathered_gpu.npz")
+    port = 29500 + (os.getpid() % 2000) + 2
+    mp.spawn(_gpu_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    g = w.generate_tree(33, 60_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
+    reads = g.reads(34, 70_001, p_substitution=0.004, p_n=0.03, p_iupac=0.1)
+    want = oracle.OracleTree(g.tree).incremental().place_batch(reads, nthreads=os.cpu_count() or 1)
+    assert (got["score"] == want["score"]).all()
+    assert (got["best_bfs_j"] == want["best_j"]).all()
+    assert (got["num_best"] == want["num_best"]).all()
+    assert ((got["flags"] & 1) == want["has_unique"]).all()
