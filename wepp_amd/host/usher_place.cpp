@@ -1,7 +1,10 @@
 // usher_place.cpp -- see usher_place.hpp (citations: /root/reference/src/usher_common.cpp).
 #include "usher_place.hpp"
 
+#include <sys/stat.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -279,6 +282,12 @@ int usher_place_samples(std::string outdir, uint32_t max_uncertainty, uint32_t m
 
     FileCloser stats, scores;
     if (!outdir.empty()) {
+        // (usher creates a missing output directory, usher_common.cpp:78-83)
+        if (mkdir(outdir.c_str(), 0755) != 0 && errno != EEXIST) {
+            fprintf(stderr, "ERROR: cannot create %s\n", outdir.c_str());
+            destroy_all();
+            return 1;
+        }
         stats.f = fopen((outdir + "/placement_stats.tsv").c_str(), "w");                      // :303-304
         if (!stats.f) {
             fprintf(stderr, "ERROR: cannot write to %s\n", outdir.c_str());
