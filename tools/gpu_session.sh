@@ -19,7 +19,6 @@ for step in "$@"; do
     alltests) timeout -k 10 1700 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; rc=$?; tail -4 "$OUT/pytest_gpu.log";;
     bench)    timeout -k 10 600 python bench.py ${BENCH_ARGS:-} > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; rc=$?; cut -c1-600 "$OUT/bench_default.json"; tail -3 "$OUT/bench_default.err";;
     probe)    timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe${PROBE_TAG:-}.log" 2>&1; rc=$?; cut -c1-330 "$OUT/probe${PROBE_TAG:-}.log";;
-    probe0)   WEPP_WALK_SORT=0 timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe_nosort.log" 2>&1; rc=$?; cut -c1-330 "$OUT/probe_nosort.log";;
     probestats) WEPP_PLACE_LIB=$REPO/variants/walkstats/libwepp_place.so WEPP_WALK_DEBUG=1 timeout -k 10 900 python tools/walk_probe.py > "$OUT/probestats.log" 2>&1; rc=$?; cut -c1-400 "$OUT/probestats.log";;
     pcie)     timeout -k 10 600 python tools/pcie_rate.py > "$OUT/pcie.log" 2>&1; rc=$?; grep -v amdgpu "$OUT/pcie.log" | cut -c1-200;;
     probe@*)  v=${step#probe@}; WEPP_PLACE_LIB=$REPO/variants/$v/libwepp_place.so timeout -k 10 900 python tools/walk_probe.py > "$OUT/probe_$v.log" 2>&1; rc=$?; cut -c1-200 "$OUT/probe_$v.log";;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate: wepp_place_batch with HOST buffers (validation, H2D of the reads, kernels, D2H of the results)
 on the bench workload, for every sub-batch count of the pipeline (wepp_mat_set_pipeline) with pageable and with
-caller-pinned buffers; WEPP_DEBUG_TIMING=1 adds the library's own phase print."""
+caller-pinned buffers; WEPP_DEBUG_TIMING=1 in the environment adds the library's own print per call (when each
+sub-batch's results were enqueued, the call's total).  PCIE_SUBBATCHES="1,2,4" restricts the sweep."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +20,7 @@ for b in batches:
     pinned.append(r)
 n = batches[0].n_reads
 pout = w.PlacementResult(pin(np.zeros(n, np.uint32)), pin(np.zeros(n, np.int32)), pin(np.zeros(n, np.uint32)), pin(np.zeros(n, np.uint32)))
-for S in (1, 2, 3, 4, 8):
+for S in [int(x) for x in os.environ.get("PCIE_SUBBATCHES", "1,2,3,4,8").split(",")]:
     mat.set_pipeline(S)
     for label, bs, o in (("pageable", batches, None), ("pinned", pinned, pout)):
         res = mat.place_batch(bs[0], out=o)

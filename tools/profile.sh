@@ -4,7 +4,9 @@
 # combined with --pmc; FETCH_SIZE and WRITE_SIZE do not fit one pass).  Summaries land in gpurun_out/prof_<tag>/;
 # tools/summarize_profile.py condenses them into profiles/<name>/ and profiles/pmc_counters.json.
 # PROFILE_PROG=tools/walk_probe.py (with PROBE_* in the environment) profiles a probe leg instead of bench.py;
-# PROFILE_PASSES="fetch write sq ..." restricts the counter passes.
+# PROFILE_PASSES="fetch write sq ..." restricts the counter passes ("none": the kernel trace only);
+# PROFILE_EXTRA="name:COUNTER COUNTER ...;name2:..." adds passes of other counters (e.g.
+# "tlb:TCP_UTCL1_REQUEST TCP_UTCL1_TRANSLATION_MISS;sqact:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS").
 set -u
 TAG=${1:-r3}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -34,6 +36,13 @@ pass tcc TCC_HIT_sum TCC_MISS_sum
 pass ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 pass grbm GRBM_GUI_ACTIVE
+if [ -n "${PROFILE_EXTRA:-}" ]; then
+  IFS=';' read -ra EXTRA <<< "$PROFILE_EXTRA"
+  for spec in "${EXTRA[@]}"; do
+    name=${spec%%:*}; PASSES="$PASSES $name"
+    pass "$name" ${spec#*:}
+  done
+fi
 # keep only the small summaries (stats + per-kernel counter rows of our kernels)
 find "$OUT" -name "*.csv" -size +2M -exec sh -c 'head -400 "$1" > "$1.head"; rm "$1"' _ {} \;
 du -sh "$OUT"
