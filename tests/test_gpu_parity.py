@@ -586,15 +586,17 @@ def test_window_crowns_walks_and_sweeps_vs_oracle(oracle):
     check(mat.place_batch(reads))
     pcls, pst = mat.last_plans(reads.n_reads)
     win, crown = mat.last_crowns(reads.n_reads)
-    on_crown = pst == w.WINDOW_CROWN_SLOT
+    on_crown = (pst == w.WINDOW_CROWN_SLOT) & (pcls != w.PLAN_WIN)      # (a window plan's stream number is its window)
     assert on_crown.mean() > 0.6 and len(np.unique(crown[on_crown])) >= 3 and len(np.unique(win[on_crown])) >= 20
     k = np.diff(reads.read_off.astype(np.int64))
     assert ((pcls == w.PLAN_SWEEP) & on_crown).sum() > 500 and (k[(pcls == w.PLAN_SWEEP) & on_crown] > 16).all()
+    # reads with more than 32 entries share tile sweeps of their window's candidates (all of them: any root score)
+    assert (pcls == w.PLAN_WIN).sum() > 100 and (k[pcls == w.PLAN_WIN] > 32).all()
     assert ((pcls == w.PLAN_WALK8) & on_crown).sum() > 1000 and ((pcls == w.PLAN_WALK16) & on_crown).sum() > 100
     mat.set_use_walk(False)
     check(mat.place_batch(reads))
     pcls2, pst2 = mat.last_plans(reads.n_reads)
-    assert ((pst2 == w.WINDOW_CROWN_SLOT) == on_crown).all() and (pcls2[on_crown] == w.PLAN_SWEEP).all()
+    assert (((pst2 == w.WINDOW_CROWN_SLOT) & (pcls2 != w.PLAN_WIN)) == on_crown).all() and (pcls2[on_crown] == w.PLAN_SWEEP).all()
     mat.set_use_walk(True)
     mat.set_use_crowns(False)
     check(mat.place_batch(reads))

@@ -164,29 +164,32 @@ def test_window_crowns_hold_every_node_that_can_win(oracle):
     has_unique) -- on trees whose mutations crowd a few windows (long genome, 1024-position stride), with reads that
     list up to 16 positions of one window, most of them N; whole and cut into jobs."""
     rng = np.random.default_rng(77)
-    n = covered = 0
+    n = covered = n_last = 0
     levels = set()
     for it in range(6):
         g = w.generate_tree(100 + it, 4000, genome_len=5000, p_ambiguous=0.02, p_masked_node=0.01, root_mutations=it % 2,
                             p_back_mutation=0.1)
         ot = oracle.OracleTree(g.tree)
         fv = w.FlatView(g.tree)
-        tau = fv.get("wc_tau").view(np.int32).reshape(-1, 6)
-        nodes = fv.get("wc_nodes").reshape(-1, 6)
+        tau = fv.get("wc_tau").view(np.int32).reshape(-1, w.WINDOW_CROWN_LEVELS)
+        nodes = fv.get("wc_nodes").reshape(-1, w.WINDOW_CROWN_LEVELS)
         assert tau.shape[0] >= 4 and (nodes[:, 0] > 0).all()
         assert fv.stats.n_window_crowns == int((nodes > 0).sum()) and fv.stats.window_crown_nodes == int(nodes.sum())
         reads = g.reads(200 + it, 160, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.01, p_n=0.04, p_iupac=0.2)
+        # ... and long reads full of substitutions: a root score beyond every bounded crown, so the window's LAST crown
+        # (all the nodes any read of the window can be placed on: out_w - in_w <= base(root), flatmat.cpp)
+        long_reads = g.reads(300 + it, 60, read_len=900, amplicon_len=1000, amplicon_step=700, p_substitution=0.04, p_n=0.02, p_iupac=0.1)
         models = {}
-        for q in range(reads.n_reads):
-            pos, ref, mut, miss = reads.entries(q)
+        for q in range(reads.n_reads + long_reads.n_reads):
+            pos, ref, mut, miss = reads.entries(q) if q < reads.n_reads else long_reads.entries(q - reads.n_reads)
             S = list(zip(pos.tolist(), ref.tolist(), mut.tolist(), miss.tolist()))
-            if not S or len(S) > 16:
+            if not S or (len(S) > 16 and q < reads.n_reads):
                 continue
             wi = S[0][0] // 1024
             if wi >= tau.shape[0] or S[-1][0] >= wi * 1024 + 2560:
                 continue
             rs = _root_score(fv, S)
-            ci = next((i for i in range(6) if nodes[wi, i] and rs <= tau[wi, i]), None)
+            ci = next((i for i in range(w.WINDOW_CROWN_LEVELS) if nodes[wi, i] and rs <= tau[wi, i]), None)
             n += 1
             if ci is None:
                 continue
@@ -201,4 +204,5 @@ def test_window_crowns_hold_every_node_that_can_win(oracle):
             assert m.n < len(fv.get("nkey"))          # a crown, not the tree
             covered += 1
             levels.add(ci)
-    assert covered > 500 and covered > 0.6 * n and len(levels) >= 3
+            n_last += int(tau[wi, ci] == 0x7FFFFFFF and len(S) > 16)
+    assert covered > 500 and covered > 0.6 * n and len(levels) >= 3 and n_last > 30

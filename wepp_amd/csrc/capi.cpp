@@ -142,6 +142,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         if ((rc = up_stream(f.wstreams[i], (uint32_t)(f.streams.size() - 1), getenv("WEPP_WIN_EAGER") ? atoi(getenv("WEPP_WIN_EAGER")) != 0 : true, ds)) != WEPP_OK) return rc;
         h->wstreams.push_back(ds);
         h->wstream_bytes.push_back(f.wstreams[i].stream_bytes());
+        if (i < MAX_WINDOWS) d.win_n[i] = f.wstreams[i].ncnt.empty() ? f.wstreams[i].n : 0xFFFFFFFFu;   // (pseudo-nodes: the whole tree)
     }
     d.n_windows = (uint32_t)f.wstreams.size();
     for (size_t i = 0; i < f.streams.size(); i++) {

@@ -88,7 +88,11 @@ struct DevMAT {
     const WcInfo* wc_info;        // [wc_windows * WC_MAX] the window crowns of every genome window, increasing tau
     const DevStream* wc_streams;  // [wc_windows * WC_MAX] their sweep streams (k_sweep_arena)
     uint32_t wc_windows;          // 0: none built
+    uint32_t win_n[MAX_WINDOWS];  // nodes of window w's stream when it is a crown (all the window's candidates, flatmat.hpp), 0xFFFFFFFF when the whole tree
 };
+// reads with more entries than this whose positions lie in one genome window share tile sweeps of the window's stream
+// (PLAN_WIN) when that is a crown; shorter ones that cannot walk sweep their window crown alone (k_sweep_arena)
+constexpr uint32_t WIN_MIN_ENTRIES = 32;
 
 // A placement call sorts its reads into PLANS: plan id = class * MAX_STREAMS + stream, the windows' plans behind
 // them (plan_id / plan_class / plan_index; k_scatter's prefix over the routing blocks costs per plan id, so the

@@ -311,7 +311,7 @@ int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::
 
 // a crown (or the whole tree): the ancestor-closed node subset `sel` (sorted global DFS indices, sel[0] == 0)
 int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err,
-                 uint32_t pos_lo = 0, uint32_t pos_hi = 0xFFFFFFFFu) {
+                 uint32_t pos_lo = 0, uint32_t pos_hi = 0xFFFFFFFFu, bool walk_index = true) {
     const uint32_t n = (uint32_t)sel.size();
     const uint32_t N = f.N;
     // number of selected nodes with global index <= g
@@ -327,6 +327,7 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
     el.g = sel;
     el.pos_lo = pos_lo;          // (a window crown indexes the mutations of its window only)
     el.pos_hi = pos_hi;
+    el.walk_index = walk_index;
     el.nkey.resize(n); el.nstat.resize(n); el.cnt.assign(n, 1); el.min_all.resize(n); el.lend.resize(n); el.lpar.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t g = sel[i];
@@ -560,9 +561,11 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
     std::vector<int32_t> D0(N, 0);
     std::vector<int32_t> base(N, 0);
     // window crowns (flatmat.hpp): inw[w] = positions of window w at which the current path's genotype differs from
-    // the reference; cand[w] = the nodes with out_w <= root score + WC_MAX_DTAU, in DFS order, with their out_w
+    // the reference; cand[w] = the nodes a read of window w can be placed on at all (below), in DFS order, with their out_w
     const uint32_t n_win = (!topology_only && max_pos + 1 > WIN_STRIDE) ? std::min<uint32_t>(MAX_WINDOWS, (max_pos + WIN_STRIDE) / WIN_STRIDE) : 0u;
-    std::vector<int32_t> inw(n_win, 0), inw_e(n_win, 0), inw_par(n_win, 0);
+    // inw_p[w] = upper bound of the window positions at which the genotype a node is SCORED against can differ from the
+    // reference, whatever the read: the parent genotype's, plus the node's own mutations away from the reference
+    std::vector<int32_t> inw(n_win, 0), inw_e(n_win, 0), inw_par(n_win, 0), inw_p(n_win, 0);
     std::vector<std::vector<std::pair<uint32_t, int32_t>>> cand(n_win);
     // the windows [w * WIN_STRIDE, w * WIN_STRIDE + WIN_SIZE) that hold position p
     auto windows_of = [&](uint32_t p, auto&& fn) {
@@ -593,7 +596,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             int32_t dcur = dpar;
             uint32_t nback_cost = 0, ncommon0 = 0;
             uint32_t w = f.node_woff[d];
-            if (n_win) { inw_par = inw; inw_e = inw; }     // the parent genotype's counts; own back-mutations are taken off inw_e below
+            if (n_win) { inw_par = inw; inw_e = inw; inw_p = inw; }     // the parent genotype's counts; own back-mutations are taken off inw_e below
             for (uint32_t k = t.mut_off[id]; k < t.mut_off[id + 1]; k++) {
                 int32_t p = t.mut_pos[k];
                 if (p < 0) continue;
@@ -611,7 +614,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
                 if (n_win) {
                     const int32_t dl = (int32_t)cost0(mut, ref) - (int32_t)cost0(par, ref);
                     const bool back = mut == ref && cost0(par, ref);
-                    if (dl || back) windows_of((uint32_t)p, [&](uint32_t wi) { inw[wi] += dl; if (back) inw_e[wi]--; });
+                    if (dl || back) windows_of((uint32_t)p, [&](uint32_t wi) { inw[wi] += dl; if (back) inw_e[wi]--; if (dl > 0) inw_p[wi]++; });
                 }
                 w++;
             }
@@ -636,10 +639,13 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             if (n_win && d) {
                 // out_w(d) = base(d) minus the window's share of it (a masked node is scored on its parent's genotype
                 // as it stands: none of its back-mutations counts, inside or outside the window)
-                const int32_t lim = base[0] + (int32_t)WC_MAX_DTAU;
+                // A read of the window scores d at least s0 + out_w(d) - in_w(d) -- s0 = what its entries cost against the
+                // reference, in_w(d) <= inw_p the window positions at which the scored genotype is not the reference
+                // (each can save the read at most one) -- and the root, which always competes, at most s0 + base(root):
+                // a node with out_w - inw_p > base(root) can neither win nor tie, whatever the read lists (flatmat.hpp)
                 for (uint32_t wi = 0; wi < n_win; wi++) {
                     const int32_t out = base[d] - (masked ? inw_par[wi] : inw_e[wi]);
-                    if (out <= lim) cand[wi].emplace_back(d, out);
+                    if (out - (masked ? inw_par[wi] : inw_p[wi]) <= base[0]) cand[wi].emplace_back(d, out);
                 }
             }
             open.push_back(d);
@@ -701,23 +707,15 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
         if (rc != WEPP_OK) return rc;
     }
 
-    // ---- window streams: the whole tree per genome window, for reads with many entries (long reads) -----
-    // windows of WIN_SIZE positions every WIN_STRIDE: a read whose listed positions span less than the stride
-    // lies inside the window that starts at its first position rounded down
-    if (f.max_pos + 1 > WIN_STRIDE) {
-        const uint32_t nw = std::min<uint32_t>(MAX_WINDOWS, (f.max_pos + WIN_STRIDE) / WIN_STRIDE);
-        f.wstreams.resize(nw);
-        for (uint32_t wi = 0; wi < nw; wi++) {
-            int rc = build_window_stream(f, wi * WIN_STRIDE, wi * WIN_STRIDE + WIN_SIZE, f.wstreams[wi], err);
-            if (rc != WEPP_OK) return rc;
-        }
-    }
-
-    // ---- window crowns (flatmat.hpp): per genome window, the nodes with out_w <= tau and their ancestors --------
+    // ---- window crowns (flatmat.hpp): per genome window, the candidates with out_w <= tau and their ancestors; and the
+    // window STREAM the tiles of long reads sweep: all the window's candidates (any root score), or the whole tree as
+    // the window sees it when they are too many to be worth a crown --------
     if (n_win) {
         f.wcrowns.assign(n_win, {});
+        f.wstreams.resize(n_win);
         std::vector<std::string> errs(n_win);
         std::vector<int> rcs(n_win, WEPP_OK);
+        static const bool no_balanced = getenv("WEPP_WIN_WHOLE_TREE") && getenv("WEPP_WIN_WHOLE_TREE")[0] == '1';   // (A/B and test aid)
         auto build_window = [&](uint32_t wi, std::vector<uint8_t>& mark) {
             // the crowns of a window nest: the marks stay from one tau to the next
             std::vector<uint32_t> sel(1, 0u);
@@ -727,19 +725,36 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             std::vector<std::pair<int32_t, uint32_t>> by_out(cw.size());
             for (size_t i = 0; i < cw.size(); i++) by_out[i] = {cw[i].second, cw[i].first};
             std::sort(by_out.begin(), by_out.end());
-            for (uint32_t dt = 0; dt <= WC_MAX_DTAU && f.wcrowns[wi].size() < WC_MAX; dt++) {
-                const int32_t tau = f.root_base + (int32_t)dt;
+            const uint32_t lo = wi * WIN_STRIDE, hi = wi * WIN_STRIDE + WIN_SIZE;
+            bool all = false;                                   // the last crown built holds every candidate
+            for (uint32_t dt = 0; dt <= WC_MAX_DTAU + 1 && f.wcrowns[wi].size() < WC_MAX; dt++) {
+                // (the last level takes all candidates: tau = "any root score")
+                const bool last = dt == WC_MAX_DTAU + 1;
+                const int32_t tau = last ? 0x7FFFFFFF : f.root_base + (int32_t)dt;
                 for (; at < by_out.size() && by_out[at].first <= tau; at++)
                     for (uint32_t d = by_out[at].second; !mark[d]; d = f.parent_dfs[d]) { mark[d] = 1; sel.push_back(d); }
                 if (sel.size() > WC_MAX_NODES || sel.size() * 4 > N) break;         // (the tree-wide crowns take over)
-                if (prev && sel.size() < prev + prev / 4 && dt < WC_MAX_DTAU) continue;   // too close to the previous one
+                if (at == by_out.size() && !last) continue;                          // (nothing more to come: the last level is this one)
+                if (prev && sel.size() < prev + prev / 4 && !last) continue;        // too close to the previous one
+                if (last && sel.size() == prev) {                                    // the previous crown already holds them all
+                    f.wcrowns[wi].back().tau = tau;
+                    all = true;
+                    break;
+                }
                 std::sort(sel.begin(), sel.end());
                 f.wcrowns[wi].emplace_back();
                 Stream& st = f.wcrowns[wi].back();
                 st.tau = tau;
-                rcs[wi] = build_stream(f, sel, st, errs[wi], wi * WIN_STRIDE, wi * WIN_STRIDE + WIN_SIZE);
+                rcs[wi] = build_stream(f, sel, st, errs[wi], lo, hi);
                 if (rcs[wi] != WEPP_OK) break;
                 prev = sel.size();
+                all = last;
+            }
+            if (rcs[wi] == WEPP_OK) {
+                if (all && !no_balanced) {
+                    rcs[wi] = build_stream(f, sel, f.wstreams[wi], errs[wi], lo, hi, /*walk_index=*/false);
+                    f.wstreams[wi].tau = 0x7FFFFFFF;
+                } else rcs[wi] = build_window_stream(f, lo, hi, f.wstreams[wi], errs[wi]);
             }
             for (uint32_t d : sel) mark[d] = 0;
         };

@@ -202,7 +202,7 @@ constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of 
 // window crowns: at most WC_MAX per window, tau = root score + 0 .. WC_MAX_DTAU, none larger than WC_MAX_NODES nodes;
 // in plan ids and diagnostics they all share ONE stream slot, the last one (the tree-wide streams use at most
 // MAX_STREAMS - 1 slots): which window crown a read walks is a per-read value (k_route)
-constexpr uint32_t WC_MAX = 6, WC_MAX_DTAU = 5, WC_MAX_NODES = 1u << 19, WC_SLOT = MAX_STREAMS - 1;
+constexpr uint32_t WC_MAX = 7, WC_MAX_DTAU = 5, WC_MAX_NODES = 1u << 19, WC_SLOT = MAX_STREAMS - 1;
 
 // flatten_tree calls of this process that built the full image (not topology_only): lets a test see that a
 // multi-device run flattened once

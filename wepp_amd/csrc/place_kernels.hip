@@ -286,11 +286,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         };
         // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
         // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
-        uint32_t sid = NONE;
-        if (use_crowns && k > 0 && m.wc_windows) {
+        uint32_t sid = NONE, wi = 0;
+        bool in_win = false;                   // all listed positions inside genome window wi
+        if (use_crowns && k > 0) {
             const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
-            const uint32_t wi = p_lo / WIN_STRIDE;
-            if (wi < m.wc_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) {
+            wi = p_lo / WIN_STRIDE;
+            in_win = p_hi < wi * WIN_STRIDE + WIN_SIZE;
+            if (in_win && wi < m.wc_windows) {
                 const int rs = m.root_base + c;
                 for (uint32_t i = 0; i < WC_MAX; i++) {
                     const WcInfo* q = m.wc_info + wi * WC_MAX + i;
@@ -320,16 +322,17 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 atomicMax(&open_of[small ? 2 : 3], open_max);
             }
         }
-        if (cls == PLAN_SWEEP && sid != NONE) {
-            // it cannot walk (more than WALK16_K entries or too deep a stack): one wave sweeps its window crown (k_sweep_arena)
+        if (cls == PLAN_SWEEP && in_win && wi < m.n_windows &&
+            (k > WIN_MIN_ENTRIES ? (m.win_n[wi] < m.walks[t].n || t + 1 == m.n_streams) : (sid == NONE && t + 1 == m.n_streams))) {
+            // many entries, all inside one genome window: a tile of such reads sweeps the window's stream -- the window's
+            // candidates (a crown of a few thousand nodes, whatever the root score) or, for the reads no crown serves,
+            // the whole tree as the window sees it
+            cls = PLAN_WIN;
+            t = wi;
+        } else if (cls == PLAN_SWEEP && sid != NONE) {
+            // it cannot walk (more than WALK16_K entries or too deep a stack): waves of its own sweep its window crown (k_sweep_arena)
             wsid[r] = sid;
             t = WC_SLOT;
-        }
-        if (cls == PLAN_SWEEP && t != WC_SLOT && use_crowns && k > 0 && t + 1 == m.n_streams && m.n_windows) {
-            // many entries, whole tree: if they all lie inside one genome window, that window's stream will do
-            const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
-            const uint32_t wi = p_lo / WIN_STRIDE;
-            if (wi < m.n_windows && p_hi < wi * WIN_STRIDE + WIN_SIZE) { cls = PLAN_WIN; t = wi; }
         }
         t = plan_id(cls, t);
         tier_of[r] = (uint8_t)t;
