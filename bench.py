@@ -453,10 +453,17 @@ def main():
             "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]), "bytes": int(st.stream_bytes_of[i]),
                          "reads_routed": int(counts[i])} for i in range(st.n_streams)],
             "window_crowns": {"what": "per genome window (2560 positions every 1024) the nodes a read confined to the window can be "
-                                      "placed on given its ROOT score: the bound of a read's search without the + |S| slack of the "
-                                      "tree-wide streams above (DESIGN.md 4.2c)",
+                                      "placed on: out_w - in_w <= base(root) whatever it lists (the last crown of a window), and "
+                                      "out_w <= its ROOT score (the smaller ones) -- no + |S| slack as for the tree-wide streams "
+                                      "above (DESIGN.md 4.2c)",
                               "crowns": int(st.n_window_crowns), "nodes_in_all": int(st.window_crown_nodes),
                               "reads_routed": int(counts[w.WINDOW_CROWN_SLOT])},
+            "window_streams": {"what": "what the tiles of reads with more than 32 entries inside one genome window sweep (plan class "
+                                       "'window'; `streams` counts them under the whole tree): the window's candidate crown, or the "
+                                       "whole tree as the window sees it where no crown was built",
+                               "streams": int(st.n_window_streams), "of_which_candidate_crowns": int(st.n_window_streams_crown),
+                               "elements_in_all": int(st.window_stream_nodes),
+                               "reads_routed": int((pcls == w.PLAN_WIN).sum())},
         }
         if whole is not None:
             wr, wc = sweep_roofline("whole_tree", R, whole["kernel_ms_per_step"], whole["algorithmic_bytes_per_step"],

@@ -104,6 +104,13 @@ typedef struct {
     /* window crowns (see wepp_mat_last_crowns): how many were built, their nodes in all */
     uint32_t n_window_crowns;
     uint64_t window_crown_nodes;
+    /* window streams (plan class WEPP_PLAN_WIN: tiles of reads with many entries inside one genome window): how many
+     * of them are the window's CANDIDATE crown -- the nodes n with out_w(n) - in_w(n) <= score of the root for an
+     * empty read, the only ones a read confined to the window can be placed on whatever it lists -- rather than the
+     * whole tree as the window sees it, and the elements of all window streams */
+    uint32_t n_window_streams;
+    uint32_t n_window_streams_crown;
+    uint64_t window_stream_nodes;
 } wepp_mat_stats;
 
 /* Per-read result flags (out parameter `flags`). */

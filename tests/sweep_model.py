@@ -178,7 +178,8 @@ class FlatModel:
                 if elig and pruned:
                     assert score > bs, "pruning bound violated"
                 if elig and not pruned:
-                    k = int(self.ncnt[n0 + i]) if self.window else 1
+                    # (a window stream that is the window's candidate crown has real nodes only: no counts)
+                    k = int(self.ncnt[n0 + i]) if self.window and len(self.ncnt) else 1
                     if score < bs:
                         bs, br, cnt = score, rank, k
                     elif score == bs:

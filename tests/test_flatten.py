@@ -205,6 +205,7 @@ def test_window_streams_match_oracle(oracle):
     from wepp_amd import _lib
     rng = np.random.default_rng(21)
     checked = 0
+    kinds = {True: 0, False: 0}
     for it in range(12):
         g = w.generate_tree(100 + it, int(rng.integers(300, 3000)), genome_len=5000, p_ambiguous=0.02, p_masked_node=0.01,
                             root_mutations=int(rng.integers(0, 3)))
@@ -229,4 +230,7 @@ def test_window_streams_match_oracle(oracle):
             checked += 1
         for wi, m in models.items():
             assert m.N < g.tree.n_nodes or g.tree.n_nodes < 50        # fewer elements than nodes
-    assert checked > 300
+            kinds[len(m.ncnt) == 0] += 1
+    # both kinds of window stream were swept: the window's candidate crown (real nodes only), and the whole tree with
+    # pseudo-nodes where the candidates were too many to be worth a crown
+    assert checked > 300 and kinds[True] >= 5 and kinds[False] >= 5, kinds

@@ -216,6 +216,34 @@ def test_config5_long_reads(oracle):
     mat.close()
 
 
+def test_long_reads_on_both_kinds_of_window_stream(oracle):
+    """The tiles of long reads sweep their genome window's CANDIDATE crown -- the nodes with out_w - in_w <= base(root),
+    the only ones a read confined to the window can be placed on whatever it lists (wepp_mat_stats:
+    n_window_streams_crown) -- or, where the candidates are too many to be worth a crown (small trees), the whole tree
+    as the window sees it.  Trees of both kinds, substitution-rich 900 bp reads (root scores far beyond every bounded
+    crown), ambiguity codes, masked nodes, root mutations: the oracle's placements on either."""
+    rng = np.random.default_rng(5)
+    crowns = whole = on_win = 0
+    for it, n in enumerate([400, 1200, 3000, 9000, 30000, 90000]):
+        # (a 5 kb genome: a window is half of it and nearly every node a candidate -- whole-tree window streams; the
+        # 29.9 kb one: candidate crowns)
+        g = w.generate_tree(300 + it, n, genome_len=5000 if it < 3 else 29903, p_ambiguous=0.02, p_masked_node=0.01,
+                            root_mutations=it % 3, p_back_mutation=0.05)
+        reads = g.reads(400 + it, 700, read_len=900, amplicon_len=1000, amplicon_step=700, p_substitution=0.05, p_n=0.02, p_iupac=0.1)
+        mat = w.Mat(g.tree)
+        st = mat.stats
+        assert st.n_window_streams >= 4 and st.window_stream_nodes > 0
+        crowns += st.n_window_streams_crown
+        whole += st.n_window_streams - st.n_window_streams_crown
+        for tile in (64, 16):
+            mat.set_tile_reads(tile)
+            assert_same(mat.place_batch(reads), oracle.OracleTree(g.tree).place_batch(reads, os.cpu_count()), f"n={n} tile={tile}")
+        pcls, _ = mat.last_plans(reads.n_reads)
+        on_win += int((pcls == w.PLAN_WIN).sum())
+        mat.close()
+    assert crowns >= 60 and whole >= 10 and on_win > 2000, (crowns, whole, on_win)
+
+
 def test_ambiguous_masked_root_mutations(oracle):
     g = w.generate_tree(41, 20000, genome_len=3000, p_ambiguous=0.03, p_masked_node=0.01, root_mutations=5,
                         p_back_mutation=0.2)

@@ -39,7 +39,7 @@ def main():
     d_word = torch.from_numpy(reads.read_word.astype(np.int32)).to(dev)
     outs = [torch.zeros(R, dtype=torch.int32, device=dev) for _ in range(4)]
     st = mat.stats
-    for crowns in (True, False):
+    for crowns in ((True,) if os.environ.get("STATS_CROWNS_ONLY") else (True, False)):
         mat.set_use_crowns(crowns)
         stats(True)
         mat.place_batch_device(d_off.data_ptr(), d_word.data_ptr(), R, nw, *[o.data_ptr() for o in outs],

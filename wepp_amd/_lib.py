@@ -65,6 +65,9 @@ class MatStats(ctypes.Structure):
         ("stream_bytes_of", ctypes.c_uint64 * 16),
         ("n_window_crowns", ctypes.c_uint32),
         ("window_crown_nodes", ctypes.c_uint64),
+        ("n_window_streams", ctypes.c_uint32),
+        ("n_window_streams_crown", ctypes.c_uint32),
+        ("window_stream_nodes", ctypes.c_uint64),
     ]
 
 

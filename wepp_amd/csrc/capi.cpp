@@ -143,6 +143,9 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         h->wstreams.push_back(ds);
         h->wstream_bytes.push_back(f.wstreams[i].stream_bytes());
         if (i < MAX_WINDOWS) d.win_n[i] = f.wstreams[i].ncnt.empty() ? f.wstreams[i].n : 0xFFFFFFFFu;   // (pseudo-nodes: the whole tree)
+        h->stats.n_window_streams++;
+        h->stats.n_window_streams_crown += f.wstreams[i].ncnt.empty() ? 1u : 0u;
+        h->stats.window_stream_nodes += f.wstreams[i].n;
     }
     d.n_windows = (uint32_t)f.wstreams.size();
     for (size_t i = 0; i < f.streams.size(); i++) {

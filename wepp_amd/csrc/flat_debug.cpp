@@ -108,6 +108,11 @@ extern "C" int wepp_flat_scalars(const wepp_flat_t* flat, wepp_mat_stats* stats,
         stats->n_streams = (uint32_t)f.streams.size();
         for (const auto& wc : f.wcrowns)
             for (const wepp::Stream& st : wc) { stats->n_window_crowns++; stats->window_crown_nodes += st.n; }
+        for (const wepp::Stream& st : f.wstreams) {
+            stats->n_window_streams++;
+            stats->n_window_streams_crown += st.ncnt.empty() ? 1u : 0u;
+            stats->window_stream_nodes += st.n;
+        }
         for (size_t i = 0; i < f.streams.size(); i++) {
             stats->stream_tau[i] = f.streams[i].tau;
             stats->stream_nodes[i] = f.streams[i].n;
