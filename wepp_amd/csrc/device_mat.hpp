@@ -246,7 +246,7 @@ constexpr uint32_t WIN_WAVE_BYTES = 64 * 16 + 192 * 4 + 64 * 4;
 inline uint32_t sweep_lds_bytes(uint32_t bm_words, uint32_t ent_cap, uint32_t key_cap, bool dense, bool win_table = false) {
     // window plans of long reads: read words (position-major) + per window position the mask of the tile's
     // reads and the index of their first word + per-wave scratch + scan scratch
-    if (win_table) return ent_cap * 4 + WIN_TAB * 10 + DENSE_WAVES_PER_WG * (WIN_WAVE_BYTES + 4);
+    if (win_table) return ent_cap * 4 + WIN_TAB * 10 + DENSE_WAVES_PER_WG * (WIN_WAVE_BYTES + 4) + 64 * 4;   // (+ the tile's best scores so far)
     return bm_words * 4 + ent_cap * (dense ? 5 : 4) +
            (dense ? key_cap * 4 + DENSE_WAVES_PER_WG * 3 * 64 * 4 + DENSE_WINDOW * 2 : 0);
 }

@@ -497,6 +497,9 @@ __device__ __forceinline__ void sweep_tile(
     int* wacc = reinterpret_cast<int*>(wrec + 64);
     uint32_t* wmark = reinterpret_cast<uint32_t*>(wacc + 192);
     uint32_t* wscan = reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(tstart + WIN_TAB) + NW * (WIN_WAVE_BYTES / 16));
+    // the best score any wave of the workgroup has found for the read of lane l so far: the waves sweep different
+    // chunks of the same stream for the same reads, and a bound found in one prunes the others
+    int* wbest = reinterpret_cast<int*>(wscan + NW);
     const uint32_t win_lo = key_cap;
 
     const uint32_t tile = wg % ntiles;
@@ -558,20 +561,39 @@ __device__ __forceinline__ void sweep_tile(
     if (WIN) {
         for (uint32_t i = threadIdx.x; i < WIN_TAB; i += 64 * NW) { tmask[i] = 0ull; tstart[i] = 0; }
         for (uint32_t i = lane; i < 192; i += 64) wacc[i] = 0;
+        if (wv == 0) wbest[lane] = have ? root_sc + 1 : -(1 << 30);
     }
     STAT_T(11, t0_);
     tile_sync();
     STAT_T(5, t0_);
     const unsigned long long ts1_ = STAT_NOW();
     (void)ts1_;
+    // WIN: the share of its lane's read this wave stages (words wv, wv + NW, ...) stays in registers between the two
+    // passes over it -- up to WIN_OWN words; longer shares are read again --, and the wave's part of c (below) is
+    // counted on the way: every wave used to read all the words of its lane's read once more for c alone, 60 loads
+    // in a row per lane, a third of the cycles of a sweep of a window's candidate crown
+    constexpr uint32_t WIN_OWN = 16;
+    uint32_t wown[WIN ? WIN_OWN : 1];
+    int c_win = 0;
     if (WIN) {
         // every wave takes its share of the words of its lane's read
         uint32_t* tm32 = reinterpret_cast<uint32_t*>(tmask);
-        for (uint32_t j = wv; j < my_k; j += NW) {
-            const uint32_t p = w_pos(read_word[so + j]), rel = p - win_lo;
+#pragma unroll
+        for (uint32_t q = 0; q < WIN_OWN; q++) wown[q] = (wv + q * NW < my_k) ? read_word[so + wv + q * NW] : NONE;
+        auto stage_mask = [&](uint32_t sw) {
+            const uint32_t rel = w_pos(sw) - win_lo;
             if (rel < WIN_SIZE) atomicOr(&tm32[2 * rel + (lane >> 5)], 1u << (lane & 31));
-        }
+            if (!rw_missing(sw)) c_win += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0;
+        };
+#pragma unroll
+        for (uint32_t q = 0; q < WIN_OWN; q++)
+            if (wv + q * NW < my_k) stage_mask(wown[q]);
+        for (uint32_t j = wv + WIN_OWN * NW; j < my_k; j += NW) stage_mask(read_word[so + j]);
+        wacc[lane] = c_win;                      // (this wave's accumulators: cleared again below)
         __syncthreads();
+        c_win = 0;
+        for (uint32_t w2 = 0; w2 < NW; w2++)
+            c_win += reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(tstart + WIN_TAB) + w2 * (WIN_WAVE_BYTES / 16) + 64)[lane];
         // tstart = exclusive prefix sum of the masks' populations (consecutive positions per thread)
         constexpr uint32_t PER = (WIN_SIZE + 64 * NW - 1) / (64 * NW);
         const uint32_t i0 = threadIdx.x * PER;
@@ -585,6 +607,7 @@ __device__ __forceinline__ void sweep_tile(
         }
         if (lane == 63) wscan[wv] = inc;
         __syncthreads();
+        wacc[lane] = 0;                          // (every wave has read the parts of c by now)
         uint32_t run = inc - mine;
         for (uint32_t w2 = 0; w2 < wv; w2++) run += wscan[w2];
         for (uint32_t i = i0; i < min(i0 + PER, WIN_SIZE); i++) {
@@ -592,11 +615,15 @@ __device__ __forceinline__ void sweep_tile(
             run += (uint32_t)__popcll(tmask[i]);
         }
         __syncthreads();
-        for (uint32_t j = wv; j < my_k; j += NW) {
-            const uint32_t w = read_word[so + j], rel = w_pos(w) - win_lo;
+        auto stage_word = [&](uint32_t w) {
+            const uint32_t rel = w_pos(w) - win_lo;
             // (the copy keeps the allele fields; its position bits name the read's lane)
             if (rel < WIN_SIZE) sval[tstart[rel] + (uint32_t)__popcll(tmask[rel] & ((1ull << lane) - 1ull))] = (w & 0xFFF00000u) | lane;
-        }
+        };
+#pragma unroll
+        for (uint32_t q = 0; q < WIN_OWN; q++)
+            if (wv + q * NW < my_k) stage_word(wown[q]);
+        for (uint32_t j = wv + WIN_OWN * NW; j < my_k; j += NW) stage_word(read_word[so + j]);
     } else if (wv == 0) {
         auto stage = [&](uint32_t j, uint32_t w) {
             const uint32_t p = w_pos(w);
@@ -706,10 +733,12 @@ __device__ __forceinline__ void sweep_tile(
     // c for "no mutation anywhere on the path": every non-missing entry is
     // compared with its own reference allele (usher_mapper.cpp:302-305,342).
     int c = 0;
-    for (uint32_t j = 0; j < my_k; j++) {
-        uint32_t s = WIN ? read_word[so + j] : S[my_off + j];   // (WIN keeps the words position-major)
-        if (!rw_missing(s)) c += ((rw_mut(s) & rw_ref(s)) == 0) ? 1 : 0;
-    }
+    if (WIN) c = c_win;                     // (counted while the words were staged; they sit position-major in LDS)
+    else
+        for (uint32_t j = 0; j < my_k; j++) {
+            uint32_t s = S[my_off + j];
+            if (!rw_missing(s)) c += ((rw_mut(s) & rw_ref(s)) == 0) ? 1 : 0;
+        }
 
     STAT_T(6, ts1_);
     const unsigned long long ts2_ = STAT_NOW();
@@ -851,6 +880,17 @@ __device__ __forceinline__ void sweep_tile(
         (void)tb_;
         unsigned long long mk0 = 0, mk1 = 0;      // WIN: the tile's reads that list the positions of this lane's events
         if (WIN) { mk0 = win_mask(w0); mk1 = win_mask(w1); }
+        // WIN: what another wave of the workgroup has found for this lane's read bounds this chunk too.  A chunk that
+        // takes the bound over holds no node of that score yet (count 0: k_finalize ignores it unless it finds one)
+        int bs_in = bs;
+        if (WIN) {
+            const int g = wbest[lane];
+            if (g < bs) { bs = g; br = 0xFFFFFFFFu; cnt = 0; }
+            bs_in = bs;
+        }
+        auto publish = [&]() {
+            if (WIN && bs < bs_in) atomicMin(&wbest[lane], bs);
+        };
         const unsigned long long hm0 = WIN ? __ballot(mk0 != 0ull) : __ballot(bit(w0));
         const unsigned long long hm1 = WIN ? __ballot(mk1 != 0ull) : __ballot(bit(w1));
         STAT_ADD(0, 1);
@@ -879,6 +919,7 @@ __device__ __forceinline__ void sweep_tile(
 #endif
         if (!any_hit) {
             summary_update(true);
+            publish();
             STAT_T(1, tb_);
             return;
         }
@@ -923,6 +964,9 @@ __device__ __forceinline__ void sweep_tile(
             }
             fetched = true;
         };
+        // (window tiles of long reads evaluate some node of nearly every block with a hit -- 8.7 reads per block on a
+        // window's candidate crown --: the node data is requested here, and arrives while the pairs are resolved)
+        if (WIN) fetch_nodes();
         {
             // per-event bounds of this lane's two events.  Crown streams interleave low- and
             // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
@@ -1120,6 +1164,7 @@ __device__ __forceinline__ void sweep_tile(
             STAT_T(4, th_);
             c += net;
         }
+        publish();
     };
 
     // ---- the sweep: groups of 60 blocks (their 61 event offsets sit in one
