@@ -777,8 +777,11 @@ __device__ __forceinline__ void sweep_tile(
     // grp = the lanes whose read is word for word the read of lane r (they hold the same c, bs, br,
     // cnt at every point of the sweep): the evaluation is done once and its outcome taken by all
     // mm = this lane's two node offsets as loaded (byte 0: first event, byte 1: second)
+    // WIN: mk0 / mk1 / ts0 / ts1 = the window table's entries of this lane's two events (read mask, first word), looked
+    // up once per block: whether read r lists an event's position is a bit of its mask
     auto heavy_eval = [&](const BlkSum& sum, uint32_t e0, uint32_t e1, uint32_t w0, uint32_t w1, uint32_t mm,
-                          int64_t key, uint32_t st, uint32_t wt, int r, unsigned long long grp) {
+                          int64_t key, uint32_t st, uint32_t wt, int r, unsigned long long grp,
+                          unsigned long long mk0, unsigned long long mk1, uint32_t ts0, uint32_t ts1) {
         const uint32_t n0 = sum.node0;
         const uint32_t off_r = (uint32_t)__builtin_amdgcn_readlane((int)my_off, r);
         const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, r);
@@ -792,9 +795,11 @@ __device__ __forceinline__ void sweep_tile(
         }
         int cadd = 0, adj = 0, dcom = 0;
         bool touched = false;
-        auto apply = [&](uint32_t w, uint32_t mt) {
+        auto apply = [&](uint32_t w, uint32_t mt, unsigned long long mk, uint32_t ts, bool tabled) {
             uint32_t sw;
-            if (OWN) {
+            if (WIN && tabled) {
+                sw = ((mk >> r) & 1ull) ? sval[ts + (uint32_t)__popcll(mk & ((1ull << r) - 1ull))] : NONE;
+            } else if (OWN) {
                 // read r's first two words come from its lane's registers (uniform), the rest from LDS
                 const uint32_t p = w_pos(w);
                 sw = NONE;
@@ -836,11 +841,11 @@ __device__ __forceinline__ void sweep_tile(
                 }
             }
         };
-        apply(w0, mm);
-        apply(w1, mm >> 8);
+        apply(w0, mm, mk0, ts0, true);
+        apply(w1, mm >> 8, mk1, ts1, true);
         for (uint32_t e = e0 + 128; e < e1; e += 64) {      // rare: a block with more than 128 events
             const bool valid = e + lane < e1;
-            apply(valid ? m.ev_word[e + lane] : W_PAD_DEV, valid ? (uint32_t)m.ev_meta[e + lane] : 0u);
+            apply(valid ? m.ev_word[e + lane] : W_PAD_DEV, valid ? (uint32_t)m.ev_meta[e + lane] : 0u, 0ull, 0u, false);
         }
         const int base = (int)(key >> 32);
         const uint32_t rank = (uint32_t)(key & 0xFFFFFFFFll);
@@ -967,6 +972,8 @@ __device__ __forceinline__ void sweep_tile(
         // (window tiles of long reads evaluate some node of nearly every block with a hit -- 8.7 reads per block on a
         // window's candidate crown --: the node data is requested here, and arrives while the pairs are resolved)
         if (WIN) fetch_nodes();
+        uint32_t ts0 = 0, ts1 = 0;               // WIN: first word of this lane's events' positions in the position-major copy
+        if (WIN) { ts0 = tstart[min(w_pos(w0) - win_lo, WIN_SIZE)]; ts1 = tstart[min(w_pos(w1) - win_lo, WIN_SIZE)]; }
         {
             // per-event bounds of this lane's two events.  Crown streams interleave low- and
             // high-score nodes, so the per-event bound (one more 2-byte load) is what prunes there;
@@ -1054,8 +1061,7 @@ __device__ __forceinline__ void sweep_tile(
                 STAT_ADD(3, npairs);
                 // (an event record keeps the word's allele / flag bits; its position bits carry the event's bound)
                 wrec[lane] = make_uint4((w0 & 0xFFF00000u) | min(lb0, 255u), (w1 & 0xFFF00000u) | min(lb1, 255u), exc | (n0 << 16),
-                                        (uint32_t)tstart[min(w_pos(w0) - win_lo, WIN_SIZE)] |
-                                            ((uint32_t)tstart[min(w_pos(w1) - win_lo, WIN_SIZE)] << 16));
+                                        ts0 | (ts1 << 16));
                 uint32_t carry = 0;
                 for (uint32_t pb = 0; pb < npairs; pb += 64) {
                     wmark[lane] = 0;
@@ -1159,7 +1165,7 @@ __device__ __forceinline__ void sweep_tile(
                 }
                 hv &= ~grp;
                 if (!fetched) fetch_nodes();
-                heavy_eval(sum, e0, e1, w0, w1, mm, key, st, wt, r, grp);
+                heavy_eval(sum, e0, e1, w0, w1, mm, key, st, wt, r, grp, mk0, mk1, ts0, ts1);
             }
             STAT_T(4, th_);
             c += net;
