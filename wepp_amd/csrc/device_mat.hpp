@@ -226,8 +226,12 @@ hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_
                         uint32_t ntiles, uint32_t nchunks, uint32_t blocks_per_chunk, bool s_in_lds, bool dense,
                         bool win_table, uint32_t ent_cap, uint32_t key_cap, uint32_t lds_bytes, int32_t* part_score,
                         uint32_t* part_rank, uint32_t* part_cnt, hipStream_t stream);
+// waves of a dense / window workgroup (one tile: they share its tables and sweep a chunk each).  16: a window's
+// candidate crown is a few hundred blocks, and a tile's set-up -- a third of the cycles there -- is paid once per
+// workgroup: 1.2 kb reads 3.03 -> 2.83 ms per 200 K against 8 (4: 3.99); on whole-tree window streams (small trees)
+// 8 was 6 % faster (107 against 114 ms)
 #ifndef WEPP_DENSE_WAVES
-#define WEPP_DENSE_WAVES 8
+#define WEPP_DENSE_WAVES 16
 #endif
 #ifndef WEPP_SWEEP_WAVES
 #define WEPP_SWEEP_WAVES 1
