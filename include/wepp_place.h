@@ -258,13 +258,15 @@ int wepp_mat_last_tiers(wepp_mat_t *mat, uint8_t *tiers, uint32_t n_reads);
 #define WEPP_PLAN_SWEEP   2   /* sweep of the stream with up to 63 other reads             */
 #define WEPP_PLAN_WALKC8  3   /* walk cut into jobs (many events), up to 8 positions       */
 #define WEPP_PLAN_WALKC16 4   /* walk cut into jobs, up to 16 positions                    */
-#define WEPP_PLAN_WIN     5   /* sweep of a genome window's stream (long reads)            */
+#define WEPP_PLAN_WIN     5   /* tile sweep of a genome window's stream (reads with more than 32 entries inside one window) */
 int wepp_mat_last_plans(wepp_mat_t *mat, uint8_t *plan_class, uint8_t *plan_stream, uint32_t n_reads);
-/* plan_stream == WEPP_WINDOW_CROWN_SLOT: the read walked a WINDOW CROWN -- the nodes whose score for any read
- * confined to its genome window can be as low as the read's root score (positions outside the window cost every
- * such read the same), far fewer than the tree-wide crown of root score + entries.  wepp_mat_last_crowns tells
- * which: window[r] = index of the genome window, crown[r] = index of the crown among the window's (increasing
- * bound); 255 / 255 for a read placed otherwise. */
+/* plan_stream == WEPP_WINDOW_CROWN_SLOT with a class other than WEPP_PLAN_WIN: the read walked (or, class
+ * WEPP_PLAN_SWEEP, swept alone) a WINDOW CROWN -- of the nodes a read confined to its genome window can be placed on at
+ * all (at least as many of the path's mutations inside the window as outside), those whose score can be as low as the
+ * read's root score (positions outside the window cost every such read the same): far fewer than the tree-wide crown
+ * of root score + entries.  wepp_mat_last_crowns tells which for the reads that walked: window[r] = index of the genome
+ * window, crown[r] = index of the crown among the window's (increasing bound; the last one admits any root score);
+ * 255 / 255 for a read placed otherwise.  (For class WEPP_PLAN_WIN plan_stream is the window's index, which may be 15.) */
 #define WEPP_WINDOW_CROWN_SLOT 15
 int wepp_mat_last_crowns(wepp_mat_t *mat, uint8_t *window, uint8_t *crown, uint32_t n_reads);
 
