@@ -297,6 +297,13 @@ def main():
         return float(tt.item())
 
     # ---- the timed region: K steps, inputs resident in HBM ----------------------------------
+    # Set-up, not warm-up: every distinct batch of the rotation is placed once, so that the handle's grow-only device
+    # workspaces have the size the rotation needs before the W warm-up steps (a batch whose longest read changes the
+    # tile size can need a workspace a quarter larger: one hipFree + hipMalloc of ~100 MB, 16 ms, once per handle -- with
+    # 8 batches and W = 2 it landed in the timed steps of the long-read run: 3.7 instead of 2.9 ms per step)
+    for b in batches:
+        b.place(mat, stream)
+    fence()
     for i in range(args.warmup):
         batches[i % len(batches)].place(mat, stream)
     fence()
@@ -432,6 +439,7 @@ def main():
                 "pcie_inclusive_reads_per_s": pcie["value"] if pcie else None,
                 "pcie_inclusive_ms_per_step": pcie["ms_per_step"] if pcie else None,
                 "distinct_batches_in_rotation": args.batches,
+                "setup_places_every_batch_once": True,     # (device workspaces reach their size before warm-up; see the timed region)
                 "workload": f"synthetic SARS-CoV-2-like MAT N={st.n_nodes} nodes M={st.n_mutations} mutations "
                             f"(seed 21, L=29903), {shape}",
                 "reads_per_gpu": R,

@@ -402,7 +402,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     auto grow = [&](size_t need) -> int {
         if (need <= L.ws_bytes) return WEPP_OK;
         if (L.ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(L.ws); L.ws = nullptr; L.ws_bytes = 0; }
-        need += need / 4;
+        // (half as much again: the partials of a batch of long reads vary by a third with the tile size its longest
+        // read allows, and a regrowth costs a hipFree + hipMalloc of ~100 MB -- 16 ms -- plus a second routing pass)
+        need += need / 2;
         hipError_t e = hipMalloc(&L.ws, need);
         if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
         L.ws_bytes = need;

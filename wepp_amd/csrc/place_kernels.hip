@@ -568,32 +568,45 @@ __device__ __forceinline__ void sweep_tile(
     STAT_T(5, t0_);
     const unsigned long long ts1_ = STAT_NOW();
     (void)ts1_;
-    // WIN: the share of its lane's read this wave stages (words wv, wv + NW, ...) stays in registers between the two
-    // passes over it -- up to WIN_OWN words; longer shares are read again --, and the wave's part of c (below) is
-    // counted on the way: every wave used to read all the words of its lane's read once more for c alone, 60 loads
-    // in a row per lane, a third of the cycles of a sweep of a window's candidate crown
-    constexpr uint32_t WIN_OWN = 16;
+    // WIN: a wave stages whole READS -- reads wv, wv + NW, ... of the tile, lane = word: one coalesced load per read
+    // (each lane used to fetch its own read's words, NW apart: ~60 scattered dwords per read, every cache line asked for
+    // by every wave) --, keeps the first 64 words of each in a register between the two passes (longer reads: read
+    // again) and counts the read's c on the way (every wave used to read all the words of its lane's read once more
+    // for c alone).  The counts travel through wave 0's accumulators (cleared again below).
+    constexpr uint32_t WIN_OWN = (64 + NW - 1) / NW;     // reads per wave
     uint32_t wown[WIN ? WIN_OWN : 1];
     int c_win = 0;
     if (WIN) {
-        // every wave takes its share of the words of its lane's read
         uint32_t* tm32 = reinterpret_cast<uint32_t*>(tmask);
+        int* cacc = reinterpret_cast<int*>(reinterpret_cast<uint4*>(tstart + WIN_TAB) + 64);      // wave 0's net[]
 #pragma unroll
-        for (uint32_t q = 0; q < WIN_OWN; q++) wown[q] = (wv + q * NW < my_k) ? read_word[so + wv + q * NW] : NONE;
-        auto stage_mask = [&](uint32_t sw) {
-            const uint32_t rel = w_pos(sw) - win_lo;
-            if (rel < WIN_SIZE) atomicOr(&tm32[2 * rel + (lane >> 5)], 1u << (lane & 31));
-            if (!rw_missing(sw)) c_win += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0;
-        };
+        for (uint32_t q = 0; q < WIN_OWN; q++) {
+            const uint32_t r = wv + q * NW;                 // wave-uniform
+            wown[q] = NONE;
+            if (r < nr) {
+                const uint32_t so_r = (uint32_t)__builtin_amdgcn_readlane((int)so, (int)r);
+                const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, (int)r);
+                if (lane < k_r) wown[q] = read_word[so_r + lane];
+            }
+        }
 #pragma unroll
-        for (uint32_t q = 0; q < WIN_OWN; q++)
-            if (wv + q * NW < my_k) stage_mask(wown[q]);
-        for (uint32_t j = wv + WIN_OWN * NW; j < my_k; j += NW) stage_mask(read_word[so + j]);
-        wacc[lane] = c_win;                      // (this wave's accumulators: cleared again below)
+        for (uint32_t q = 0; q < WIN_OWN; q++) {
+            const uint32_t r = wv + q * NW;
+            if (r >= nr) continue;
+            const uint32_t so_r = (uint32_t)__builtin_amdgcn_readlane((int)so, (int)r);
+            const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, (int)r);
+            uint32_t cnt_r = 0;
+            for (uint32_t j0 = 0; j0 < k_r; j0 += 64) {
+                const bool on = j0 + lane < k_r;
+                const uint32_t sw = j0 == 0 ? wown[q] : (on ? read_word[so_r + j0 + lane] : NONE);
+                const uint32_t rel = w_pos(sw) - win_lo;
+                if (on && rel < WIN_SIZE) atomicOr(&tm32[2 * rel + (r >> 5)], 1u << (r & 31));
+                cnt_r += (uint32_t)__popcll(__ballot(on && !rw_missing(sw) && (rw_mut(sw) & rw_ref(sw)) == 0));
+            }
+            if (lane == 0) cacc[r] = (int)cnt_r;
+        }
         __syncthreads();
-        c_win = 0;
-        for (uint32_t w2 = 0; w2 < NW; w2++)
-            c_win += reinterpret_cast<const int*>(reinterpret_cast<const uint4*>(tstart + WIN_TAB) + w2 * (WIN_WAVE_BYTES / 16) + 64)[lane];
+        c_win = have ? cacc[lane] : 0;
         // tstart = exclusive prefix sum of the masks' populations (consecutive positions per thread)
         constexpr uint32_t PER = (WIN_SIZE + 64 * NW - 1) / (64 * NW);
         const uint32_t i0 = threadIdx.x * PER;
@@ -607,7 +620,7 @@ __device__ __forceinline__ void sweep_tile(
         }
         if (lane == 63) wscan[wv] = inc;
         __syncthreads();
-        wacc[lane] = 0;                          // (every wave has read the parts of c by now)
+        if (wv == 0) wacc[lane] = 0;             // (every wave has read its reads' c by now)
         uint32_t run = inc - mine;
         for (uint32_t w2 = 0; w2 < wv; w2++) run += wscan[w2];
         for (uint32_t i = i0; i < min(i0 + PER, WIN_SIZE); i++) {
@@ -615,15 +628,21 @@ __device__ __forceinline__ void sweep_tile(
             run += (uint32_t)__popcll(tmask[i]);
         }
         __syncthreads();
-        auto stage_word = [&](uint32_t w) {
-            const uint32_t rel = w_pos(w) - win_lo;
-            // (the copy keeps the allele fields; its position bits name the read's lane)
-            if (rel < WIN_SIZE) sval[tstart[rel] + (uint32_t)__popcll(tmask[rel] & ((1ull << lane) - 1ull))] = (w & 0xFFF00000u) | lane;
-        };
 #pragma unroll
-        for (uint32_t q = 0; q < WIN_OWN; q++)
-            if (wv + q * NW < my_k) stage_word(wown[q]);
-        for (uint32_t j = wv + WIN_OWN * NW; j < my_k; j += NW) stage_word(read_word[so + j]);
+        for (uint32_t q = 0; q < WIN_OWN; q++) {
+            const uint32_t r = wv + q * NW;
+            if (r >= nr) continue;
+            const uint32_t so_r = (uint32_t)__builtin_amdgcn_readlane((int)so, (int)r);
+            const uint32_t k_r = (uint32_t)__builtin_amdgcn_readlane((int)my_k, (int)r);
+            const unsigned long long below_r = (1ull << r) - 1ull;
+            for (uint32_t j0 = 0; j0 < k_r; j0 += 64) {
+                const bool on = j0 + lane < k_r;
+                const uint32_t w = j0 == 0 ? wown[q] : (on ? read_word[so_r + j0 + lane] : NONE);
+                const uint32_t rel = w_pos(w) - win_lo;
+                // (the copy keeps the allele fields; its position bits name the read's lane)
+                if (on && rel < WIN_SIZE) sval[tstart[rel] + (uint32_t)__popcll(tmask[rel] & below_r)] = (w & 0xFFF00000u) | r;
+            }
+        }
     } else if (wv == 0) {
         auto stage = [&](uint32_t j, uint32_t w) {
             const uint32_t p = w_pos(w);
