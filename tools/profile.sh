@@ -44,5 +44,5 @@ if [ -n "${PROFILE_EXTRA:-}" ]; then
   done
 fi
 # keep only the small summaries (stats + per-kernel counter rows of our kernels)
-find "$OUT" -name "*.csv" -size +2M -exec sh -c 'head -400 "$1" > "$1.head"; rm "$1"' _ {} \;
+find "$OUT" -name "*.csv" -size +12M -exec sh -c 'head -400 "$1" > "$1.head"; rm "$1"' _ {} \;
 du -sh "$OUT"

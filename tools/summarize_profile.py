@@ -34,6 +34,8 @@ def main(src, name, mode):
         try:
             b = json.load(open(bt))
             steps = b["steps"] + b["warmup"] + 1      # (+ the untimed step that reports batch 0's routing)
+            if b["config"].get("setup_places_every_batch_once"):
+                steps += b["config"]["distinct_batches_in_rotation"]     # (+ bench.py's set-up pass over the rotation)
             summ["reads_per_step"] = b["config"]["reads_per_gpu"]
             summ["bench_under_trace"] = {k: b[k] for k in ("value", "ms_per_step")}
             summ["bench_under_trace"]["kernel_ms_per_step"] = b["roofline"]["kernel_ms_per_step"]
