@@ -577,7 +577,7 @@ def test_full_size_nrich_and_long_shard():
     the exactly-8-entries batch on the 16 M-node MAT (chunked walks of both classes, start states by bisection,
     per-entry pre-test bytes at the PRODUCT's threshold: the child process does not inherit this suite's
     WEPP_IX_PRE_MIN_NODES=0), >= 5 000 reads of each against the incremental checker with every (class, stream)
-    plan covered; then configs[4] at its per-GPU shard size, 125 000 reads of 1.2 kb: every 250th read against the
+    plan covered; then configs[4] at its per-GPU shard size, 125 000 reads of 1.2 kb: every 25th read against the
     checker, two half batches = the whole, tile-size invariance.  tests/nrich_full_size.py does the work."""
     import subprocess
     import sys
@@ -587,7 +587,7 @@ def test_full_size_nrich_and_long_shard():
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
     rep = json.loads(run.stdout.strip().splitlines()[-1])
     assert rep["nodes"] == 16_000_000 and {"walk8", "walk16"} <= set(rep["classes_seen"])
-    assert all(b["checked"] >= 5000 for b in rep["batches"]) and rep["long_reads"]["checked"] >= 500
+    assert all(b["checked"] >= 5000 for b in rep["batches"]) and rep["long_reads"]["checked"] >= 5000
     assert rep["long_reads"]["window_plan_share"] > 0.9
     print("full-size N-rich / long-shard report:", json.dumps(rep))
 
