@@ -594,9 +594,10 @@ def test_full_size_nrich_and_long_shard():
 
 def test_window_crowns_walks_and_sweeps_vs_oracle(oracle):
     """Window crowns (include/wepp_place.h: wepp_mat_last_crowns): reads confined to a genome window are placed on the
-    crown of their window that their ROOT score admits -- by a walk when they list at most 16 positions, by a one-wave
-    sweep of the crown when they list more (N-rich reads: 10 % and 20 % N) -- with the oracle's results; with the walks
-    off every such read sweeps its crown; with work skipping off none does.  Crowns of several levels are reached."""
+    crown of their window that their ROOT score admits -- by a walk when they list at most 16 positions, by a sweep of
+    the crown of their own when they list 17-32 (k_sweep_arena), in tiles on the window's candidates when they list more
+    (N-rich reads: 10 % and 20 % N) -- with the oracle's results; with the walks off every read of a crown sweeps it;
+    with work skipping off none does.  Crowns of several levels are reached."""
     g = w.generate_tree(81, 150_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
     batches = [g.reads(82, 3000, p_substitution=0.004, p_n=0.02, p_iupac=0.1), g.reads(83, 1500, p_n=0.10),
                g.reads(84, 1500, p_substitution=0.01, p_n=0.20)]
