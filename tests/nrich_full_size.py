@@ -111,6 +111,20 @@ def main():
         assert (getattr(r16, f) == getattr(rl, f)[: sub.n_reads]).all(), ("tile size", f)
     out["long_reads"] = {"n_reads": lr.n_reads, "checked": int(len(every)), "checker_s": round(time.perf_counter() - t1, 1),
                          "window_plan_share": float((lcls == w.PLAN_WIN).mean()), "mean_entries": float(lr.read_off[-1]) / lr.n_reads}
+    # best_j_vec of long reads (wepp_best_nodes): listed on the window's candidates -- on the whole tree, the only
+    # tree-wide stream a root score of ~36 admits, 20 000 reads x 16 M nodes would take minutes
+    sub = lr.slice(0, min(20000, lr.n_reads))
+    rs = mat.place_batch(sub)
+    t1 = time.perf_counter()
+    vec = mat.best_nodes(sub, rs)
+    dt = time.perf_counter() - t1
+    for q in range(0, sub.n_reads, 100):
+        want = inc.place_sample(*sub.entries(q), want_best_vec=True)["best_j_vec"]
+        if vec[q].tolist() != want.tolist():
+            raise SystemExit(f"best_j_vec of long read {q}: {vec[q].tolist()[:8]} vs {want.tolist()[:8]}")
+    out["long_reads"]["best_nodes"] = {"reads": sub.n_reads, "seconds": round(dt, 3), "checked": len(range(0, sub.n_reads, 100)),
+                                       "nodes_listed": int(sum(len(v) for v in vec))}
+    assert dt < 10.0 or n_nodes < 1_000_000, dt
     inc.close()
     ot.close()
     mat.close()

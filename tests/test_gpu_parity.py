@@ -718,8 +718,9 @@ def test_two_handles_two_host_threads(oracle):
 
 def test_best_nodes_vs_oracle(oracle):
     """best_j_vec (usher_common.cpp:376-381, filled at usher_mapper.cpp:475-476,497): the BFS indices of all optimal
-    nodes of a sample, against the oracle's vector -- every (tree, sample) pair of the fuzz trees, then 1 000 reads
-    on a 100 K-node tree (reads of every routed stream, short and 1.2 kb) with work skipping on and off."""
+    nodes of a sample, against the oracle's vector -- every (tree, sample) pair of the fuzz trees, then 1 200 reads
+    on a 100 K-node tree (reads of every routed stream, short, N-rich and 1.2 kb: the last two list their nodes on their
+    genome window's candidates) with work skipping on and off."""
     rng = np.random.default_rng(808)
     n_nodes = 0
     for it in range(30):
@@ -741,8 +742,10 @@ def test_best_nodes_vs_oracle(oracle):
     g = w.generate_tree(71, 100_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
     short = g.reads(72, 900, p_substitution=0.004, p_n=0.02, p_iupac=0.1)
     long_ = g.reads(73, 100, read_len=1200, amplicon_len=1200, amplicon_step=1020, p_substitution=0.03, p_n=0.02)
-    reads = Reads(np.concatenate([short.read_off, long_.read_off[1:] + short.read_off[-1]]),
-                  np.concatenate([short.read_word, long_.read_word]))
+    nrich = g.reads(74, 200, p_substitution=0.01, p_n=0.15)       # (a window's candidates are the smaller stream for these)
+    reads = Reads(np.concatenate([short.read_off, long_.read_off[1:] + short.read_off[-1],
+                                  nrich.read_off[1:] + short.read_off[-1] + long_.read_off[-1]]),
+                  np.concatenate([short.read_word, long_.read_word, nrich.read_word]))
     mat = w.Mat(g.tree)
     inc = oracle.OracleTree(g.tree).incremental()
     res = mat.place_batch(reads)

@@ -1415,27 +1415,32 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     uint32_t* d_jobs = (uint32_t*)q; q += b_r;
     uint32_t* d_nodes = (uint32_t*)q;
     HIP_TRY(hipMemsetAsync(d_cursor, 0, (size_t)n_reads * 4, nullptr));
-    // the stream of every read: the routing of a placement call with the walks and the window streams off (a
-    // window stream folds runs of nodes into pseudo-nodes: nothing to list there)
+    // the stream of every read: the routing of a placement call with the walks off.  A read inside one genome window
+    // lists its nodes on the window's stream when that is the window's candidate crown (real nodes only, a few
+    // thousand of them whatever the read's root score: device_mat.hpp win_n) and smaller than the tree-wide stream of
+    // its theta; a whole-tree window stream folds runs of nodes into pseudo-nodes: nothing to list there
     DevMAT dm = mat->dev;
-    dm.n_windows = 0;
-    dm.wc_windows = 0;            // (and no window crowns: the list is made on the tree-wide streams)
+    dm.wc_windows = 0;            // (no per-read window crowns: k_scores takes one stream per launch)
     uint32_t* tier_info = mat->lane[0].d_info + mat->lane[0].info_idx * TI_WORDS;
     uint32_t* tier_info_next = mat->lane[0].d_info + (mat->lane[0].info_idx ^ 1u) * TI_WORDS;
     uint32_t* blk_counts = mat->lane[0].d_info + 2 * TI_WORDS;
-    HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
+    HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns ? 3 : 0, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
                          d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, nullptr));
     mat->lane[0].info_idx ^= 1u;
     HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
     HIP_TRY(hipMemcpy(mat->lane[0].h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const uint32_t* info = mat->lane[0].h_info;
+    static const bool debug_plans = getenv("WEPP_DEBUG_PLANS") != nullptr;
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
-        if (plan_class(id) != PLAN_SWEEP || plan_index(id) >= mat->streams.size())
+        const bool win = plan_class(id) == PLAN_WIN;
+        if (win ? (plan_index(id) >= mat->wstreams.size() || mat->wstreams[plan_index(id)].ncnt != nullptr)
+                : (plan_class(id) != PLAN_SWEEP || plan_index(id) >= mat->streams.size()))
             return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
-        HIP_TRY(launch_best_nodes(mat->dev, mat->streams[plan_index(id)], d_off, d_word, d_list + info[TI_OFF + id], count, d_best,
-                                  d_o64, d_cursor, d_nodes, nullptr));
+        if (debug_plans) fprintf(stderr, "[best_nodes] %s %u: %u reads\n", win ? "window" : "stream", plan_index(id), count);
+        HIP_TRY(launch_best_nodes(mat->dev, win ? mat->wstreams[plan_index(id)] : mat->streams[plan_index(id)], d_off, d_word,
+                                  d_list + info[TI_OFF + id], count, d_best, d_o64, d_cursor, d_nodes, nullptr));
     }
     {
         hipError_t e = hipMemcpy(hp, d_nodes, total * 4, hipMemcpyDeviceToHost);

@@ -322,8 +322,11 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 atomicMax(&open_of[small ? 2 : 3], open_max);
             }
         }
+        // (use_crowns & 2 -- wepp_best_nodes, which lists nodes and so takes streams of real nodes only: every read
+        // inside a window whose stream is the window's candidate crown takes it when it is the smaller one)
         if (cls == PLAN_SWEEP && in_win && wi < m.n_windows &&
-            (k > WIN_MIN_ENTRIES ? (m.win_n[wi] < m.walks[t].n || t + 1 == m.n_streams) : (sid == NONE && t + 1 == m.n_streams))) {
+            ((use_crowns & 2) ? m.win_n[wi] < m.walks[t].n
+                              : k > WIN_MIN_ENTRIES ? (m.win_n[wi] < m.walks[t].n || t + 1 == m.n_streams) : (sid == NONE && t + 1 == m.n_streams))) {
             // many entries, all inside one genome window: a tile of such reads sweeps the window's stream -- the window's
             // candidates (a crown of a few thousand nodes, whatever the root score) or, for the reads no crown serves,
             // the whole tree as the window sees it
@@ -1250,8 +1253,8 @@ __global__ __launch_bounds__(DENSE ? 64 * DENSE_WAVES : 64) void k_sweep(
 }
 
 // the reads that cannot walk (more than WALK16_K entries, or too many open intervals) but lie inside one genome
-// window and have a low root score: one wave per read sweeps the read's WINDOW CROWN (wsid: a few hundred to a few
-// hundred thousand nodes) instead of a 64-read tile sweeping the tree-wide stream of theta = root score + |S|
+// window: waves of its own (ARENA_CHUNKS per read) sweep the read's WINDOW CROWN (wsid: a few hundred to a few ten
+// thousand nodes) instead of a 64-read tile sweeping the tree-wide stream of theta = root score + |S|
 __global__ __launch_bounds__(64) void k_sweep_arena(const DevStream* __restrict__ wc_streams, const uint32_t* __restrict__ wsid,
                                                     uint32_t bm_words, uint32_t max_pos, uint32_t ent_cap,
                                                     const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
