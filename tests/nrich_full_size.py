@@ -86,6 +86,14 @@ def main():
             plans[f"{w.PLAN_NAMES[k // 1024]}:{(k // 16) % 64}" + (f".{k % 16}" if (k // 16) % 64 == w.WINDOW_CROWN_SLOT else "")] = \
                 [int(members.sum()), int((checked & members).sum())]
         classes_seen |= set(np.unique(pcls).tolist())
+        # the whole batch against the placement without work skipping (whole-tree sweeps), all four result arrays
+        mat.set_use_crowns(False)
+        mat.set_use_walk(False)
+        r0 = mat.place_batch(rd)
+        mat.set_use_crowns(True)
+        mat.set_use_walk(True)
+        for f in ("score", "best_bfs_j", "num_best", "flags"):
+            assert (getattr(r0, f) == getattr(res, f)).all(), (label, "work skipping on / off", f)
         out["batches"].append({"reads": label, "n_reads": rd.n_reads, "checked": int(len(pick)),
                                "checker_s": round(time.perf_counter() - t1, 1), "plans_total_checked": plans})
     if n_nodes >= 1_000_000:
@@ -99,6 +107,15 @@ def main():
     every = np.arange(0, lr.n_reads, 25)          # (5 000 of the shard's 125 000: the incremental checker takes seconds)
     t1 = time.perf_counter()
     same(rl, every, inc.place_batch(gather(lr, every), nthreads=nthr), "1.2 kb shard")
+    # ... and the WHOLE shard against the placement without any work skipping (every read sweeps the whole tree: no
+    # crowns, no window candidates, no walks), all four result arrays
+    mat.set_use_crowns(False)
+    mat.set_use_walk(False)
+    r0 = mat.place_batch(lr)
+    mat.set_use_crowns(True)
+    mat.set_use_walk(True)
+    for f in ("score", "best_bfs_j", "num_best", "flags"):
+        assert (getattr(r0, f) == getattr(rl, f)).all(), ("long shard, work skipping on / off", f)
     half = lr.n_reads // 2
     ra, rb = mat.place_batch(lr.slice(0, half)), mat.place_batch(lr.slice(half, lr.n_reads))
     for f in ("score", "best_bfs_j", "num_best", "flags"):
@@ -109,7 +126,7 @@ def main():
     mat.set_tile_reads(64)
     for f in ("score", "best_bfs_j", "num_best", "flags"):
         assert (getattr(r16, f) == getattr(rl, f)[: sub.n_reads]).all(), ("tile size", f)
-    out["long_reads"] = {"n_reads": lr.n_reads, "checked": int(len(every)), "checker_s": round(time.perf_counter() - t1, 1),
+    out["long_reads"] = {"n_reads": lr.n_reads, "whole_shard_equals_no_work_skipping": True, "checked": int(len(every)), "checker_s": round(time.perf_counter() - t1, 1),
                          "window_plan_share": float((lcls == w.PLAN_WIN).mean()), "mean_entries": float(lr.read_off[-1]) / lr.n_reads}
     # best_j_vec of long reads (wepp_best_nodes): listed on the window's candidates -- on the whole tree, the only
     # tree-wide stream a root score of ~36 admits, 20 000 reads x 16 M nodes would take minutes
