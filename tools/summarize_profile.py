@@ -3,7 +3,10 @@
 placement kernels + kernel-trace durations) and refreshes profiles/pmc_counters.json, which bench.py reads for
 its roofline objects (keyed by workload mode and by the hash of the kernel sources the profile was taken on).
 
-    python tools/summarize_profile.py gpurun_out/prof_<tag> <name> <mode: short_reads|whole_tree|long_reads>
+    python tools/summarize_profile.py gpurun_out/prof_<tag> <name> <mode: short_reads|whole_tree|long_reads|probe>
+
+(mode probe: a tools/walk_probe.py leg profiled with PROFILE_PROG; PROFILE_STEPS = placements in the run; not entered into
+pmc_counters.json)
 
 profiles/pmc_counters.json is keyed "<mode>:<reads per step>" (+ the kernel hash inside the entry): bench.py quotes a
 profile only for the workload, the batch size and the build it was taken on.
@@ -28,9 +31,11 @@ def main(src, name, mode):
     out_dir = os.path.join("profiles", name)
     os.makedirs(out_dir, exist_ok=True)
     summ = {"source": src, "mode": mode, "kernel_hash": kernel_hash()}
-    steps = 3
+    steps = int(os.environ.get("PROFILE_STEPS", "3"))     # (a probe leg, tools/walk_probe.py: 1 + PROBE_STEPS placements)
     bt = os.path.join(src, "bench_trace.json")
-    if os.path.exists(bt):
+    if mode.startswith("probe"):
+        summ["probe_under_trace"] = open(bt).read().strip().splitlines()[-1] if os.path.exists(bt) else None
+    elif os.path.exists(bt):
         try:
             b = json.load(open(bt))
             steps = b["steps"] + b["warmup"] + 1      # (+ the untimed step that reports batch 0's routing)
@@ -90,6 +95,9 @@ def main(src, name, mode):
         entry["cache_lines_per_vmem_read_inst"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"]
     summ["entry"] = entry
     json.dump(summ, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
+    if mode.startswith("probe"):              # (a probe leg is not a bench workload: nothing for bench.py to quote)
+        print(json.dumps(entry, indent=1))
+        return
     tp = os.path.join("profiles", "pmc_counters.json")
     t = json.load(open(tp)) if os.path.exists(tp) else {}
     t[f"{mode}:{summ.get('reads_per_step', 0)}"] = entry
