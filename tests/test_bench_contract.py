@@ -1,0 +1,61 @@
+"""The bench line's contract (the round's task statement, section 4): the committed lines under profiles/ -- what
+`python bench.py` printed on the GPU box for this build -- carry every field in the shape the driver and the judge read;
+`bench.py` itself defaults to one GPU and a short run.  (No GPU needed: the lines are data.)"""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINES = ["r3_bench_default.json", "r3_bench_config3_shard.json", "r3_bench_long_reads.json", "r3_bench_whole_tree.json"]
+
+
+@pytest.mark.parametrize("name", LINES)
+def test_committed_bench_line_has_the_contract_shape(name):
+    with open(os.path.join(ROOT, "profiles", name)) as fh:
+        text = fh.read().strip()
+    assert len(text.splitlines()) == 1                      # ONE JSON line
+    d = json.loads(text)
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        base = json.load(fh)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "reads/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["n_gpus"] == 1
+    assert d["vs_baseline"] is None                         # BASELINE.md holds no published number for this metric
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert str(base.get("metric", d["metric"]))[:12].lower() in d["metric"].lower() or "reads" in d["metric"]
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["reads_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port")
+    assert c["sample_matches_gpu"] is True and c["incremental"]["sample_matches_gpu"] is True
+    # the counters a line quotes were taken on the build the line was measured on
+    if r["traffic"] is not None:
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as fh:
+            pmc = json.load(fh)
+        assert any(e["kernel_hash"] == d["config"]["kernel_hash"] for e in pmc.values())
+
+
+def test_bench_defaults_to_one_gpu_and_a_short_run():
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_for_contract", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.gpus == 1 and 1 <= a.steps <= 100 and 0 <= a.warmup <= 10
+    # counters of the three bench workloads are committed (bench.py quotes them only for the build they were taken
+    # on -- kernel hash inside -- and prints null otherwise: a stale table is not an error, just not evidence)
+    with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as fh:
+        pmc = json.load(fh)
+    assert {"short_reads:1000000", "whole_tree:1000000", "long_reads:200000"} <= set(pmc)
+    assert all(len(e["kernel_hash"]) == len(bench.kernel_hash()) for e in pmc.values())
