@@ -111,6 +111,14 @@ typedef struct {
     uint32_t n_window_streams;
     uint32_t n_window_streams_crown;
     uint64_t window_stream_nodes;
+    /* genome windows: WIN_SIZE positions every WIN_STRIDE (flatmat.hpp; 2560 / 1024 in the product build), at most 32
+     * of them: positions from 32 * stride on lie in no window -- window_uncovered_positions of the tree's mutated
+     * positions -- and reads there take the tree-wide streams (a SARS-CoV-2 or RSV genome has none) */
+    uint32_t window_size, window_stride, window_uncovered_positions;
+    /* seed signatures (wepp_mat_set_use_seeds): chunks of the whole-tree stream, blocks per chunk, bytes of the
+     * (position x chunk) nibble table; 0 when none was built (genomes beyond 2^18 positions, tables beyond 1 GB) */
+    uint32_t seed_chunks, seed_chunk_blocks;
+    uint64_t seed_sig_bytes;
 } wepp_mat_stats;
 
 /* Per-read result flags (out parameter `flags`). */
@@ -224,6 +232,22 @@ int wepp_mat_set_use_crowns(wepp_mat_t *mat, int enable);
  * stack packs a subtree end into 25 bits; such a tree is placed by sweeps). */
 int wepp_mat_set_use_walk(wepp_mat_t *mat, int enable);
 
+/* Seeded placement of whole-genome samples on (default) / off.  A sample that lists more positions than a walk takes
+ * and fits no genome window -- what read_vcf makes of a consensus genome, src/mutation_annotated_tree.cpp:2033-2130 --
+ * is placed by a workgroup of its own: for every chunk (about a thousand nodes) of the whole-tree stream it counts how
+ * many of the sample's reference-excluding alleles the chunk's signature -- the alleles carried by the chunk's nodes
+ * and the ancestors of its first node -- could serve; a node of the chunk scores at least (such entries) - (count),
+ * so only the chunks whose bound reaches the best score found so far are evaluated, node by node, exactly
+ * (wepp_amd/csrc/seed_kernels.hip).  Off: such samples share tile sweeps of the whole-tree stream.  Affects speed
+ * only, never results. */
+int wepp_mat_set_use_seeds(wepp_mat_t *mat, int enable);
+/* Diagnostic: samples seeded by the handle since wepp_mat_timing_reset(), the chunks they evaluated, the chunks they
+ * could have evaluated (samples x wepp_mat_stats::seed_chunks), the most chunks one sample evaluated, and the samples
+ * by chunks evaluated (histogram8: <= 1, <= 4, <= 16, <= 64, <= 256, <= 1024, <= 4096, more).  Any pointer may be
+ * NULL.  Synchronises the device. */
+int wepp_mat_last_seeds(wepp_mat_t *mat, uint64_t *samples, uint64_t *chunks_evaluated, uint64_t *chunks_total,
+                        uint64_t *most_per_sample, uint64_t *histogram8);
+
 /* Tuning knob: sub-batches wepp_place_batch cuts a batch of 65 536 reads or more into (1..8; 0 = default:
  * 4 from 262 144 reads, 2 below).  Affects speed only, never results. */
 int wepp_mat_set_pipeline(wepp_mat_t *mat, uint32_t sub_batches);
@@ -259,6 +283,7 @@ int wepp_mat_last_tiers(wepp_mat_t *mat, uint8_t *tiers, uint32_t n_reads);
 #define WEPP_PLAN_WALKC8  3   /* walk cut into jobs (many events), up to 8 positions       */
 #define WEPP_PLAN_WALKC16 4   /* walk cut into jobs, up to 16 positions                    */
 #define WEPP_PLAN_WIN     5   /* tile sweep of a genome window's stream (reads with more than 32 entries inside one window) */
+#define WEPP_PLAN_SEED    6   /* whole-genome sample: chunk signatures, then exact evaluation of the chunks left (plan_stream 0) */
 int wepp_mat_last_plans(wepp_mat_t *mat, uint8_t *plan_class, uint8_t *plan_stream, uint32_t n_reads);
 /* plan_stream == WEPP_WINDOW_CROWN_SLOT with a class other than WEPP_PLAN_WIN: the read walked (or, class
  * WEPP_PLAN_SWEEP, swept alone) a WINDOW CROWN -- of the nodes a read confined to its genome window can be placed on at
@@ -417,7 +442,8 @@ int wepp_epp_last_timing(double *select_ms, double *sweep1_ms, double *sweep2_ms
  * Lets the CPU test-suite check the flattener (orders, parent alleles, per-node
  * constants, event stream) against the oracle.  `name` is one of: node_woff,
  * words, nkey, nstat, rank2dfs, dfs2bfs, bfs2id, dfs2id, parent_dfs, dfs_end,
- * num_leaves, blk_node0, blk_eoff, blk_sum, ev_word, ev_meta, ev_lb, cp_off, cp_word.
+ * num_leaves, blk_node0, blk_eoff, blk_sum, ev_word, ev_meta, ev_lb, cp_off, cp_word, seed_sig (the signature
+ * table: rows of wepp_mat_stats::seed_chunks nibbles, 8 to a dword, padded to 16 bytes).
  * Stream fields (nkey, nstat, blk_*, ev_*, cp_*) take an optional "<i>:" prefix
  * selecting sweep stream i (default: the whole-tree stream).
  * The returned pointer is borrowed from the handle; *elem_bytes is the element

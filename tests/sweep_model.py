@@ -1,4 +1,4 @@
-"""Pure-Python model of the GPU sweep (wepp_amd/csrc/place_kernels.hip) over
+"""Pure-Python model of the GPU sweep (wepp_amd/csrc/sweep_kernels.hip) over
 the flattened MAT, used by the CPU test-suite to check the flattener and the
 closed form against the oracle when no GPU is present.  It is NOT a product
 path (nothing in wepp_amd imports it) and it is only usable on small trees.
@@ -225,7 +225,7 @@ class FlatModel:
 
 def theta(flat, S):
     """score(root) + |S|: no node whose static score exceeds it can win or tie
-    (k_route in place_kernels.hip)."""
+    (k_route in route_kernels.hip)."""
     words, woff = flat.get("words"), flat.get("node_woff")
     root_base = int(flat.get("nkey")[0]) >> 32
     Sd = {s[0]: s for s in S}

@@ -1,4 +1,4 @@
-"""Pure-Python model of the per-read walk (k_walk in wepp_amd/csrc/place_kernels.hip): a read visits only
+"""Pure-Python model of the per-read walk (k_walk in wepp_amd/csrc/walk_kernels.hip): a read visits only
 the events of the positions it lists -- taken from the stream's position index in stream order -- and
 answers everything between two events with a range query over the statically eligible nodes (sparse table
 for "can anything in there matter", segment tree for the exact (score, rank, count)).  Used by the CPU

@@ -68,6 +68,12 @@ class MatStats(ctypes.Structure):
         ("n_window_streams", ctypes.c_uint32),
         ("n_window_streams_crown", ctypes.c_uint32),
         ("window_stream_nodes", ctypes.c_uint64),
+        ("window_size", ctypes.c_uint32),
+        ("window_stride", ctypes.c_uint32),
+        ("window_uncovered_positions", ctypes.c_uint32),
+        ("seed_chunks", ctypes.c_uint32),
+        ("seed_chunk_blocks", ctypes.c_uint32),
+        ("seed_sig_bytes", ctypes.c_uint64),
     ]
 
 
@@ -130,6 +136,8 @@ _SIGS = {
     "wepp_mat_set_use_crowns": (ctypes.c_int, [_V, ctypes.c_int]),
     "wepp_mat_set_use_walk": (ctypes.c_int, [_V, ctypes.c_int]),
     "wepp_mat_set_pipeline": (ctypes.c_int, [_V, ctypes.c_uint32]),
+    "wepp_mat_set_use_seeds": (ctypes.c_int, [_V, ctypes.c_int]),
+    "wepp_mat_last_seeds": (ctypes.c_int, [_V] + [ctypes.POINTER(ctypes.c_uint64)] * 4 + [_V]),
     "wepp_mat_last_tiers": (ctypes.c_int, [_V, _V, ctypes.c_uint32]),
     "wepp_mat_last_plans": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32]),
     "wepp_mat_last_crowns": (ctypes.c_int, [_V, _V, _V, ctypes.c_uint32]),

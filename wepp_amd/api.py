@@ -377,6 +377,20 @@ class Mat:
         """Per-read walks on (default) / off (every read placed by a sweep); speed only, never results."""
         check(lib.wepp_mat_set_use_walk(self._h, 1 if enable else 0))
 
+    def set_use_seeds(self, enable):
+        """Whole-genome samples by chunk signatures (default) or by tile sweeps; speed only, never results."""
+        check(lib.wepp_mat_set_use_seeds(self._h, 1 if enable else 0))
+
+    def last_seeds(self, detail=False):
+        """(samples seeded, chunks evaluated, chunks in all) since the last timing reset; detail=True adds the most
+        chunks one sample evaluated and the samples by chunks evaluated (<= 1, 4, 16, 64, 256, 1024, 4096, more)."""
+        a, b, c, d = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        hist = np.zeros(8, np.uint64)
+        check(lib.wepp_mat_last_seeds(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d), _ptr(hist)))
+        if detail:
+            return a.value, b.value, c.value, d.value, hist.tolist()
+        return a.value, b.value, c.value
+
     def set_pipeline(self, sub_batches):
         """Sub-batches place_batch cuts a large batch into (0 = default); speed only, never results."""
         check(lib.wepp_mat_set_pipeline(self._h, int(sub_batches)))

@@ -99,7 +99,8 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
     while (d.bm_words < (f.max_pos >> 5) + 1) d.bm_words <<= 1;   // power of two (k_sweep masks the index)
     d.n_streams = (uint32_t)f.streams.size();
     d.root_base = f.root_base;
-    d.walk_eager_nodes = getenv("WEPP_WALK_EAGER_NODES") ? (uint32_t)atoll(getenv("WEPP_WALK_EAGER_NODES")) : WALK_EAGER_MAX_NODES;
+    h->tun = PlaceTunables::from_env();
+    d.walk_eager_nodes = h->tun.walk_eager_nodes;
     int rc;
 #define UP(dst, vec) if ((rc = upload(h, vec, &dst)) != WEPP_OK) { release(h); return rc; }
     // (inside up_stream a failure returns the code; the caller releases the handle)
@@ -139,7 +140,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
     };
     for (size_t i = 0; i < f.wstreams.size(); i++) {
         DevStream ds;
-        if ((rc = up_stream(f.wstreams[i], (uint32_t)(f.streams.size() - 1), getenv("WEPP_WIN_EAGER") ? atoi(getenv("WEPP_WIN_EAGER")) != 0 : true, ds)) != WEPP_OK) return rc;
+        if ((rc = up_stream(f.wstreams[i], (uint32_t)(f.streams.size() - 1), h->tun.win_eager, ds)) != WEPP_OK) return rc;
         h->wstreams.push_back(ds);
         h->wstream_bytes.push_back(f.wstreams[i].stream_bytes());
         if (i < MAX_WINDOWS) d.win_n[i] = f.wstreams[i].ncnt.empty() ? f.wstreams[i].n : 0xFFFFFFFFu;   // (pseudo-nodes: the whole tree)
@@ -273,9 +274,25 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         h->walks[WC_SLOT] = arena;
     }
     UP(d.walks, h->walks)
+    // seed signatures (flatmat.hpp): whole-genome samples
+    d.seed_sig = nullptr;
+    d.seed_stride = d.seed_chunks = d.seed_row_words = 0;
+    if (!f.seed_sig.empty()) {
+        UP(d.seed_sig, f.seed_sig)
+        d.seed_stride = f.seed_stride;
+        d.seed_chunks = f.seed_chunks;
+        d.seed_row_words = f.seed_row_words;
+    }
+    h->use_seeds = h->tun.seed ? 1 : 0;
+    h->stats.seed_chunks = d.seed_chunks;
+    h->stats.seed_chunk_blocks = d.seed_stride;
+    h->stats.seed_sig_bytes = (uint64_t)f.seed_sig.size() * 4;
+    h->stats.window_size = WIN_SIZE;
+    h->stats.window_stride = WIN_STRIDE;
+    h->stats.window_uncovered_positions = f.max_pos + 1 > MAX_WINDOWS * WIN_STRIDE ? f.max_pos + 1 - MAX_WINDOWS * WIN_STRIDE : 0;
 #undef UP
     {
-        static const bool walk_on = !(getenv("WEPP_WALK") && getenv("WEPP_WALK")[0] == '0');
+        const bool walk_on = h->tun.walk;
         // k_walk keeps an open interval as (subtree end << WALK_DELTA_BITS) | delta in one dword: a stream of
         // 2^(32 - WALK_DELTA_BITS) nodes or more is left to the sweeps (device_mat.hpp)
         h->walk_ok = 1;
@@ -284,8 +301,8 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         h->use_walk = (walk_on && h->walk_ok) ? 1 : 0;
     }
     // (two arrays of WALK_COUNTERS slots: loop iterations of the walks' waves, bytes their lanes asked memory for)
-    e = hipMalloc((void**)&h->d_work, 2 * WALK_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->d_work, 0, 2 * WALK_COUNTERS * sizeof(unsigned long long));
+    e = hipMalloc((void**)&h->d_work, wepp_mat::D_WORK_BYTES);
+    if (e == hipSuccess) e = hipMemset(h->d_work, 0, wepp_mat::D_WORK_BYTES);
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     for (PlaceLane& L : h->lane) {
         if (e == hipSuccess) e = hipMalloc((void**)&L.d_info, (2 * TI_WORDS + ROUTE_BLOCKS * MAX_PLANS) * sizeof(uint32_t));
@@ -302,6 +319,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
     if (e == hipSuccess) e = sweep_set_max_lds(160 * 1024);
+    if (e == hipSuccess) e = seed_set_max_lds(160 * 1024);
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     *out = h;
     return WEPP_OK;
@@ -360,6 +378,12 @@ extern "C" int wepp_mat_set_use_crowns(wepp_mat_t* mat, int enable) {
     return WEPP_OK;
 }
 
+extern "C" int wepp_mat_set_use_seeds(wepp_mat_t* mat, int enable) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    mat->use_seeds = enable ? 1 : 0;
+    return WEPP_OK;
+}
+
 extern "C" int wepp_mat_set_pipeline(wepp_mat_t* mat, uint32_t sub_batches) {
     if (!mat) return set_error(WEPP_EINVAL, "null argument");
     if (sub_batches > wepp_mat::kPipeMax) return set_error(WEPP_EINVAL, "at most 8 sub-batches");
@@ -413,8 +437,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     };
     const size_t tier_bytes = 0;       // (the plan ids live in mat->d_plan_of)
     const size_t list_bytes = (((size_t)n_reads * 4) + 255) & ~(size_t)255;
-    // WEPP_SORT_READS=0 (A/B aid): keep the caller's read order on the whole-tree stream too
-    static const bool sort_reads = !(getenv("WEPP_SORT_READS") && getenv("WEPP_SORT_READS")[0] == '0');
+    const PlaceTunables& tun = mat->tun;
+    const bool sort_reads = tun.sort_reads;   // (WEPP_SORT_READS=0, an A/B aid: keep the caller's read order on the whole-tree stream too)
     size_t sort_temp = 0;
     if (sort_reads) HIP_TRY(sort_reads_temp_bytes(n_reads, &sort_temp));
     sort_temp = (sort_temp + 255) & ~(size_t)255;
@@ -454,18 +478,17 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
 
     // events per job of the two chunked classes: WEPP_WALK_JOB_EVENTS fixes them, else they follow the handle's
     // traffic (device_mat.hpp: WALK_TARGET_JOBS)
-    static const uint32_t job_events_env = getenv("WEPP_WALK_JOB_EVENTS") ? (uint32_t)std::min(0xFFFF, std::max(1, atoi(getenv("WEPP_WALK_JOB_EVENTS")))) : 0u;
-    const uint32_t job_events = job_events_env ? (job_events_env | (job_events_env << 16)) : (mat->job_events[0] | (mat->job_events[1] << 16));
-    static const uint32_t walk_max_events = getenv("WEPP_WALK_MAX_EVENTS") ? (uint32_t)atoi(getenv("WEPP_WALK_MAX_EVENTS")) : WALK_MAX_EVENTS;
-    static const uint32_t stack8 = getenv("WEPP_WALK_STACK8") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK8")) : WALK8_ROWS;
-    static const uint32_t stack16 = getenv("WEPP_WALK_STACK16") ? (uint32_t)atoi(getenv("WEPP_WALK_STACK16")) : WALK16_ROWS;
+    const uint32_t job_events = tun.job_events ? (tun.job_events | (tun.job_events << 16)) : (mat->job_events[0] | (mat->job_events[1] << 16));
+    const uint32_t walk_max_events = tun.walk_max_events, stack8 = tun.stack8, stack16 = tun.stack16;
+    // whole-genome samples are seeded (seed_kernels.hip) when work skipping is on and the tree carries signatures
+    const uint32_t seed_min_hard = (mat->use_seeds && mat->use_crowns && mat->dev.seed_chunks) ? tun.seed_min_hard : 0xFFFFFFFFu;
     // ---- route the reads to streams ------------------------------------------------------
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
         tier_info = L.d_info + L.info_idx * TI_WORDS;
         uint32_t* tier_info_next = L.d_info + (L.info_idx ^ 1u) * TI_WORDS;
-        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, stack8, stack16, job_n, tier_of, root_score, blk_counts,
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, stack8, stack16, seed_min_hard, tun.seed_min_nodes, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, wsid, stream));
         L.info_idx ^= 1u;
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
@@ -505,11 +528,20 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     uint64_t walk_reads = 0, n_jobs[2] = {0, 0};
     uint32_t walkc_reads[2] = {0, 0};
     uint32_t arena_n = 0, arena_off = 0, arena_maxk = 1;
+    uint32_t seed_n = 0, seed_off = 0, seed_maxk = 1;
     size_t arena_part = 0;
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
         const uint32_t t = plan_index(id), cls = plan_class(id);
+        if (cls == PLAN_SEED) {
+            // whole-genome samples: a workgroup each, final results written by the kernel (seed_kernels.hip)
+            if (!mat->dev.seed_chunks) return set_error(WEPP_EDEVICE, "routing produced an invalid plan id");
+            seed_n = count;
+            seed_off = info[TI_OFF + id];
+            seed_maxk = std::max<uint32_t>(1, info[TI_MAXK + id]);
+            continue;
+        }
         {
             // (slot WC_SLOT of a walk class = the window crowns: one plan, a crown per read)
             if (cls > PLAN_WIN || (cls == PLAN_WIN ? t >= mat->wstreams.size() : (t >= ns && !(t == WC_SLOT && mat->dev.wc_windows))))
@@ -585,16 +617,16 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         p.lds_bytes = p.s_in_lds ? sweep_lds_bytes(mat->dev.bm_words, cap, kcap, p.dense, p.win_table) : bm_bytes;
         // chunks: enough single-wave workgroups to fill 256 CUs, cut at checkpoints
         const DevStream& st = *p.st;
-        static const uint32_t target_waves = getenv("WEPP_TARGET_WAVES") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES")) : 4096;   // 16 resident single-wave workgroups per CU x 256 CUs; 2048 / 8192 / 16384 measured slower (WEPP_TARGET_WAVES: tuning aid)
+        const uint32_t target_waves = tun.target_waves;   // 4096: 16 resident single-wave workgroups per CU x 256 CUs; 2048 / 8192 / 16384 measured slower (WEPP_TARGET_WAVES: tuning aid)
         // (the 8-wave workgroups of the dense / window variant run for milliseconds: four times as many of them
         // balance the chip better -- 1.2 kb reads 132 -> 120 ms per 200 K at 16384, the same at 32768)
-        static const uint32_t target_waves_dense = getenv("WEPP_TARGET_WAVES_DENSE") ? (uint32_t)atoi(getenv("WEPP_TARGET_WAVES_DENSE")) : 16384;
+        const uint32_t target_waves_dense = tun.target_waves_dense;
         uint32_t nchunks = std::max<uint32_t>(1, ((p.dense ? target_waves_dense : target_waves) + p.ntiles - 1) / p.ntiles);
         // ... and chunks no longer than what stays in an XCD's L2 while the tiles sweep it: the waves of
         // a launch are ordered chunk-major (all tiles of chunk 0, then of chunk 1, ...), so the ~4 K
         // resident waves walk the same ~1.5 MB of the stream together instead of drifting apart over
         // 118 MB (whole-tree sweep of 1 M reads: 432 ms with one chunk per tile, 235 ms with 80)
-        static const uint64_t chunk_bytes = getenv("WEPP_CHUNK_BYTES") ? (uint64_t)atoll(getenv("WEPP_CHUNK_BYTES")) : SWEEP_CHUNK_BYTES;
+        const uint64_t chunk_bytes = tun.chunk_bytes;
         nchunks = std::max<uint32_t>(nchunks, (uint32_t)((p.sbytes + chunk_bytes - 1) / chunk_bytes));
         nchunks = std::min<uint32_t>(nchunks, (uint32_t)std::max<uint64_t>(1, SWEEP_MAX_PARTIAL_BYTES / ((uint64_t)count * 12)));
         // ... but a chunk's wave pays a set-up (bitmap, read words, checkpoint) worth several blocks: no chunk
@@ -627,7 +659,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = list + walk_off[cls][k];
     for (uint32_t cc = 0; cc < 2; cc++)
         for (uint32_t k = 0; k < walkc[cc].n; k++) walkc[cc].p[k].list = list + walkc_off[cc];
-    static const bool debug_plans = getenv("WEPP_DEBUG_PLANS") != nullptr;
+    const bool debug_plans = tun.debug_plans;
     for (uint32_t i = 0; i < np; i++) {
         Plan& p = plans[i];
         p.lst = list + p.off;
@@ -658,7 +690,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     uint32_t order[MAX_PLANS], n_plain = 0, n_other = 0, others[MAX_PLANS];
     // WEPP_SWEEP_UNFUSED=1 (profiling aid): one launch per plan, back to back on `stream`, so that a
     // kernel trace shows the time of every stream's sweep; results are identical
-    static const bool unfused = getenv("WEPP_SWEEP_UNFUSED") && getenv("WEPP_SWEEP_UNFUSED")[0] == '1';
+    const bool unfused = tun.sweep_unfused;
     for (uint32_t i = 0; i < np; i++) {
         if (plans[i].s_in_lds && !plans[i].dense && !unfused && n_plain < MAX_STREAMS) order[n_plain++] = i;
         else others[n_other++] = i;
@@ -673,7 +705,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
     const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
-    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
+    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u) + (seed_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
     const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
     if (fork) HIP_TRY(hipEventRecord(L.fork_ev, stream));
     // the side streams join the caller's stream only after everything has been launched: a join in between
@@ -685,7 +717,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // A walk class's reads go by (stream, first listed position) when there are enough of them (device_mat.hpp:
     // WALK_SORT_MIN_READS; WEPP_WALK_SORT=0: A/B aid): sorted on the class's own stream, right before its launch.
     // `region` = which of the sort temp regions (1..4; 0 is the whole-tree plan's).
-    static const bool walk_sort = sort_reads && !(getenv("WEPP_WALK_SORT") && getenv("WEPP_WALK_SORT")[0] == '0');
+    const bool walk_sort = tun.walk_sort;
     auto sort_class = [&](uint32_t cls, uint32_t region, hipStream_t q, bool& sorted) -> int {
         sorted = false;
         if (!walk_sort) return WEPP_OK;
@@ -707,7 +739,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             if (!walk[cls].n) continue;
             // (the plain classes keep the caller's order unless WEPP_WALK_SORT_PLAIN=1: their reads have at most 16
             // events each, mostly on streams the L2s hold anyway, and a sort of 1 M reads costs 0.15 ms of a 0.3 ms step)
-            static const bool sort_plain = getenv("WEPP_WALK_SORT_PLAIN") && getenv("WEPP_WALK_SORT_PLAIN")[0] == '1';
+            const bool sort_plain = tun.walk_sort_plain;
             bool sorted = false;
             if (sort_plain) {
                 int rc = sort_class(cls, 1 + cls, q, sorted);
@@ -819,6 +851,22 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         }
         passes += arena_n;
     }
+    if (seed_n) {
+        if (seed_maxk > SEED_MAX_ENTRIES) return set_error(WEPP_EDEVICE, "routing seeded a sample with too many entries");
+        const uint32_t cap = (seed_maxk + 63) & ~63u;
+        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 2] : stream;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
+        if (debug_plans) fprintf(stderr, "[plan] seed count=%u maxk=%u chunks=%u lds=%u\n", seed_n, seed_maxk, mat->dev.seed_chunks, seed_lds_bytes(mat->dev, cap));
+        HIP_TRY(launch_seed(mat->dev, mat->streams.back(), list + seed_off, seed_n, cap, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
+                            d_num_best, d_flags, mat->d_work, q));
+        if (fork) {
+            HIP_TRY(hipEventRecord(L.join_ev[OTHER_SIDE_STREAMS - 2], q));
+            bool listed = false;
+            for (uint32_t i = 0; i < n_joins; i++) listed = listed || joins[i] == OTHER_SIDE_STREAMS - 2;
+            if (!listed) joins[n_joins++] = OTHER_SIDE_STREAMS - 2;
+        }
+        passes += seed_n;
+    }
     if (n_plain) {
         SweepPlans pl{};
         uint32_t wg = 0, fin = 0, lds_max = 0;
@@ -876,7 +924,7 @@ extern "C" int wepp_mat_timing_reset(wepp_mat_t* mat) {
     mat->acc_passes = mat->acc_bytes = 0;
     HIP_TRY(hipSetDevice(mat->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(mat->d_work, 0, 2 * WALK_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(mat->d_work, 0, wepp_mat::D_WORK_BYTES));
     return WEPP_OK;
 }
 
@@ -938,7 +986,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     if (nw && !read_word) return set_error(WEPP_EINVAL, "null read_word");
     HIP_TRY(hipSetDevice(mat->device));
     // WEPP_DEBUG_TIMING=1: wall time of the call's phases to stderr
-    static const bool dbg_time = getenv("WEPP_DEBUG_TIMING") != nullptr;
+    const bool dbg_time = mat->tun.debug_timing;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 
@@ -998,7 +1046,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
         mat->pool.reset(new HostPool(std::min<uint32_t>(15, hw > 1 ? hw - 1 : 1)));
     }
-    static const uint32_t pipe_env = getenv("WEPP_PIPE_SUBBATCHES") ? (uint32_t)std::max(1, atoi(getenv("WEPP_PIPE_SUBBATCHES"))) : 0u;
+    const uint32_t pipe_env = mat->tun.pipe_sub_batches;
     const uint32_t pipe_knob = mat->pipe_sub_batches ? mat->pipe_sub_batches : pipe_env;
     // S sub-batches = device calls.  A device call is a chain of ~20 short launches with a host round trip in the
     // middle (routing counters): ~0.3 ms whatever its size up to a million short reads, most of it the HOST's share,
@@ -1425,12 +1473,12 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     uint32_t* tier_info_next = mat->lane[0].d_info + (mat->lane[0].info_idx ^ 1u) * TI_WORDS;
     uint32_t* blk_counts = mat->lane[0].d_info + 2 * TI_WORDS;
     HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns ? 3 : 0, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
-                         d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, nullptr));
+                         0xFFFFFFFFu, 0u, d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, nullptr));
     mat->lane[0].info_idx ^= 1u;
     HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
     HIP_TRY(hipMemcpy(mat->lane[0].h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const uint32_t* info = mat->lane[0].h_info;
-    static const bool debug_plans = getenv("WEPP_DEBUG_PLANS") != nullptr;
+    const bool debug_plans = mat->tun.debug_plans;
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
@@ -1469,7 +1517,7 @@ extern "C" int wepp_mat_last_tiers(wepp_mat_t* mat, uint8_t* tiers, uint32_t n_r
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tiers, mat->d_plan_of, n_reads, hipMemcpyDeviceToHost));
     for (uint32_t r = 0; r < n_reads; r++)       // the workspace holds plan ids (device_mat.hpp: plan_id)
-        tiers[r] = plan_class(tiers[r]) == PLAN_WIN ? (uint8_t)(mat->dev.n_streams - 1) : (uint8_t)plan_index(tiers[r]);
+        tiers[r] = (plan_class(tiers[r]) == PLAN_WIN || plan_class(tiers[r]) == PLAN_SEED) ? (uint8_t)(mat->dev.n_streams - 1) : (uint8_t)plan_index(tiers[r]);
     return WEPP_OK;
 }
 
@@ -1521,7 +1569,7 @@ extern "C" int wepp_mat_last_walk(wepp_mat_t* mat, uint64_t* reads_walked, uint6
     }
     if (reads_walked) *reads_walked = mat->last_walk_reads;
     if (walk_iterations) *walk_iterations = it;
-    if (getenv("WEPP_WALK_DEBUG")) {
+    if (mat->tun.walk_debug) {
         std::vector<unsigned long long> slots(WALK_COUNTERS);
         HIP_TRY(hipMemcpy(slots.data(), mat->d_work, WALK_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long a = 0, b = 0;
@@ -1540,5 +1588,23 @@ extern "C" int wepp_mat_last_walk(wepp_mat_t* mat, uint64_t* reads_walked, uint6
                         100.0 * v[7] / std::max(1.0, 64.0 * v[6]), v[8], v[9], v[10]);
         }
     }
+    return WEPP_OK;
+}
+
+// diagnostic: the whole-genome samples the handle seeded since the last timing reset, the chunks of the whole-tree
+// stream they evaluated and the chunks they could have evaluated (samples x chunks of the tree)
+extern "C" int wepp_mat_last_seeds(wepp_mat_t* mat, uint64_t* samples, uint64_t* chunks_evaluated, uint64_t* chunks_total,
+                                   uint64_t* most_per_sample, uint64_t* histogram8) {
+    if (!mat) return set_error(WEPP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(mat->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v[12] = {};
+    HIP_TRY(hipMemcpy(v, mat->d_work + 2 * WALK_COUNTERS, sizeof(v), hipMemcpyDeviceToHost));
+    if (samples) *samples = v[0];
+    if (chunks_evaluated) *chunks_evaluated = v[1];
+    if (chunks_total) *chunks_total = v[2];
+    if (most_per_sample) *most_per_sample = v[3];
+    if (histogram8)
+        for (int i = 0; i < 8; i++) histogram8[i] = v[4 + i];
     return WEPP_OK;
 }

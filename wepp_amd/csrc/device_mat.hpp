@@ -1,5 +1,5 @@
 // device_mat.hpp -- the flat MAT as the kernels see it (device pointers) and
-// the launcher prototypes shared between place_kernels.hip and capi.cpp.
+// the launcher prototypes shared between the kernel units (route / sweep / walk / pass2 / seed _kernels.hip) and capi.cpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -89,6 +89,9 @@ struct DevMAT {
     const DevStream* wc_streams;  // [wc_windows * WC_MAX] their sweep streams (k_sweep_arena)
     uint32_t wc_windows;          // 0: none built
     uint32_t win_n[MAX_WINDOWS];  // nodes of window w's stream when it is a crown (all the window's candidates, flatmat.hpp), 0xFFFFFFFF when the whole tree
+    // seed signatures (flatmat.hpp): nibble (position, chunk of the whole-tree stream); seed_chunks == 0: none built
+    const uint32_t* seed_sig;
+    uint32_t seed_stride, seed_chunks, seed_row_words;
 };
 // reads with more entries than this whose positions lie in one genome window share tile sweeps of the window's stream
 // (PLAN_WIN) when that is a crown; shorter ones that cannot walk sweep their window crown alone (k_sweep_arena)
@@ -101,12 +104,25 @@ constexpr uint32_t WIN_MIN_ENTRIES = 32;
 // the intervals it can hold open at once (sum of maxnest over its positions) fit WALK8_STACK / WALK16_STACK, by a
 // sweep of the whole stream otherwise.
 constexpr uint32_t MAX_PLANS = 128;
-constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC8 = 3, PLAN_WALKC16 = 4, PLAN_WIN = 5;
+constexpr uint32_t PLAN_WALK8 = 0, PLAN_WALK16 = 1, PLAN_SWEEP = 2, PLAN_WALKC8 = 3, PLAN_WALKC16 = 4, PLAN_WIN = 5, PLAN_SEED = 6;
 constexpr uint32_t PLAN_WIN_BASE = PLAN_WIN * MAX_STREAMS;
-static_assert(PLAN_WIN_BASE + MAX_WINDOWS <= MAX_PLANS, "plan ids");
-__host__ __device__ inline uint32_t plan_id(uint32_t cls, uint32_t idx) { return cls * MAX_STREAMS + idx; }   // (PLAN_WIN is the last class)
-__host__ __device__ inline uint32_t plan_class(uint32_t id) { return id >= PLAN_WIN_BASE ? PLAN_WIN : id / MAX_STREAMS; }
-__host__ __device__ inline uint32_t plan_index(uint32_t id) { return id >= PLAN_WIN_BASE ? id - PLAN_WIN_BASE : id % MAX_STREAMS; }
+constexpr uint32_t PLAN_SEED_ID = PLAN_WIN_BASE + MAX_WINDOWS;     // ONE plan behind the windows' plans
+static_assert(PLAN_SEED_ID < MAX_PLANS, "plan ids");
+__host__ __device__ inline uint32_t plan_id(uint32_t cls, uint32_t idx) { return cls == PLAN_SEED ? PLAN_SEED_ID : cls * MAX_STREAMS + idx; }   // (PLAN_WIN is the last class with an index)
+__host__ __device__ inline uint32_t plan_class(uint32_t id) { return id == PLAN_SEED_ID ? PLAN_SEED : id >= PLAN_WIN_BASE ? PLAN_WIN : id / MAX_STREAMS; }
+__host__ __device__ inline uint32_t plan_index(uint32_t id) { return id == PLAN_SEED_ID ? 0u : id >= PLAN_WIN_BASE ? id - PLAN_WIN_BASE : id % MAX_STREAMS; }
+// PLAN_SEED (seed_kernels.hip): a sample that cannot walk and fits no genome window -- a whole-genome
+// sample -- but lists at least SEED_MIN_HARD alleles that exclude its reference base: a workgroup of its own counts,
+// per chunk of the whole-tree stream, how many of those the chunk's signature could serve, and evaluates only the
+// chunks whose count leaves a score within reach of the best one found so far.
+constexpr uint32_t SEED_MIN_HARD = 3;               // fewer such entries: no chunk is ever ruled out
+constexpr uint32_t SEED_MIN_STREAM_NODES = 65536;   // a read whose tree-wide stream is smaller keeps its tile sweep
+constexpr uint32_t SEED_MAX_ENTRIES = 4096;         // entries of a seeded sample (its words are staged in LDS)
+#ifndef WEPP_SEED_THREADS
+#define WEPP_SEED_THREADS 512
+#endif
+constexpr uint32_t SEED_THREADS = WEPP_SEED_THREADS;   // one workgroup per sample (256 / 512 / 1024: 8.7 / 5.6 / 6.3 ms per 20 000 samples of ~67 entries at 16 M nodes)
+constexpr uint32_t SEED_MAX_HARD = 255;             // hard entries counted per chunk (byte counters; a subset is a valid bound)
 // PLAN_WIN: a read with more entries than a walk takes, all inside one genome window, sweeps that window's
 // stream (the whole tree reduced to the nodes that mutate the window + pseudo-nodes) instead of the whole tree.
 // PLAN_WALKC8 / 16: a read with many events at its positions (a frequently mutated site) walks them as several
@@ -197,10 +213,20 @@ constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chain
 
 // route: tier of every read + per-(block, tier) counts and per-tier max entries; also clears tier_info_next,
 // the counters the next call will use (they must be zero before its k_route)
+// seed_min_hard / seed_min_nodes: a read left to the sweeps with at least that many reference-excluding entries, on a
+// tree-wide stream of at least that many nodes, becomes a seeded sample (seed_min_hard == 0xFFFFFFFF: none does)
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
+                        uint32_t seed_min_hard, uint32_t seed_min_nodes,
                         uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
                         uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, uint32_t* wsid, hipStream_t stream);
+// the seeded samples of one call: a workgroup per sample writes its final results (seed_kernels.hip)
+uint32_t seed_lds_bytes(const DevMAT& m, uint32_t ent_cap);
+hipError_t seed_set_max_lds(uint32_t bytes);
+hipError_t launch_seed(const DevMAT& m, const DevStream& full, const uint32_t* list, uint32_t n_list, uint32_t ent_cap,
+                       const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score,
+                       uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags,
+                       unsigned long long* work_counter, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
 constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less than the sort

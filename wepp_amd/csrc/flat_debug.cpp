@@ -64,7 +64,7 @@ extern "C" int wepp_flat_get(const wepp_flat_t* flat, const char* name, const vo
         if (si >= f.streams.size()) return wepp::set_error(WEPP_EINVAL, "stream index out of range");
     } else {
         FIELD(f, node_woff) FIELD(f, words) FIELD(f, rank2dfs) FIELD(f, dfs2bfs) FIELD(f, bfs2id) FIELD(f, dfs2id)
-        FIELD(f, parent_dfs) FIELD(f, dfs_end) FIELD(f, num_leaves) FIELD(f, epp_word) FIELD(f, epp_node) FIELD(f, maxnest) FIELD(f, rank2bfs)
+        FIELD(f, parent_dfs) FIELD(f, dfs_end) FIELD(f, num_leaves) FIELD(f, epp_word) FIELD(f, epp_node) FIELD(f, maxnest) FIELD(f, rank2bfs) FIELD(f, seed_sig)
     }
     // "w<i>:" selects window stream i
     const bool win = name[0] == 'w' && name[1] >= '0' && name[1] <= '9' && std::strchr(name, ':');
@@ -118,6 +118,12 @@ extern "C" int wepp_flat_scalars(const wepp_flat_t* flat, wepp_mat_stats* stats,
             stats->stream_nodes[i] = f.streams[i].n;
             stats->stream_bytes_of[i] = f.streams[i].stream_bytes();
         }
+        stats->window_size = wepp::WIN_SIZE;
+        stats->window_stride = wepp::WIN_STRIDE;
+        stats->window_uncovered_positions = f.max_pos + 1 > wepp::MAX_WINDOWS * wepp::WIN_STRIDE ? f.max_pos + 1 - wepp::MAX_WINDOWS * wepp::WIN_STRIDE : 0;
+        stats->seed_chunks = f.seed_chunks;
+        stats->seed_chunk_blocks = f.seed_stride;
+        stats->seed_sig_bytes = (uint64_t)f.seed_sig.size() * 4;
     }
     if (cp_stride) *cp_stride = f.full().cp_stride;
     return WEPP_OK;

@@ -17,6 +17,7 @@
 //   * tie-break (num_leaves, then larger BFS index j)
 //                                usher_mapper.cpp:484-487
 #include "flatmat.hpp"
+#include "flatten_options.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -46,6 +47,8 @@ struct StreamElems {
     uint32_t pos_lo = 0, pos_hi = 0xFFFFFFFFu;   // only mutations with pos_lo <= position < pos_hi become events
     bool weighted = false;           // has pseudo-nodes: the stream carries ncnt
     bool walk_index = true;          // build the position index / range-query tables of the walk
+    uint32_t cp_max_stride = 0;      // != 0: checkpoints at least every cp_max_stride blocks (the whole-tree stream: seed chunks start at checkpoints)
+    uint32_t ix_pre_min_nodes = IX_PRE_MIN_NODES;
 };
 
 int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::string& err) {
@@ -262,8 +265,7 @@ int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::
         }
         // pre-test byte of the nodes between consecutive entries of a list, in the entry that ends the range
         st.ix_pre.assign(1, 0);
-        static const uint32_t pre_min_nodes = getenv("WEPP_IX_PRE_MIN_NODES") ? (uint32_t)atoll(getenv("WEPP_IX_PRE_MIN_NODES")) : IX_PRE_MIN_NODES;
-        if (f.N <= (1u << IX_RANK_BITS) && n >= pre_min_nodes) {
+        if (f.N <= (1u << IX_RANK_BITS) && n >= el.ix_pre_min_nodes) {
             st.ix_pre[0] = 1;
             auto range_min = [&](uint32_t a, uint32_t b) -> uint32_t {     // [a, b), a < b: exact minimum (two overlapping spans)
                 uint32_t l = 0;
@@ -283,7 +285,8 @@ int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::
         }
     }
     // checkpoints
-    st.cp_stride = std::max<uint32_t>(1, (st.NB + 1023) / 1024);   // <= 1024 places where a sweep may start
+    st.cp_stride = std::max<uint32_t>(1, (st.NB + 1023) / 1024);   // <= 1024 places where a sweep may start ...
+    if (el.cp_max_stride) st.cp_stride = std::min(st.cp_stride, el.cp_max_stride);   // ... more on the whole-tree stream: one per seed chunk
     {
         const uint32_t ncp = (st.NB + st.cp_stride - 1) / st.cp_stride;
         st.cp_off.assign(ncp + 1, 0);
@@ -310,8 +313,8 @@ int build_stream_core(const FlatMAT& f, const StreamElems& el, Stream& st, std::
 }
 
 // a crown (or the whole tree): the ancestor-closed node subset `sel` (sorted global DFS indices, sel[0] == 0)
-int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err,
-                 uint32_t pos_lo = 0, uint32_t pos_hi = 0xFFFFFFFFu, bool walk_index = true) {
+int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st, std::string& err, const FlattenOptions& opt,
+                 uint32_t pos_lo = 0, uint32_t pos_hi = 0xFFFFFFFFu, bool walk_index = true, uint32_t cp_max_stride = 0) {
     const uint32_t n = (uint32_t)sel.size();
     const uint32_t N = f.N;
     // number of selected nodes with global index <= g
@@ -328,6 +331,8 @@ int build_stream(const FlatMAT& f, const std::vector<uint32_t>& sel, Stream& st,
     el.pos_lo = pos_lo;          // (a window crown indexes the mutations of its window only)
     el.pos_hi = pos_hi;
     el.walk_index = walk_index;
+    el.cp_max_stride = cp_max_stride;
+    el.ix_pre_min_nodes = opt.ix_pre_min_nodes;
     el.nkey.resize(n); el.nstat.resize(n); el.cnt.assign(n, 1); el.min_all.resize(n); el.lend.resize(n); el.lpar.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t g = sel[i];
@@ -421,6 +426,7 @@ static std::atomic<uint64_t> g_flatten_count{0};
 uint64_t flatten_count() { return g_flatten_count.load(std::memory_order_relaxed); }
 
 int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool topology_only) {
+    const FlattenOptions opt = FlattenOptions::from_env();
     const uint32_t N = t.n_nodes;
     if (N == 0 || !t.parent || !t.mut_off) { err = "empty tree or null arrays"; return WEPP_EINVAL; }
     if (N >= 0xFFFFFFF0u) { err = "too many nodes"; return WEPP_ELIMIT; }
@@ -696,15 +702,47 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
             if (prev && sel.size() < prev + prev / 4) continue;  // too close to the previous crown
             f.streams.emplace_back();
             f.streams.back().tau = tau;
-            int rc = build_stream(f, sel, f.streams.back(), err);
+            int rc = build_stream(f, sel, f.streams.back(), err, opt);
             if (rc != WEPP_OK) return rc;
             prev = sel.size();
         }
         sel.resize(N);
         std::iota(sel.begin(), sel.end(), 0u);
         f.streams.emplace_back();
-        int rc = build_stream(f, sel, f.streams.back(), err);
+        int rc = build_stream(f, sel, f.streams.back(), err, opt, 0, 0xFFFFFFFFu, true, opt.seed_chunk_blocks);
         if (rc != WEPP_OK) return rc;
+    }
+
+    // ---- seed signatures (flatmat.hpp): per (position, chunk of the whole-tree stream) the alleles a genotype scored in
+    // the chunk can hold -- the mutations of the chunk's nodes and of the ancestors of its first node ---------------
+    {
+        const Stream& full = f.streams.back();
+        uint32_t stride = full.cp_stride * ((opt.seed_chunk_blocks + full.cp_stride - 1) / full.cp_stride);
+        if ((full.NB + stride - 1) / stride > SEED_MAX_CHUNKS) {
+            const uint32_t need = (full.NB + SEED_MAX_CHUNKS - 1) / SEED_MAX_CHUNKS;
+            stride = full.cp_stride * ((need + full.cp_stride - 1) / full.cp_stride);
+        }
+        const uint32_t nch = (full.NB + stride - 1) / stride;
+        const uint32_t row_words = (((nch + 7) / 8) + 3) & ~3u;          // 16-byte rows
+        const uint64_t bytes = (uint64_t)(f.max_pos + 2) * row_words * 4;
+        if (f.max_pos <= SEED_MAX_POS && bytes <= SEED_MAX_SIG_BYTES) {
+            f.seed_stride = stride;
+            f.seed_chunks = nch;
+            f.seed_row_words = row_words;
+            f.seed_sig.assign((size_t)(f.max_pos + 2) * row_words, 0u);
+            auto mark = [&](uint32_t word, uint32_t c) {
+                f.seed_sig[(size_t)(word & W_POS_MASK) * row_words + (c >> 3)] |= w_mut(word) << ((c & 7u) * 4u);
+            };
+            for (uint32_t c = 0; c < nch; c++) {
+                // (the whole-tree stream's local node indices are the global DFS indices)
+                const uint32_t a = full.blk_node0[c * stride], b = full.blk_node0[std::min(full.NB, (c + 1) * stride)];
+                for (uint32_t w = f.node_woff[a]; w < f.node_woff[b]; w++) mark(f.words[w], c);
+                for (uint32_t v = a; v != 0;) {
+                    v = f.parent_dfs[v];
+                    for (uint32_t w = f.node_woff[v]; w < f.node_woff[v + 1]; w++) mark(f.words[w], c);
+                }
+            }
+        }
     }
 
     // ---- window crowns (flatmat.hpp): per genome window, the candidates with out_w <= tau and their ancestors; and the
@@ -715,7 +753,7 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
         f.wstreams.resize(n_win);
         std::vector<std::string> errs(n_win);
         std::vector<int> rcs(n_win, WEPP_OK);
-        static const bool no_balanced = getenv("WEPP_WIN_WHOLE_TREE") && getenv("WEPP_WIN_WHOLE_TREE")[0] == '1';   // (A/B and test aid)
+        const bool no_balanced = opt.win_whole_tree;   // (A/B and test aid)
         auto build_window = [&](uint32_t wi, std::vector<uint8_t>& mark) {
             // the crowns of a window nest: the marks stay from one tau to the next
             std::vector<uint32_t> sel(1, 0u);
@@ -745,14 +783,14 @@ int flatten_tree(const wepp_tree_desc& t, FlatMAT& f, std::string& err, bool top
                 f.wcrowns[wi].emplace_back();
                 Stream& st = f.wcrowns[wi].back();
                 st.tau = tau;
-                rcs[wi] = build_stream(f, sel, st, errs[wi], lo, hi);
+                rcs[wi] = build_stream(f, sel, st, errs[wi], opt, lo, hi);
                 if (rcs[wi] != WEPP_OK) break;
                 prev = sel.size();
                 all = last;
             }
             if (rcs[wi] == WEPP_OK) {
                 if (all && !no_balanced) {
-                    rcs[wi] = build_stream(f, sel, f.wstreams[wi], errs[wi], lo, hi, /*walk_index=*/false);
+                    rcs[wi] = build_stream(f, sel, f.wstreams[wi], errs[wi], opt, lo, hi, /*walk_index=*/false);
                     f.wstreams[wi].tau = 0x7FFFFFFF;
                 } else rcs[wi] = build_window_stream(f, lo, hi, f.wstreams[wi], errs[wi]);
             }

@@ -192,17 +192,44 @@ struct FlatMAT {
     // consecutive events i, j is constant and belongs to the nodes [epp_node[i], epp_node[j]).
     std::vector<uint32_t> epp_word;    // [2M]
     std::vector<uint32_t> epp_node;    // [2M]
+    // SEED SIGNATURES (seed_kernels.hip): the whole-tree stream cut into seed_chunks chunks of
+    // seed_stride blocks (about a thousand nodes; every chunk starts at a checkpoint of the stream).  Nibble
+    // (position p, chunk c) of seed_sig = OR of the mut_nuc masks of every mutation at p carried by a node of the
+    // chunk or by an ancestor of the chunk's first node -- a superset of the alleles any genotype a node of the chunk
+    // is scored against (usher_mapper.cpp:191-287) can hold at p.  A sample entry whose allele excludes its reference
+    // base costs one at a node unless that genotype offers a compatible allele there (:293-389), so a sample with s0
+    // such entries, H of which the chunk's signature could serve, scores at least s0 - H on every node of the chunk.
+    // Row p = seed_row_words dwords, 8 chunks per dword; empty when the tree is too small or the table too large.
+    uint32_t seed_stride = 0, seed_chunks = 0, seed_row_words = 0;
+    std::vector<uint32_t> seed_sig;    // [(max_pos + 2) * seed_row_words]
     const Stream& full() const { return streams.back(); }
 };
 
 // window streams (flatmat.cpp): a read whose positions span at most WIN_SIZE - WIN_STRIDE = 1536 (a 1.2 kb
 // amplicon) lies inside the window that starts at its first position rounded down to the stride
-constexpr uint32_t WIN_SIZE = 2560, WIN_STRIDE = 1024, MAX_WINDOWS = 32;
+// (-DWEPP_WIN_SIZE / -DWEPP_WIN_STRIDE: a test-only build with windows of a few dozen positions lets the fuzz trees --
+// masked nodes, multi-allelic alleles, repeated positions, back-mutations -- straddle window edges on the GPU,
+// tools/build_variant.sh win64; the product is built with the defaults.)  Positions from MAX_WINDOWS * WIN_STRIDE on
+// lie in no window: reads there take the tree-wide streams (wepp_mat_stats::window_uncovered_positions).
+#ifndef WEPP_WIN_SIZE
+#define WEPP_WIN_SIZE 2560
+#endif
+#ifndef WEPP_WIN_STRIDE
+#define WEPP_WIN_STRIDE 1024
+#endif
+constexpr uint32_t WIN_SIZE = WEPP_WIN_SIZE, WIN_STRIDE = WEPP_WIN_STRIDE, MAX_WINDOWS = 32;
+static_assert(WIN_STRIDE > 0 && WIN_SIZE >= 2 * WIN_STRIDE && WIN_SIZE <= 3 * WIN_STRIDE, "a position lies in at most three windows");
 constexpr uint32_t MAX_STREAMS = 16;   // also the size of the stream arrays of wepp_mat_stats
 // window crowns: at most WC_MAX per window, tau = root score + 0 .. WC_MAX_DTAU, none larger than WC_MAX_NODES nodes;
 // in plan ids and diagnostics they all share ONE stream slot, the last one (the tree-wide streams use at most
 // MAX_STREAMS - 1 slots): which window crown a read walks is a per-read value (k_route)
 constexpr uint32_t WC_MAX = 7, WC_MAX_DTAU = 5, WC_MAX_NODES = 1u << 19, WC_SLOT = MAX_STREAMS - 1;
+
+// seed chunks: blocks of the whole-tree stream per chunk (rounded up to the stream's checkpoint stride), most chunks
+// (a sample's per-chunk counters are bytes in LDS), largest signature table built
+constexpr uint32_t SEED_CHUNK_BLOCKS = 16, SEED_MAX_CHUNKS = 32768;
+constexpr uint64_t SEED_MAX_SIG_BYTES = 1ull << 30;
+constexpr uint32_t SEED_MAX_POS = (1u << 18) - 1;   // the position bitmap of a sample shares the workgroup's LDS with its counters
 
 // flatten_tree calls of this process that built the full image (not topology_only): lets a test see that a
 // multi-device run flattened once

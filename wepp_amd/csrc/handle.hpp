@@ -14,6 +14,7 @@
 #include "errors.hpp"
 #include "flatmat.hpp"
 #include "host_pool.hpp"
+#include "tunables.hpp"
 
 using namespace wepp;
 
@@ -43,10 +44,15 @@ struct wepp_mat {
     std::vector<DevWalk> walks;       // position index + range-query structures of every stream (k_walk)
     uint64_t wc_nodes = 0;            // nodes of all window crowns (the arena of slot WC_SLOT)
     uint32_t wc_count = 0;            // window crowns built
+    PlaceTunables tun;                // the environment's knobs, read once when the handle was created (tunables.hpp)
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
+    int use_seeds = 1;                // whole-genome samples go by chunk signatures (WEPP_SEED=0: tile sweeps)
     uint32_t job_events[2] = {WALK_JOB_EVENTS, WALK_JOB_EVENTS};   // events per job of the chunked classes in the next call
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
-    unsigned long long* d_work = nullptr;   // loop iterations of the walks since the last timing reset
+    unsigned long long* d_work = nullptr;   // [WALK_COUNTERS] loop iterations of the walks, [WALK_COUNTERS] bytes the walks / seeds asked memory for,
+                                            // [D_WORK_EXTRA] seeded samples, chunks they evaluated, chunks in all, most per sample, histogram -- since the last timing reset
+    static constexpr uint32_t D_WORK_EXTRA = 16;
+    static constexpr size_t D_WORK_BYTES = (2 * WALK_COUNTERS + D_WORK_EXTRA) * sizeof(unsigned long long);
     std::vector<uint64_t> stream_bytes;
     std::vector<DevStream> wstreams;  // window streams (PLAN_WIN)
     std::vector<uint64_t> wstream_bytes;

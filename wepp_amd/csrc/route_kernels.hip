@@ -1,0 +1,307 @@
+// route_kernels.hip -- routing of a batch: which stream / plan every read takes (k_route), the read lists per plan
+// (k_scatter) and the sort keys of the lists that are position-sorted.
+//
+// Work skipping (exact): score(n) >= base(n) - |S| for every node, and the best score is <=
+// the root's score, so a read with theta = score(root) + |S| only needs the "crown" of nodes with base <= theta
+// (plus ancestors); a read confined to a genome window needs the window crown its ROOT score admits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "device_mat.hpp"
+#include "place_dev.hpp"
+
+namespace wepp {
+
+// -----------------------------------------------------------------------------
+// k_route: theta(read) = score(root) + |S| -> index of the smallest stream whose
+// tau covers it.  Per-(block, tier) counts go to blk_counts, per-tier totals and
+// the largest read of each tier to tier_info.
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_t* __restrict__ read_off,
+                                                          const uint32_t* __restrict__ read_word, uint32_t n_reads,
+                                                          int use_crowns, uint32_t walk_max_events, uint32_t job_events,
+                                                          uint32_t stack8, uint32_t stack16,
+                                                          uint32_t seed_min_hard, uint32_t seed_min_nodes,
+                                                          uint32_t* __restrict__ job_n, uint8_t* __restrict__ tier_of,
+                                                          int32_t* __restrict__ root_score,
+                                                          uint32_t* __restrict__ blk_counts,
+                                                          uint32_t* __restrict__ tier_info,
+                                                          uint32_t* __restrict__ slot_in_blk,
+                                                          uint32_t* __restrict__ tier_info_next,
+                                                          uint32_t* __restrict__ wsid) {
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2];
+    // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
+    // (two fill kernels, ~10 us) in front of every call
+    if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
+    if (threadIdx.x < MAX_PLANS) { cnt[threadIdx.x] = 0; mx[threadIdx.x] = 0; }
+    if (threadIdx.x < 4) open_of[threadIdx.x] = 0;
+    if (threadIdx.x < 2) events_of[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
+    // four reads per thread and round: their offsets, then their first two words, are requested together
+    // (one read after the other, every read cost its thread three memory round trips in a row)
+    for (uint32_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4 * blockDim.x) {
+      uint32_t so4[4], k4[4], fw[4][2];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+          const uint32_t r = r0 + u * blockDim.x;
+          so4[u] = r < hi ? read_off[r] : 0u;
+          k4[u] = r < hi ? read_off[r + 1] - so4[u] : 0u;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++)
+#pragma unroll
+          for (uint32_t j = 0; j < 2; j++) fw[u][j] = k4[u] > j ? read_word[so4[u] + j] : 0u;
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t r = r0 + u * blockDim.x;
+        if (r >= hi) break;
+        const uint32_t so = so4[u], k = k4[u];
+        int c = 0;
+        auto count = [&](uint32_t sw) { if (!rw_missing(sw)) c += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0; };
+        if (k > 0) count(fw[u][0]);
+        if (k > 1) count(fw[u][1]);
+        for (uint32_t j = 2; j < k; j++) count(read_word[so + j]);
+        const uint32_t n_hard = (uint32_t)c;   // entries whose alleles exclude their reference base (seed_kernels.hip)
+        for (uint32_t w = m.node_woff[0]; w < m.node_woff[1]; w++) {   // the root's own mutations
+            const uint32_t tw = m.words[w];
+            const uint32_t sw = find_entry(read_word, so, k, w_pos(tw));
+            if (sw != NONE) c += enter_delta(tw, sw);
+        }
+        root_score[r] = m.root_base + c;       // the root always competes: an upper bound of the best score
+        const int theta = m.root_base + c + (int)k;
+        uint32_t t = m.n_streams - 1;
+        if (use_crowns)
+            for (uint32_t i = 0; i + 1 < m.n_streams; i++)
+                if (theta <= m.tau[i]) { t = i; break; }
+        // how the read is placed (device_mat.hpp): by walking its own events when it lists few positions and
+        // the intervals it can hold open at once fit the walk's stack, by a sweep of the stream otherwise
+        // A walk runs a read's events one after the other: reads with many events in their stream (a
+        // frequently mutated position) are left to the sweeps, whose cost does not depend on it.
+        uint32_t cls = PLAN_SWEEP;
+        // how a read with at most WALK16_K entries would walk a stream whose position index starts at (ix_head,
+        // ix_nest): plain, cut into jobs, or not at all (more open intervals than a walk's stack holds)
+        auto classify = [&](const IxHead* ix_head, const uint8_t* ix_nest, uint32_t& nj_out, uint32_t& open_out, uint32_t& ev_out) -> uint32_t {
+            uint32_t open_max = 0, events = 0, longest = 0;
+            for (uint32_t j = 0; j < k; j++) {
+                const uint32_t p = w_pos(j < 2 ? fw[u][j] : read_word[so + j]);
+                if (p <= m.max_pos) {
+                    open_max += (uint32_t)ix_nest[p];
+                    const uint32_t len = ix_head[p + 1].off - ix_head[p].off - 1u;      // (every list ends in a sentinel)
+                    events += len;
+                    longest = max(longest, len);
+                }
+            }
+            open_out = open_max;
+            ev_out = events;
+            nj_out = 0;
+            // (stack8 <= WALK8_STACK, stack16 <= WALK16_STACK: the stack rows the walks' workgroups get; the few
+            // reads that could hold more intervals open are left to the sweeps)
+            if (events <= walk_max_events) {
+                if (k <= WALK8_K && open_max <= stack8) return PLAN_WALK8;
+                if (open_max <= stack16) return PLAN_WALK16;
+                return PLAN_SWEEP;
+            }
+            if (open_max > stack16) return PLAN_SWEEP;
+            // many events: jobs of about `job_events`, cut at quantiles of the longest list
+            const uint32_t small = (k <= WALK8_K && open_max <= stack8) ? 1u : 0u;
+            const uint32_t je = small ? (job_events & 0xFFFFu) : (job_events >> 16);   // (per class, capi.cpp)
+            nj_out = min((events + je - 1) / je, longest);
+            return small ? PLAN_WALKC8 : PLAN_WALKC16;
+        };
+        // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
+        // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
+        uint32_t sid = NONE, wi = 0;
+        bool in_win = false;                   // all listed positions inside genome window wi
+        if (use_crowns && k > 0) {
+            const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
+            wi = p_lo / WIN_STRIDE;
+            in_win = p_hi < wi * WIN_STRIDE + WIN_SIZE;
+            if (in_win && wi < m.wc_windows) {
+                const int rs = m.root_base + c;
+                for (uint32_t i = 0; i < WC_MAX; i++) {
+                    const WcInfo* q = m.wc_info + wi * WC_MAX + i;
+                    const uint32_t qn = q->n;
+                    if (!qn) break;
+                    if (rs <= q->tau) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
+                }
+            }
+        }
+        if (walk_max_events && k <= WALK16_K) {
+            uint32_t nj = 0, open_max = 0, events = 0;
+            if (sid != NONE) {
+                const WcInfo* q = m.wc_info + sid;
+                const DevWalk& ar = m.walks[WC_SLOT];
+                cls = classify(ar.ix_head + q->head_off, ar.ix_nest + q->nest_off, nj, open_max, events);
+                if (cls != PLAN_SWEEP) { wsid[r] = sid; t = WC_SLOT; }
+            }
+            if (cls == PLAN_SWEEP) cls = classify(m.walks[t].ix_head, m.walks[t].ix_nest, nj, open_max, events);
+            if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
+                // the deepest stack a walk of the class can need in this call: its kernel's LDS request
+                atomicMax(&open_of[cls], open_max);
+            } else if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
+                const uint32_t small = cls == PLAN_WALKC8 ? 1u : 0u;
+                job_n[r] = nj;
+                atomicAdd(&events_of[small ? 0 : 1], events);
+                atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
+                atomicMax(&open_of[small ? 2 : 3], open_max);
+            }
+        }
+        // (use_crowns & 2 -- wepp_best_nodes, which lists nodes and so takes streams of real nodes only: every read
+        // inside a window whose stream is the window's candidate crown takes it when it is the smaller one)
+        if (cls == PLAN_SWEEP && in_win && wi < m.n_windows &&
+            ((use_crowns & 2) ? m.win_n[wi] < m.walks[t].n
+                              : k > WIN_MIN_ENTRIES ? (m.win_n[wi] < m.walks[t].n || t + 1 == m.n_streams) : (sid == NONE && t + 1 == m.n_streams))) {
+            // many entries, all inside one genome window: a tile of such reads sweeps the window's stream -- the window's
+            // candidates (a crown of a few thousand nodes, whatever the root score) or, for the reads no crown serves,
+            // the whole tree as the window sees it
+            cls = PLAN_WIN;
+            t = wi;
+        } else if (cls == PLAN_SWEEP && sid != NONE) {
+            // it cannot walk (more than WALK16_K entries or too deep a stack): waves of its own sweep its window crown (k_sweep_arena)
+            wsid[r] = sid;
+            t = WC_SLOT;
+        } else if (cls == PLAN_SWEEP && n_hard >= seed_min_hard && m.seed_chunks && k <= SEED_MAX_ENTRIES && m.walks[t].n >= seed_min_nodes) {
+            // a whole-genome sample (no window holds it, too many entries to walk): the chunk signatures rule out nearly
+            // all of the tree for it, whatever its tree-wide bound admits (seed_kernels.hip)
+            cls = PLAN_SEED;
+            t = 0;
+        }
+        t = plan_id(cls, t);
+        tier_of[r] = (uint8_t)t;
+        slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the plan (k_scatter)
+        atomicMax(&mx[t], k);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_PLANS) {
+        blk_counts[blockIdx.x * MAX_PLANS + threadIdx.x] = cnt[threadIdx.x];
+        if (cnt[threadIdx.x]) {
+            atomicAdd(&tier_info[TI_COUNT + threadIdx.x], cnt[threadIdx.x]);
+            atomicMax(&tier_info[TI_MAXK + threadIdx.x], mx[threadIdx.x]);
+        }
+    }
+    if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
+    if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
+    if (threadIdx.x < 2 && events_of[threadIdx.x]) atomicAdd(&tier_info[TI_EVENTS + threadIdx.x], (events_of[threadIdx.x] + 63) >> 6);
+}
+
+// -----------------------------------------------------------------------------
+// k_scatter: list[] = read indices grouped by tier (same block decomposition as
+// k_route; a block's reads of one tier occupy a contiguous range).
+// -----------------------------------------------------------------------------
+__global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __restrict__ tier_of,
+                                                            const uint32_t* __restrict__ slot_in_blk, uint32_t n_reads,
+                                                            const uint32_t* __restrict__ blk_counts,
+                                                            uint32_t* __restrict__ tier_info,
+                                                            uint32_t* __restrict__ list) {
+    __shared__ uint32_t base[MAX_PLANS], before[MAX_PLANS];
+    if (threadIdx.x < MAX_PLANS) before[threadIdx.x] = 0;
+    __syncthreads();
+    // reads of every tier in the blocks before this one: thread = (tier, one earlier block in 64), so that a
+    // wave's sixteen-lane groups read whole 64-byte rows and only four lanes of a wave add to the same LDS
+    // word (one thread per row with sixteen adds each serialised 64 lanes on every word)
+    {
+        const uint32_t t = threadIdx.x & (MAX_PLANS - 1), c0 = threadIdx.x / MAX_PLANS;
+        uint32_t acc = 0;
+        for (uint32_t b = c0; b < blockIdx.x; b += blockDim.x / MAX_PLANS) acc += blk_counts[b * MAX_PLANS + t];
+        if (acc) atomicAdd(&before[t], acc);
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_PLANS) {
+        const uint32_t t = threadIdx.x;
+        uint32_t off = 0;                       // start of plan t in the list
+        for (uint32_t i = 0; i < t; i++) off += tier_info[TI_COUNT + i];
+        base[t] = off + before[t];
+        if (blockIdx.x == 0) {
+            tier_info[TI_OFF + t] = off;
+            if (t == MAX_PLANS - 1) tier_info[TI_OFF + MAX_PLANS] = off + tier_info[TI_COUNT + t];
+        }
+    }
+    __syncthreads();
+    const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
+    // no atomics here.  Four reads per thread and round: their loads are issued together (a thread's
+    // reads used to cost it one memory round trip after the other: 28 us per 1 M reads)
+    for (uint32_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4 * blockDim.x) {
+        uint32_t t[4], sl[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * blockDim.x;
+            t[u] = r < hi ? tier_of[r] : 0u;
+            sl[u] = r < hi ? slot_in_blk[r] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * blockDim.x;
+            if (r < hi) list[base[t[u]] + sl[u]] = r;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// k_first_pos: sort key of the reads of one stream's list = first listed position (reads that
+// list nothing first).  Sorted by it, the reads of a tile list the same or neighbouring
+// positions: the tile looks at an event of the stream once per DISTINCT position, every read
+// that lists it takes the delta in the same instructions, and equal reads are evaluated once.
+// -----------------------------------------------------------------------------
+__global__ void k_first_pos(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ read_off,
+                            const uint32_t* __restrict__ read_word, uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = list[i], so = read_off[r];
+    keys[i] = (read_off[r + 1] > so) ? w_pos(read_word[so]) + 1u : 0u;
+}
+
+// sort key of the reads of a walk class's list: (stream, first listed position) -- the list is grouped by stream
+// already (plan ids ascend), so a sort by this key reorders the reads inside every stream's range only
+__global__ void k_walk_keys(const uint32_t* __restrict__ list, uint32_t n, const uint8_t* __restrict__ tier_of,
+                            const uint32_t* __restrict__ read_off, const uint32_t* __restrict__ read_word,
+                            uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = list[i], so = read_off[r];
+    const uint32_t first = (read_off[r + 1] > so) ? w_pos(read_word[so]) + 1u : 0u;
+    keys[i] = (plan_index(tier_of[r]) << SORT_KEY_BITS) | first;
+}
+
+// -----------------------------------------------------------------------------
+// launchers (called from capi.cpp)
+// -----------------------------------------------------------------------------
+hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
+                        int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
+                        uint32_t seed_min_hard, uint32_t seed_min_nodes, uint32_t* job_n, uint8_t* tier_of,
+                        int32_t* root_score, uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk,
+                        uint32_t* tier_info_next, uint32_t* wsid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
+                       n_reads, use_crowns, walk_max_events, job_events, std::min(stack8, WALK8_STACK), std::min(stack16, WALK16_STACK),
+                       seed_min_hard, seed_min_nodes, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next, wsid);
+    return hipGetLastError();
+}
+
+hipError_t launch_first_pos(const uint32_t* list, uint32_t n, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                            uint32_t* keys, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_first_pos, dim3((n + 255) / 256), dim3(256), 0, stream, list, n, d_read_off, d_read_word, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_keys(const uint32_t* list, uint32_t n, const uint8_t* tier_of, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, uint32_t* keys, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_walk_keys, dim3((n + 255) / 256), dim3(256), 0, stream, list, n, tier_of, d_read_off, d_read_word, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(const uint8_t* tier_of, const uint32_t* slot_in_blk, uint32_t n_reads, const uint32_t* blk_counts,
+                          uint32_t* tier_info, uint32_t* list, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scatter, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, tier_of, slot_in_blk, n_reads,
+                       blk_counts, tier_info, list);
+    return hipGetLastError();
+}
+
+}  // namespace wepp

@@ -1,5 +1,5 @@
 // sort_reads.hip -- orders the reads that sweep the whole-tree stream by first listed position
-// (keys from k_first_pos, place_kernels.hip) with rocPRIM's device radix sort, a library
+// (keys from k_first_pos, route_kernels.hip) with rocPRIM's device radix sort, a library
 // primitive.  Only used when that stream holds enough reads for a sweep to cost more than the sort.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
