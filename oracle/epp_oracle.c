@@ -27,6 +27,7 @@
  *   constants               config.hpp:9,13,14,18
  */
 #include <limits.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -361,12 +362,29 @@ static void fill_reads(oread *reads, omut *pool, uint32_t n_reads, const uint32_
  * hap_score[N], hap_counts[N*50], hap_divergence[N] (:224-233).  node_mapped may be NULL.
  * Returns 0, -1 when a read fits no window (assert in the reference), -2 on bad arguments.
  */
-int oracle_epp_map(const otree *T, int genome_size, uint32_t n_reads, const uint32_t *read_off, const int32_t *r_pos,
-                   const uint8_t *r_ref, const uint8_t *r_mut, const int32_t *r_start, const int32_t *r_end,
-                   const int32_t *r_degree, const uint8_t *node_mapped, int32_t *max_parsimony,
-                   uint32_t *multiplicity, uint64_t *epp_off, uint32_t *epp_nodes, uint64_t epp_capacity,
-                   double *hap_score, int32_t *hap_counts, double *hap_divergence) {
+/* the per-read part of the loop below (single_read_tree only reads the arena) for reads [lo, hi), strided over threads */
+typedef struct { oarena *A; const oread *reads; uint32_t lo, hi; int tid, nthreads; ivec *idx; int *val; int rc; } epp_job;
+static void *epp_worker(void *p) {
+    epp_job *j = (epp_job *)p;
+    for (uint32_t r = j->lo + (uint32_t)j->tid; r < j->hi; r += (uint32_t)j->nthreads) {
+        ivec *v = &j->idx[r - j->lo];
+        v->n = 0;
+        j->val[r - j->lo] = INT32_MAX;
+        if (single_read_tree(j->A, &j->reads[r], v, &j->val[r - j->lo]) != 0) j->rc = -1;
+    }
+    return NULL;
+}
+
+/* nthreads > 1 (test infrastructure at full size: a 16 M-node arena places ~4 reads/s on one core): the reads of a
+ * block of `nthreads` are walked in parallel, their results folded in in read order -- the same additions in the same
+ * order as the serial loop. */
+int oracle_epp_map_mt(const otree *T, int genome_size, uint32_t n_reads, const uint32_t *read_off, const int32_t *r_pos,
+                      const uint8_t *r_ref, const uint8_t *r_mut, const int32_t *r_start, const int32_t *r_end,
+                      const int32_t *r_degree, const uint8_t *node_mapped, int32_t *max_parsimony,
+                      uint32_t *multiplicity, uint64_t *epp_off, uint32_t *epp_nodes, uint64_t epp_capacity,
+                      double *hap_score, int32_t *hap_counts, double *hap_divergence, int nthreads) {
     if (genome_size < NUM_RANGE_BINS) return -2;
+    if (nthreads < 1) nthreads = 1;
     oarena *A = arena_new(T, genome_size);
     oread *reads = (oread *)calloc(n_reads ? n_reads : 1, sizeof(oread));
     omut *pool = (omut *)calloc(read_off[n_reads] ? read_off[n_reads] : 1, sizeof(omut));
@@ -377,11 +395,24 @@ int oracle_epp_map(const otree *T, int genome_size, uint32_t n_reads, const uint
     int rc = 0;
     uint64_t ecur = 0;
     epp_off[0] = 0;
-    ivec max_indices = {0, 0, 0};
+    ivec *blk_idx = (ivec *)calloc((size_t)nthreads, sizeof(ivec));
+    int *blk_val = (int *)calloc((size_t)nthreads, sizeof(int));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    epp_job *jobs = (epp_job *)calloc((size_t)nthreads, sizeof(epp_job));
     for (uint32_t r = 0; r < n_reads && rc == 0; r++) {
-        max_indices.n = 0;
-        int max_val = INT32_MAX;
-        if (single_read_tree(A, &reads[r], &max_indices, &max_val) != 0) { rc = -1; break; }
+        if (r % (uint32_t)nthreads == 0) {
+            const uint32_t hi = r + (uint32_t)nthreads < n_reads ? r + (uint32_t)nthreads : n_reads;
+            for (int t = 0; t < nthreads; t++) jobs[t] = (epp_job){A, reads, r, hi, t, nthreads, blk_idx, blk_val, 0};
+            if (nthreads == 1) epp_worker(&jobs[0]);
+            else {
+                for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, epp_worker, &jobs[t]);
+                for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+            }
+            for (int t = 0; t < nthreads; t++) if (jobs[t].rc) rc = -1;
+            if (rc) break;
+        }
+        ivec max_indices = blk_idx[r % (uint32_t)nthreads];
+        const int max_val = blk_val[r % (uint32_t)nthreads];
         double delta = (double)reads[r].degree / ((1 + max_val) * max_indices.n);   /* initial_filter.hpp:54-57 */
         int bucket = reads[r].start / bin_size;
         if (bucket > NUM_RANGE_BINS - 1) bucket = NUM_RANGE_BINS - 1;
@@ -412,9 +443,19 @@ int oracle_epp_map(const otree *T, int genome_size, uint32_t n_reads, const uint
         if (hap_divergence) hap_divergence[i] = (double)divergence / bins_active;
         if (hap_counts) memcpy(hap_counts + (size_t)i * NUM_RANGE_BINS, A->nodes[i].mapped_read_counts, sizeof(int) * NUM_RANGE_BINS);
     }
-    free(max_indices.v); free(pool); free(reads);
+    for (int t = 0; t < nthreads; t++) free(blk_idx[t].v);
+    free(blk_idx); free(blk_val); free(th); free(jobs); free(pool); free(reads);
     arena_free(A);
     return rc;
+}
+
+int oracle_epp_map(const otree *T, int genome_size, uint32_t n_reads, const uint32_t *read_off, const int32_t *r_pos,
+                   const uint8_t *r_ref, const uint8_t *r_mut, const int32_t *r_start, const int32_t *r_end,
+                   const int32_t *r_degree, const uint8_t *node_mapped, int32_t *max_parsimony,
+                   uint32_t *multiplicity, uint64_t *epp_off, uint32_t *epp_nodes, uint64_t epp_capacity,
+                   double *hap_score, int32_t *hap_counts, double *hap_divergence) {
+    return oracle_epp_map_mt(T, genome_size, n_reads, read_off, r_pos, r_ref, r_mut, r_start, r_end, r_degree, node_mapped,
+                             max_parsimony, multiplicity, epp_off, epp_nodes, epp_capacity, hap_score, hap_counts, hap_divergence, 1);
 }
 
 /* haplotype.hpp:123-173: mutation_distance(comp = read.mutations, min_pos = start, max_pos = end) */

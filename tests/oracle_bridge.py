@@ -53,6 +53,8 @@ def lib():
         L.oracle_place_batch_nodepar.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         L.oracle_epp_map.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32] + [ctypes.c_void_p] * 12 + [
             ctypes.c_uint64] + [ctypes.c_void_p] * 3
+        L.oracle_epp_map_mt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32] + [ctypes.c_void_p] * 12 + [
+            ctypes.c_uint64] + [ctypes.c_void_p] * 3 + [ctypes.c_int]
         L.oracle_epp_distance.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [
             ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.inc_tree_build.restype = ctypes.c_void_p
@@ -179,9 +181,11 @@ class OracleTree:
                                                  ("best_node_id", "<i4"), ("has_unique", "<u4")]), count=R).copy()
         return arr
 
-    def epp_map(self, reads, genome_size, node_mapped=None):
+    def epp_map(self, reads, genome_size, node_mapped=None, nthreads=1, want_counts=True):
         """wepp_filter::cartesian_map (src/WEPP/initial_filter.cpp:140-239) for a wepp_amd.EppReads
-        batch.  Haplotype indices are pre-order (arena) indices."""
+        batch.  Haplotype indices are pre-order (arena) indices.  nthreads > 1: the reads of a block are walked in
+        parallel and folded in in read order (same sums in the same order); want_counts=False leaves out the
+        [n_nodes, 50] read-count array (3.2 GB at 16 M nodes)."""
         from wepp_amd import unpack_read_word
         R = reads.n_reads
         pos, ref, mut, _ = unpack_read_word(reads.read_word)
@@ -192,12 +196,14 @@ class OracleTree:
         eoff = np.zeros(R + 1, np.uint64)
         cap = 2048 * max(R, 1)
         enodes = np.zeros(cap, np.uint32)
-        score = np.zeros(self.n, np.float64); counts = np.zeros((self.n, 50), np.int32)
+        score = np.zeros(self.n, np.float64)
+        counts = np.zeros((self.n, 50), np.int32) if want_counts else None
         div = np.zeros(self.n, np.float64)
         nm = None if node_mapped is None else np.ascontiguousarray(node_mapped, np.uint8)
-        rc = lib().oracle_epp_map(self._h, int(genome_size), R, _p(reads.read_off), _p(pos), _p(ref), _p(mut),
-                                  _p(reads.start), _p(reads.end), _p(reads.degree), _p(nm) if nm is not None else None,
-                                  _p(mp), _p(mult), _p(eoff), _p(enodes), cap, _p(score), _p(counts), _p(div))
+        rc = lib().oracle_epp_map_mt(self._h, int(genome_size), R, _p(reads.read_off), _p(pos), _p(ref), _p(mut),
+                                     _p(reads.start), _p(reads.end), _p(reads.degree), _p(nm) if nm is not None else None,
+                                     _p(mp), _p(mult), _p(eoff), _p(enodes), cap, _p(score),
+                                     _p(counts) if want_counts else None, _p(div), int(nthreads))
         if rc != 0:
             raise ValueError("oracle_epp_map failed: %d" % rc)
         return dict(max_parsimony=mp[:R], multiplicity=mult[:R], epp_off=eoff, epp_nodes=enodes[: int(eoff[R])],

@@ -592,6 +592,26 @@ def test_full_size_nrich_and_long_shard():
     print("full-size N-rich / long-shard report:", json.dumps(rep))
 
 
+def test_full_size_genome_samples_epp_fitch():
+    """The three paths whose speeds are quoted at 16 M nodes, oracle-checked at 16 M nodes (tests/full_size_more.py, a
+    child process with the product's defaults): whole-genome samples through the seeded path -- every 4th of 2 400
+    against the incremental checker, 4 against the faithful restatement, best_j_vec of 50, seeds off, work skipping
+    off --; wepp_epp_map -- 300+ of 20 000 reads against oracle_epp_map, run-to-run identity --; wepp_fitch_plan_run --
+    64 rows against oracle_mapper_body."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "WEPP_IX_PRE_MIN_NODES"}
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "full_size_more.py")
+    run = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    rep = json.loads(run.stdout.strip().splitlines()[-1])
+    assert rep["nodes"] == 16_000_000
+    assert sum(leg["checked_incremental"] for leg in rep["whole_genome_samples"]["legs"]) >= 600
+    assert all(leg["chunks_evaluated_per_sample"] < leg["chunks"] / 100 for leg in rep["whole_genome_samples"]["legs"])
+    assert rep["epp"]["checked_against_oracle"] >= 300 and rep["fitch"]["rows"] >= 64
+    print("full-size genome samples / EPP / Fitch report:", json.dumps(rep))
+
+
 def test_window_crowns_walks_and_sweeps_vs_oracle(oracle):
     """Window crowns (include/wepp_place.h: wepp_mat_last_crowns): reads confined to a genome window are placed on the
     crown of their window that their ROOT score admits -- by a walk when they list at most 16 positions, by a sweep of

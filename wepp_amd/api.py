@@ -14,8 +14,8 @@ from ._lib import lib, check
 
 A, C, G, T, N = 1, 2, 4, 8, 15  # nucleotide masks, src/mutation_annotated_tree.cpp:19-74
 # how a read was placed (include/wepp_place.h WEPP_PLAN_*, Mat.last_plans)
-PLAN_WALK8, PLAN_WALK16, PLAN_SWEEP, PLAN_WALKC8, PLAN_WALKC16, PLAN_WIN = range(6)
-PLAN_NAMES = ("walk8", "walk16", "sweep", "walkc8", "walkc16", "window")
+PLAN_WALK8, PLAN_WALK16, PLAN_SWEEP, PLAN_WALKC8, PLAN_WALKC16, PLAN_WIN, PLAN_SEED = range(7)
+PLAN_NAMES = ("walk8", "walk16", "sweep", "walkc8", "walkc16", "window", "seed")
 WINDOW_CROWN_LEVELS = 7  # crowns per genome window at most (flatmat.hpp: WC_MAX; FlatView 'wc_tau' / 'wc_nodes' rows)
 WINDOW_CROWN_SLOT = 15   # stream slot of the window crowns in Mat.last_plans / last_tiers (Mat.last_crowns tells which crown)
 
