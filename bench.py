@@ -30,7 +30,8 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 (per XCD 4 MiB) ~34.5 TB/s aggr
 N_CUS = 256            # MI355X_MICROARCH.md chip-level parameters
 MAX_CLOCK_GHZ = 2.4    # max clock; a CU issues at most one vector instruction per cycle (4 SIMDs, one per 4 cycles)
 VALU_ISSUE_PEAK = N_CUS * MAX_CLOCK_GHZ   # G wave-instructions / s
-KERNEL_SOURCES = ("place_kernels.hip", "device_mat.hpp", "flatmat.hpp", "flatmat.cpp", "capi.cpp", "sort_reads.hip")
+KERNEL_SOURCES = ("place_dev.hpp", "route_kernels.hip", "sweep_kernels.hip", "walk_kernels.hip", "seed_kernels.hip", "device_mat.hpp",
+                  "flatmat.hpp", "flatmat.cpp", "capi.cpp", "sort_reads.hip")
 
 
 def kernel_hash():
@@ -72,6 +73,12 @@ def parse():
                     help="distinct read batches (all resident in HBM) the timed loop rotates over")
     ap.add_argument("--p-n", type=float, default=None, help="per-base N rate of the synthetic reads (default 0.005 "
                     "for 150 bp reads, SURVEY 8(d) config 2/3; 0.02 for long reads, config 5)")
+    ap.add_argument("--workload", choices=("reads", "genome"), default="reads",
+                    help="genome: the timed batches are whole-genome samples (what read_vcf makes of consensus genomes; "
+                         "--reads of them per step) instead of amplicon reads")
+    ap.add_argument("--no-legs", action="store_true", help="skip the legs of the other configs (configs[3] shard, configs[4] "
+                    "long reads, whole-genome samples) and the tree-shape ladder")
+    ap.add_argument("--ladder-nodes", type=int, default=4_000_000, help="nodes of the tree-shape ladder's trees (0 disables it)")
     return ap.parse_args()
 
 
@@ -94,7 +101,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(tree, reads, gpu_res, target_s):
+def cpu_baseline(tree, reads, gpu_res, target_s, ot=None, inc=None):
     """Oracle (CPU restatement of the reference loop) on a bounded sample of the
     same reads; the NODE range is split over all usable host threads, which is
     how the reference parallelises a sample (tbb::parallel_for,
@@ -102,7 +109,8 @@ def cpu_baseline(tree, reads, gpu_res, target_s):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bridge
     cores = usable_cores()
-    ot = oracle_bridge.OracleTree(tree)
+    if ot is None:
+        ot = oracle_bridge.OracleTree(tree)
     t0 = time.perf_counter()
     ot.place_batch(reads.slice(0, 1), nthreads=cores, node_parallel=True)   # probe: sizes the sample
     t1 = time.perf_counter() - t0
@@ -118,7 +126,8 @@ def cpu_baseline(tree, reads, gpu_res, target_s):
     # of reads instead of one evaluation per (read, node); proven equal to the faithful one by tests/test_incremental.py)
     # on a larger sample, reads split over the threads -- what a CPU can do once the per-node loop of the reference is
     # given up, a fairer yardstick for a throughput claim than the faithful loop
-    inc = ot.incremental()
+    if inc is None:
+        inc = ot.incremental()
     n2 = int(min(reads.n_reads, 4096))
     t0 = time.perf_counter()
     want2 = inc.place_batch(reads.slice(0, n2), nthreads=cores)
@@ -244,6 +253,136 @@ def truncate_reads(w, reads, k):
     return w.Reads((np.arange(len(sel) + 1) * k).astype(np.uint32), reads.read_word[idx])
 
 
+GENOME_LEN = 29903
+LADDER = (   # tree shapes of the ladder (wepp_place.h: wepp_gen_tree_params): what the default tree is a best case of
+    ("default shape", {}),
+    ("paths ~3x longer (parent = the deeper of 2 draws)", {"depth_choices": 2}),
+    ("paths ~5x longer (deepest of 3 draws)", {"depth_choices": 3}),
+    ("10 % back-mutations", {"p_back_mutation": 0.10}),
+    ("star-like: half of the nodes hang off ~1000 hubs (polytomies of ~2000 children)", {"p_hub": 0.5}),
+    ("deep and bushy: deepest of 3 draws, 30 % on hubs", {"depth_choices": 3, "p_hub": 0.3}),
+)
+
+
+def genome_samples(g, seed, n, p_sub=0.001, p_n=0.0005):
+    """Whole-genome samples: a leaf's genotype over the whole genome with substitution errors and Ns -- what read_vcf
+    (src/mutation_annotated_tree.cpp:2033-2130) makes of a consensus genome: ~20 true + ~30 erroneous alleles + ~15 Ns."""
+    return g.reads(seed, n, read_len=GENOME_LEN, amplicon_len=GENOME_LEN, amplicon_step=GENOME_LEN, p_substitution=p_sub, p_n=p_n)
+
+
+def long_reads_batch(g, seed, n):
+    return g.reads(seed, n, read_len=1200, amplicon_len=1200, amplicon_step=1020, p_substitution=0.03, p_n=0.02)
+
+
+def matches(want, out, n):
+    """the checker's structured results against the first n entries of a DeviceBatch's output tensors"""
+    return bool((want["score"] == out[1][:n].cpu().numpy()).all() and (want["best_j"] == out[0][:n].cpu().numpy().view(np.uint32)).all()
+                and (want["num_best"] == out[2][:n].cpu().numpy().view(np.uint32)).all()
+                and (want["has_unique"] == (out[3][:n].cpu().numpy().view(np.uint32) & 1)).all())
+
+
+def run_leg(torch, mat, dev, stream, label, mode, host_batches, steps, pcie_steps, checker=None, n_check=256):
+    """One workload on the resident MAT: device-resident rate over `steps` placements rotating over the batches,
+    PCIe-inclusive rate (wepp_place_batch from host buffers), the contract-shaped roofline of its placement kernels,
+    and the first reads of batch 0 against the incremental CPU checker."""
+    batches = [DeviceBatch(torch, rd, dev) for rd in host_batches]
+    for b in batches:                     # set-up: the handle's grow-only workspaces reach their size
+        b.place(mat, stream)
+    torch.cuda.synchronize()
+    mat.timing_reset()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        batches[i % len(batches)].place(mat, stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sweep_ms, n_launch, passes, alg_bytes = mat.last_timing()
+    seeds = mat.last_seeds(detail=True)
+    batches[0].place(mat, stream)
+    torch.cuda.synchronize()
+    R = batches[0].R
+    pcls, _ = mat.last_plans(R)
+    roof, cands = sweep_roofline(mode, R, sweep_ms, alg_bytes, passes, n_launch)
+    out = {"leg": label, "reads_per_step": R, "mean_entries": batches[0].nw / max(1, R), "distinct_batches": len(batches), "steps": steps,
+           "reads_per_s": R / dt, "ms_per_step": dt * 1e3,
+           "reads_by_plan_class": {PLAN_NAMES[c]: int(k) for c, k in enumerate(np.bincount(pcls, minlength=7)) if k},
+           "roofline": roof, "roofline_candidates": cands}
+    if seeds[0]:
+        out["seeded"] = {"samples_per_step": seeds[0] // steps, "chunks_evaluated_per_sample": seeds[1] / seeds[0],
+                         "chunks_of_the_tree": seeds[2] // seeds[0], "most_chunks_one_sample": seeds[3],
+                         "samples_by_chunks_le_1_4_16_64_256_1024_4096_more": [int(x) // steps for x in seeds[4]]}
+    if pcie_steps:
+        hres = mat.place_batch(host_batches[0])
+        t0 = time.perf_counter()
+        for i in range(pcie_steps):
+            hres = mat.place_batch(host_batches[(i + 1) % len(host_batches)], out=hres)
+        dtp = (time.perf_counter() - t0) / pcie_steps
+        out["pcie_inclusive_reads_per_s"] = R / dtp
+        out["pcie_inclusive_ms_per_step"] = dtp * 1e3
+    if checker is not None:
+        n = min(n_check, R)
+        t0 = time.perf_counter()
+        want = checker.place_batch(host_batches[0].slice(0, n), nthreads=usable_cores())
+        out["sample_matches_gpu"] = matches(want, batches[0].out, n)
+        out["sample"] = f"first {n} reads of the leg's first batch against oracle/incremental_oracle.c, {time.perf_counter() - t0:.1f} s"
+    return out
+
+
+PLAN_NAMES = ("walk8", "walk16", "sweep", "walkc8", "walkc16", "window", "seed")
+
+
+def ladder_prepare(w, nodes, label, kw, want_checker):
+    """Host side of one ladder entry (runs in a background thread: the ctypes calls release the GIL): the tree, its
+    shape, its flat image, the two batches, and the checker's results for the first reads of each."""
+    t0 = time.perf_counter()
+    g = w.generate_tree(21, nodes, **kw)
+    shape = g.shape()
+    short = g.reads(22, 1_000_000, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.001, p_n=0.005)
+    longr = long_reads_batch(g, 24, 50_000)
+    t1 = time.perf_counter()
+    flat = w.FlatView(g.tree)
+    t_flat = time.perf_counter() - t1
+    want = None
+    if want_checker:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_bridge
+        ot = oracle_bridge.OracleTree(g.tree)
+        inc = ot.incremental()
+        want = (inc.place_batch(short.slice(0, 256), nthreads=4), inc.place_batch(longr.slice(0, 64), nthreads=4))
+        inc.close()
+        ot.close()
+    return {"label": label, "params": kw, "g": g, "shape": shape, "short": short, "long": longr, "flat": flat,
+            "flatten_s": t_flat, "host_s": time.perf_counter() - t0, "want": want}
+
+
+def ladder_measure(torch, w, dev, stream, prep):
+    """Device side of one ladder entry: upload, the default batch and the long-read batch, crown / candidate sizes."""
+    mat = w.Mat(prep["g"].tree, device=dev.index, flat=prep["flat"])
+    prep["flat"].close()
+    st = mat.stats
+    out = {"tree": prep["label"], "generator": prep["params"], "shape": prep["shape"], "flatten_s": round(prep["flatten_s"], 1),
+           "streams_nodes": [int(st.stream_nodes[i]) for i in range(st.n_streams)],
+           "window_crowns": int(st.n_window_crowns), "window_crown_nodes": int(st.window_crown_nodes),
+           "window_streams_that_are_candidate_crowns": int(st.n_window_streams_crown), "window_streams": int(st.n_window_streams),
+           "window_stream_elements": int(st.window_stream_nodes), "seed_chunks": int(st.seed_chunks), "device_bytes": int(st.device_bytes)}
+    for key, rd, nchk, k in (("default_batch", prep["short"], 256, 0), ("long_reads", prep["long"], 64, 1)):
+        b = DeviceBatch(torch, rd, dev)
+        b.place(mat, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            b.place(mat, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        pc, _ = mat.last_plans(rd.n_reads)
+        out[key] = {"reads": rd.n_reads, "mean_entries": b.nw / rd.n_reads, "reads_per_s": rd.n_reads / dt, "ms_per_step": dt * 1e3,
+                    "reads_by_plan_class": {PLAN_NAMES[c]: int(n) for c, n in enumerate(np.bincount(pc, minlength=7)) if n}}
+        if prep["want"] is not None:
+            out[key]["sample_matches_gpu"] = matches(prep["want"][k], b.out, nchk)
+    mat.close()
+    prep["g"].close()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,20 +405,31 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- synthetic workload (identical tree on every rank, per-rank reads) ----
-    long_reads = args.read_len > 400
+    genome = args.workload == "genome"
+    long_reads = args.read_len > 400 and not genome
     t0 = time.perf_counter()
+    # the tree-shape ladder's host work (trees, flat images, batches, checker results) runs in background threads from
+    # the start: it is ready when the main workload has been measured
+    ladder_jobs = None
+    if rank == 0 and world == 1 and not args.no_legs and not args.no_crowns and args.ladder_nodes > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        ladder_pool = ThreadPoolExecutor(max_workers=3)
+        want_chk = not args.no_cpu_baseline
+        ladder_jobs = [ladder_pool.submit(ladder_prepare, w, args.ladder_nodes, label, kw, want_chk) for label, kw in LADDER]
     g = w.generate_tree(21, args.nodes)
     amp_len, amp_step = (args.read_len, int(args.read_len * 0.85)) if long_reads else (400, 300)
     p_sub = 0.03 if long_reads else 0.001
-    p_n = args.p_n if args.p_n is not None else (0.02 if long_reads else 0.005)
+    p_n = args.p_n if args.p_n is not None else (0.0005 if genome else 0.02 if long_reads else 0.005)
 
     def gen_reads(seed, n, pn=p_n):
+        if genome:
+            return genome_samples(g, seed, n, p_sub, pn)
         return g.reads(seed, n, read_len=args.read_len, amplicon_len=amp_len, amplicon_step=amp_step,
                        p_substitution=p_sub, p_n=pn)
 
     # the timed loop rotates over N_BATCHES distinct batches, all resident in HBM (seeds 22 + 8 * rank + i: rank 0 places
     # seeds 22 .. 29): no step finds the index lines and the routing of the step before it in the caches
-    seed0 = (24 if long_reads else 22) + args.batches * rank
+    seed0 = (900 if genome else 24 if long_reads else 22) + args.batches * rank
     batches_host = [gen_reads(seed0 + i, args.reads) for i in range(args.batches)]
     reads = batches_host[0]
     t_gen = time.perf_counter() - t0
@@ -386,7 +536,7 @@ def main():
 
     # ---- sensitivity: how much of `value` is the generator's choice of |S| (rank 0 only) --------
     sens = None
-    if rank == 0 and world == 1 and not args.no_sensitivity and not args.no_crowns:
+    if rank == 0 and world == 1 and not args.no_sensitivity and not args.no_crowns and not genome:
         sens = []
 
         def leg(label, rd, steps=3):
@@ -406,7 +556,7 @@ def main():
                          "reads_per_s": rd.n_reads / dt, "ms_per_step": dt * 1e3,
                          "share_on_whole_tree_stream": float((tr == st.n_streams - 1).mean()),
                          "share_on_window_crowns": float((tr == w.WINDOW_CROWN_SLOT).mean()),
-                         "reads_by_plan_class": {w.PLAN_NAMES[c]: int(k) for c, k in enumerate(np.bincount(pc, minlength=6)) if k}})
+                         "reads_by_plan_class": {w.PLAN_NAMES[c]: int(k) for c, k in enumerate(np.bincount(pc, minlength=7)) if k}})
 
         n_s = min(R, 1_000_000)
         for pn in ((0.005, 0.02, 0.05) if not long_reads else (0.02, 0.05)):
@@ -421,7 +571,7 @@ def main():
                    "num_best": ref_out[2].cpu().numpy().view(np.uint32), "flags": ref_out[3].cpu().numpy().view(np.uint32)}
         total_reads = reads_timed * world          # (every rank places batches of the same sizes)
         value = total_reads / elapsed
-        mode = "long_reads" if long_reads else ("whole_tree" if (args.no_crowns and args.no_walk) else "short_reads")
+        mode = "genome_samples" if genome else "long_reads" if long_reads else ("whole_tree" if (args.no_crowns and args.no_walk) else "short_reads")
         roof, cands = sweep_roofline(mode, R, sweep_ms, alg_bytes, passes, n_launch)
         if mode == "whole_tree":
             # every tile streams the whole-tree stream: the tiles of a launch sweep the same 1 MB chunk together, the bytes
@@ -429,7 +579,9 @@ def main():
             roof.update({"served_from": "L2 (chunk-major 1 MB chunks shared by the tiles of a launch): frac > 1 is possible and says "
                                         "nothing about HBM; the binding unit of this run is vector issue (roofline_candidates)",
                          "l2_peak_gbs": L2_PEAK_GBS, "frac_of_l2_peak": roof["achieved"] / L2_PEAK_GBS})
-        shape = (f"{R} synthetic midnight-amplicon-like {args.read_len} bp reads per GPU per step (3 % substitutions, "
+        shape = (f"{R} synthetic whole-genome samples per GPU per step (a leaf genotype + 0.1 % substitutions + N rate {p_n}: what read_vcf "
+                 f"makes of consensus genomes; {args.batches} batches in rotation from seed {seed0})" if genome else
+                 f"{R} synthetic midnight-amplicon-like {args.read_len} bp reads per GPU per step (3 % substitutions, "
                  f"N rate {p_n}; {args.batches} batches in rotation from seed {seed0}); BASELINE.json configs[4] shape on one GPU" if long_reads else
                  f"{R} synthetic ARTIC-like {args.read_len} bp reads per GPU per step (0.1 % substitutions, N rate {p_n}; "
                  f"{args.batches} distinct batches in rotation, seeds {seed0}..{seed0 + args.batches - 1}); BASELINE.json configs[2]")
@@ -475,7 +627,7 @@ def main():
             "roofline_candidates": cands,
             "walk": {"reads_walked_per_step": int(walk_reads), "wave_iterations_per_step": int(walk_iters // max(1, args.steps)),
                      "enabled": not args.no_walk,
-                     "reads_by_plan_class": {w.PLAN_NAMES[c]: int(n) for c, n in enumerate(np.bincount(pcls, minlength=6)) if n}},
+                     "reads_by_plan_class": {w.PLAN_NAMES[c]: int(n) for c, n in enumerate(np.bincount(pcls, minlength=7)) if n}},
             "streams": [{"tau": int(st.stream_tau[i]), "nodes": int(st.stream_nodes[i]), "bytes": int(st.stream_bytes_of[i]),
                          "reads_routed": int(counts[i])} for i in range(st.n_streams)],
             "window_crowns": {"what": "per genome window (2560 positions every 1024) the nodes a read confined to the window can be "
@@ -508,8 +660,36 @@ def main():
                 "hbm_side_traffic_gbs": wr.get("traffic_gbs"), "hbm_side_traffic_frac_of_8TBs": wr.get("traffic_frac"),
                 "l2_hit_rate": wr.get("l2_hit_rate"), "valu_issue": valu, "provenance": wr.get("provenance")}
         out["sensitivity"] = sens
+        # ---- the CPU checker (oracle/incremental_oracle.c) on the bench MAT: shared by the legs and the CPU baseline ----
+        ot = inc = None
         if world == 1 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(g.tree, reads, gpu_res, args.cpu_baseline_seconds)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_bridge
+            ot = oracle_bridge.OracleTree(g.tree)
+            inc = ot.incremental()
+        # ---- the other configs of BASELINE.json on the same resident MAT (rank 0, one GPU): each leg is one GPU's share
+        # of its config, device-resident and PCIe-inclusive, with its own contract-shaped roofline ----
+        if world == 1 and not args.no_legs and not args.no_crowns and not genome and not long_reads:
+            legs = []
+            legs.append(run_leg(torch, mat, dev, stream, "configs[3]: 1.25 M 150 bp reads, one GPU's shard of the 10 M-read run", "short_reads",
+                                [g.reads(52 + i, 1_250_000, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.001, p_n=0.005) for i in range(4)],
+                                steps=8, pcie_steps=3, checker=inc))
+            legs.append(run_leg(torch, mat, dev, stream, "configs[4]: 125 000 reads of 1.2 kb, one GPU's shard of the 1 M-read run", "long_reads",
+                                [long_reads_batch(g, 24 + i, 125_000) for i in range(4)], steps=8, pcie_steps=3, checker=inc, n_check=128))
+            legs.append(run_leg(torch, mat, dev, stream, "whole-genome samples (the input of usher_common: read_vcf's Missing_Samples), 20 000 per step", "genome_samples",
+                                [genome_samples(g, 900 + i, 20_000) for i in range(4)], steps=8, pcie_steps=3, checker=inc, n_check=128))
+            out["legs"] = legs
+        # ---- tree-shape ladder: the default batch and 1.2 kb reads on trees of other shapes (what every number above is
+        # a best case of: median root path ~20 mutations, no polytomies) ----
+        if ladder_jobs is not None:
+            out["tree_ladder"] = {"nodes": args.ladder_nodes,
+                                  "what": "same generator, other shapes (wepp_gen_tree_params: depth_choices, p_hub, p_back_mutation); per tree "
+                                          "the crown / candidate sizes, 1 M default reads and 50 000 reads of 1.2 kb per step, first reads "
+                                          "checked against the incremental oracle",
+                                  "trees": [ladder_measure(torch, w, dev, stream, j.result()) for j in ladder_jobs]}
+            ladder_pool.shutdown()
+        if ot is not None:
+            out["cpu_baseline"] = cpu_baseline(g.tree, reads, gpu_res, args.cpu_baseline_seconds, ot, inc)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -318,7 +318,19 @@ typedef struct {
     double   p_ambiguous;       /* prob. a node mutation gets a 2-bit mut_nuc   */
     double   p_masked_node;     /* prob. a non-root node gets a masked mutation */
     uint32_t root_mutations;    /* mutations placed on the root                 */
+    /* tree shape (0 = the default shape: uniform attachment, median root path ~20 mutations at 16 M nodes) */
+    uint32_t depth_choices;     /* parent = the DEEPEST of this many uniformly drawn earlier nodes: 2 -> paths of ~2x
+                                 * the mutations, 16 -> ~5x (real SARS-CoV-2 paths carry 60-100+)              */
+    double   p_hub;             /* prob. the parent is one of the tree's hubs instead: polytomies ...           */
+    uint32_t n_hubs;            /* ... the first n_hubs nodes (0: n_nodes / 4096 + 1), each ~p_hub * n / n_hubs children */
 } wepp_gen_tree_params;
+
+/* shape of a generated tree: mutations on the root path of its leaves, depth, largest polytomy */
+typedef struct {
+    uint32_t n_nodes, n_leaves, max_depth, max_children;
+    uint32_t path_mutations_median, path_mutations_p95, path_mutations_max;
+    double   path_mutations_mean, mutations_per_node;
+} wepp_gen_tree_shape;
 
 typedef struct {
     uint64_t seed;
@@ -333,6 +345,7 @@ typedef struct {
 
 int wepp_gen_tree_create(const wepp_gen_tree_params *p, wepp_gen_tree_t **out);
 int wepp_gen_tree_desc(const wepp_gen_tree_t *t, wepp_tree_desc *out);  /* borrowed pointers */
+int wepp_gen_tree_get_shape(const wepp_gen_tree_t *t, wepp_gen_tree_shape *out);
 int wepp_gen_tree_destroy(wepp_gen_tree_t *t);
 
 int wepp_gen_reads_create(const wepp_gen_tree_t *t, const wepp_gen_reads_params *p, wepp_gen_reads_t **out);

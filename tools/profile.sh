@@ -15,7 +15,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PROG=${PROFILE_PROG:-bench.py}
 if [ "$PROG" = "bench.py" ]; then
-  ARGS="--steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 --no-sensitivity --pcie-steps 0 $*"
+  ARGS="--steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 --no-sensitivity --pcie-steps 0 --no-legs $*"
 else
   ARGS="$*"
 fi

@@ -88,6 +88,18 @@ class GenTreeParams(ctypes.Structure):
         ("p_ambiguous", ctypes.c_double),
         ("p_masked_node", ctypes.c_double),
         ("root_mutations", ctypes.c_uint32),
+        ("depth_choices", ctypes.c_uint32),
+        ("p_hub", ctypes.c_double),
+        ("n_hubs", ctypes.c_uint32),
+    ]
+
+
+class GenTreeShape(ctypes.Structure):
+    _fields_ = [
+        ("n_nodes", ctypes.c_uint32), ("n_leaves", ctypes.c_uint32), ("max_depth", ctypes.c_uint32),
+        ("max_children", ctypes.c_uint32), ("path_mutations_median", ctypes.c_uint32),
+        ("path_mutations_p95", ctypes.c_uint32), ("path_mutations_max", ctypes.c_uint32),
+        ("path_mutations_mean", ctypes.c_double), ("mutations_per_node", ctypes.c_double),
     ]
 
 
@@ -165,6 +177,7 @@ _SIGS = {
     "wepp_last_error": (ctypes.c_char_p, []),
     "wepp_gen_tree_create": (ctypes.c_int, [ctypes.POINTER(GenTreeParams), ctypes.POINTER(_V)]),
     "wepp_gen_tree_desc": (ctypes.c_int, [_V, ctypes.POINTER(TreeDescC)]),
+    "wepp_gen_tree_get_shape": (ctypes.c_int, [_V, ctypes.POINTER(GenTreeShape)]),
     "wepp_gen_tree_destroy": (ctypes.c_int, [_V]),
     "wepp_gen_reads_create": (ctypes.c_int, [_V, ctypes.POINTER(GenReadsParams), ctypes.POINTER(_V)]),
     "wepp_gen_reads_get": (

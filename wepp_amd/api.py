@@ -142,10 +142,11 @@ class EppReads(Reads):
 
 
 def generate_tree(seed, n_nodes, genome_len=29903, p_recent_parent=0.25, zipf_s=0.6, p_back_mutation=0.02,
-                  p_ambiguous=0.0, p_masked_node=0.0, root_mutations=0):
-    """Deterministic synthetic MAT (wepp_gen_tree_create); returns (Tree, handle)."""
+                  p_ambiguous=0.0, p_masked_node=0.0, root_mutations=0, depth_choices=0, p_hub=0.0, n_hubs=0):
+    """Deterministic synthetic MAT (wepp_gen_tree_create).  Shape knobs: depth_choices (parent = the deepest of that
+    many random earlier nodes: longer root paths), p_hub / n_hubs (polytomies: star-like trees)."""
     p = _lib.GenTreeParams(seed, n_nodes, genome_len, p_recent_parent, zipf_s, p_back_mutation, p_ambiguous,
-                           p_masked_node, root_mutations)
+                           p_masked_node, root_mutations, depth_choices, p_hub, n_hubs)
     h = ctypes.c_void_p()
     check(lib.wepp_gen_tree_create(ctypes.byref(p), ctypes.byref(h)))
     return GenTree(h)
@@ -164,6 +165,12 @@ class GenTree:
             np.ctypeslib.as_array(d.mut_off, shape=(n + 1,)).copy(),
             mk(d.mut_pos, np.int32), mk(d.mut_ref, np.uint8), mk(d.mut_mut, np.uint8), mk(d.mut_par, np.uint8),
         )
+
+    def shape(self):
+        """Root-path mutations of the leaves (median, mean, 95 %, max), depth, largest polytomy."""
+        sh = _lib.GenTreeShape()
+        check(lib.wepp_gen_tree_get_shape(self._h, ctypes.byref(sh)))
+        return {f: getattr(sh, f) for f, _ in sh._fields_}
 
     def reads(self, seed, n_reads, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.001,
               p_n=0.005, p_iupac=0.0, windows=False, max_degree=1):

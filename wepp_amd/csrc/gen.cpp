@@ -104,11 +104,24 @@ extern "C" int wepp_gen_tree_create(const wepp_gen_tree_params* pp, wepp_gen_tre
         t->mut_mut.reserve((size_t)N + N / 8);
         std::vector<uint32_t> nchild(N, 0);
         std::vector<std::pair<int32_t, uint8_t>> mine;  // (pos, mut)
+        // tree shape knobs (wepp_place.h): with the defaults no extra random number is drawn -- the default tree of a
+        // seed is the tree it has always been
+        const uint32_t choices = std::max<uint32_t>(1, pp->depth_choices);
+        const uint32_t hubs = pp->p_hub > 0.0 ? (pp->n_hubs ? std::min(pp->n_hubs, N) : N / 4096 + 1) : 0;
+        std::vector<uint32_t> depth(choices > 1 ? N : 0, 0);
         for (uint32_t i = 0; i < N; i++) {
             if (i > 0) {
                 uint32_t par;
-                if (i > 8 && rng.chance(pp->p_recent_parent)) par = i - 1 - (uint32_t)rng.below(8);
-                else par = (uint32_t)rng.below(i);
+                if (hubs && i > hubs && rng.chance(pp->p_hub)) par = (uint32_t)rng.below(hubs);
+                else if (i > 8 && rng.chance(pp->p_recent_parent)) par = i - 1 - (uint32_t)rng.below(8);
+                else {
+                    par = (uint32_t)rng.below(i);
+                    for (uint32_t c = 1; c < choices; c++) {
+                        const uint32_t alt = (uint32_t)rng.below(i);
+                        if (depth[alt] > depth[par]) par = alt;
+                    }
+                }
+                if (choices > 1) depth[i] = depth[par] + 1;
                 t->parent[i] = (int32_t)par;
                 nchild[par]++;
             }
@@ -175,6 +188,40 @@ extern "C" int wepp_gen_tree_desc(const wepp_gen_tree_t* t, wepp_tree_desc* out)
     out->mut_ref = t->mut_ref.data();
     out->mut_par = t->mut_par.data();
     out->mut_mut = t->mut_mut.data();
+    return WEPP_OK;
+}
+
+extern "C" int wepp_gen_tree_get_shape(const wepp_gen_tree_t* t, wepp_gen_tree_shape* out) {
+    if (!t || !out) return wepp::set_error(WEPP_EINVAL, "null argument");
+    const uint32_t N = (uint32_t)t->parent.size();
+    std::vector<uint32_t> pm(N, 0), dep(N, 0), nch(N, 0);
+    uint32_t max_depth = 0, max_children = 0;
+    for (uint32_t i = 0; i < N; i++) {          // (a parent's index is below its children's)
+        uint32_t own = 0;
+        for (uint32_t k = t->mut_off[i]; k < t->mut_off[i + 1]; k++) own += t->mut_pos[k] >= 0 ? 1u : 0u;
+        if (i) {
+            const uint32_t p = (uint32_t)t->parent[i];
+            pm[i] = pm[p] + own;
+            dep[i] = dep[p] + 1;
+            max_children = std::max(max_children, ++nch[p]);
+        } else pm[i] = own;
+        max_depth = std::max(max_depth, dep[i]);
+    }
+    std::vector<uint32_t> leaf_pm;
+    leaf_pm.reserve(t->leaves.size());
+    double sum = 0;
+    for (uint32_t l : t->leaves) { leaf_pm.push_back(pm[l]); sum += pm[l]; }
+    std::sort(leaf_pm.begin(), leaf_pm.end());
+    const size_t nl = leaf_pm.size();
+    out->n_nodes = N;
+    out->n_leaves = (uint32_t)nl;
+    out->max_depth = max_depth;
+    out->max_children = max_children;
+    out->path_mutations_median = nl ? leaf_pm[nl / 2] : 0;
+    out->path_mutations_p95 = nl ? leaf_pm[std::min(nl - 1, nl * 95 / 100)] : 0;
+    out->path_mutations_max = nl ? leaf_pm.back() : 0;
+    out->path_mutations_mean = nl ? sum / (double)nl : 0.0;
+    out->mutations_per_node = N ? (double)t->mut_pos.size() / N : 0.0;
     return WEPP_OK;
 }
 

@@ -20,7 +20,8 @@ static const char NUC_CH[16] = {'?', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W'
 int main(int argc, char** argv) {
     uint32_t nodes = 100000, samples = 0, read_len = 150;
     uint64_t seed = 21, sample_seed = 22;
-    double p_n = 0.005, p_sub = 0.001;
+    double p_n = 0.005, p_sub = 0.001, p_hub = 0.0, p_back = 0.02;
+    uint32_t depth_choices = 0;
     std::string pb, vcf;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -34,14 +35,17 @@ int main(int argc, char** argv) {
         else if (a == "--p-n") p_n = atof(next());
         else if (a == "--p-sub") p_sub = atof(next());
         else if (a == "--vcf") vcf = next();
+        else if (a == "--depth-choices") depth_choices = (uint32_t)atoll(next());     // tree shape: longer root paths
+        else if (a == "--p-hub") p_hub = atof(next());                                // tree shape: polytomies
+        else if (a == "--p-back") p_back = atof(next());
         else {
             fprintf(stderr, "usage: wepp-synth --nodes N [--seed S] --pb out.pb[.gz] [--samples K --vcf out.vcf[.gz] [--sample-seed S] "
-                            "[--read-len L] [--p-n x] [--p-sub x]]\n");
+                            "[--read-len L] [--p-n x] [--p-sub x]] [--depth-choices c] [--p-hub x] [--p-back x]\n");
             return 1;
         }
     }
     // the same parameters as wepp_amd.generate_tree(seed, nodes): the tree of the bench and of the tests
-    wepp_gen_tree_params tp{seed, nodes, 29903, 0.25, 0.6, 0.02, 0.0, 0.0, 0};
+    wepp_gen_tree_params tp{seed, nodes, 29903, 0.25, 0.6, p_back, 0.0, 0.0, 0, depth_choices, p_hub, 0};
     wepp_gen_tree_t* gt = nullptr;
     if (wepp_gen_tree_create(&tp, &gt) != WEPP_OK) { fprintf(stderr, "ERROR: %s\n", wepp_last_error()); return 1; }
     wepp_tree_desc d{};
