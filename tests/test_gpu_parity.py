@@ -612,6 +612,48 @@ def test_full_size_genome_samples_epp_fitch():
     print("full-size genome samples / EPP / Fitch report:", json.dumps(rep))
 
 
+def test_window_bound_on_fuzz_trees():
+    """The window-candidate bound on the GPU with the adversarial fuzz: a test-only build of the library with genome
+    windows of 64 positions every 32 (tools/build_variant.sh win64; built by __graft_entry__.build(), or here when
+    missing) places reads confined to such windows -- walks of window crowns, per-read sweeps of a window crown, window
+    tiles -- on trees with masked nodes, multi-allelic alleles, repeated positions and back-mutations straddling the
+    window edges; tests/window_fuzz.py compares every read with the faithful oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    lib = os.path.join(root, "variants", "win64", "libwepp_place.so")
+    if not os.path.exists(lib):
+        subprocess.run(["bash", os.path.join(root, "tools", "build_variant.sh"), "win64", "-DWEPP_WIN_SIZE=64", "-DWEPP_WIN_STRIDE=32"],
+                       check=True, capture_output=True, timeout=1500)
+    env = dict(os.environ, WEPP_PLACE_LIB=lib)
+    run = subprocess.run([sys.executable, os.path.join(HERE, "window_fuzz.py")], env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    rep = json.loads(run.stdout.strip().splitlines()[-1])
+    assert rep["trees_with_window_crowns"] >= 20 and rep["reads_on_window_crowns"] >= 1000, rep
+    assert {"walk8", "sweep", "window"} <= set(rep["reads_by_plan_class"]), rep
+    print("window fuzz report:", json.dumps(rep))
+
+
+def test_genome_beyond_the_window_table(oracle):
+    """A 100 kb genome: positions from 32 * 1024 on lie in no genome window (wepp_mat_stats::window_uncovered_positions);
+    reads there take the tree-wide streams -- a documented limit, not a silent one; same results as the oracle on both
+    sides of the edge and across it."""
+    L = 100000
+    g = w.generate_tree(41, 60000, genome_len=L)
+    mat = w.Mat(g.tree)
+    assert mat.stats.window_size == 2560 and mat.stats.window_stride == 1024
+    assert mat.stats.window_uncovered_positions > 60000
+    reads = g.reads(42, 3000, read_len=150, amplicon_len=400, amplicon_step=300, p_substitution=0.002, p_n=0.02)
+    res = mat.place_batch(reads)
+    first = np.array([reads.read_word[reads.read_off[r]] & 0xFFFFF if reads.read_off[r + 1] > reads.read_off[r] else 0 for r in range(reads.n_reads)])
+    assert (first >= 32 * 1024 + 2560).sum() > 500 and ((first > 0) & (first < 32 * 1024)).sum() > 200
+    assert_same(res, oracle.OracleTree(g.tree).incremental().place_batch(reads, nthreads=8), "100 kb genome")
+    _, pst = mat.last_plans(reads.n_reads)
+    beyond = first >= 32 * 1024 + 2560
+    assert (pst[beyond] != w.WINDOW_CROWN_SLOT).all()              # no window crown out there
+    mat.close()
+
+
 def test_window_crowns_walks_and_sweeps_vs_oracle(oracle):
     """Window crowns (include/wepp_place.h: wepp_mat_last_crowns): reads confined to a genome window are placed on the
     crown of their window that their ROOT score admits -- by a walk when they list at most 16 positions, by a sweep of
