@@ -435,8 +435,11 @@ def main():
     t_gen = time.perf_counter() - t0
     # one flatten (host), one upload (this rank's device): the C++ host flattens once per node and uploads from every
     # device thread (wepp_flat_create + wepp_mat_upload); a bench rank is its own process, so its flatten is rank-local
+    # ... under torch.distributed.run every rank is a process: local rank 0 flattens and leaves the image in /dev/shm
+    # (wepp_flat_save), the other ranks of the node read it back (wepp_flat_load): ONE flatten per node here too
     t0 = time.perf_counter()
-    flat = w.FlatView(g.tree)
+    from wepp_amd.sharding import shared_flat_image
+    flat = shared_flat_image(g.tree, dist if world > 1 else None, local_rank, f"{os.environ.get('MASTER_PORT', '0')}_{args.nodes}")
     t_flat = time.perf_counter() - t0
     t0 = time.perf_counter()
     mat = w.Mat(g.tree, device=local_rank, flat=flat)
@@ -621,6 +624,8 @@ def main():
                         "blocks": int(st.n_blocks), "leaves": int(st.n_leaves), "max_depth": int(st.max_depth),
                         "device_bytes": int(st.device_bytes)},
                 "setup_s": {"generate_tree_and_batches": round(t_gen, 1), "flatten_host": round(t_flat, 1), "upload_and_handle": round(t_up, 1)},
+                "flatten": "one per node: local rank 0 flattens and shares the image through /dev/shm (wepp_flat_save / wepp_flat_load)" if world > 1
+                           else "one flatten, one upload",
                 "kernel_hash": kernel_hash(),
             },
             "roofline": roof,

@@ -473,6 +473,13 @@ int wepp_flat_destroy(wepp_flat_t *flat);
  * reference re-expands the tree per sample (src/usher_common.cpp:339).  wepp_mat_create == flatten + upload.
  * The image may be destroyed as soon as the uploads have returned. */
 int wepp_mat_upload(const wepp_flat_t *flat, int device, wepp_mat_t **out);
+/* The flat image as a file: one flatten per NODE when the ranks are processes of their own (one per GPU under
+ * torch.distributed.run, MPI, ...): rank 0 calls wepp_flat_create + wepp_flat_save (to /dev/shm), the other ranks
+ * wepp_flat_load + wepp_mat_upload -- seconds instead of a flatten each.  A cache bound to this build of the library
+ * (the header pins its layout constants; WEPP_EINVAL otherwise), not an exchange format.  The file is written under
+ * a temporary name and renamed: a reader never sees a partial image. */
+int wepp_flat_save(const wepp_flat_t *flat, const char *path);
+int wepp_flat_load(const char *path, wepp_flat_t **out);
 /* Diagnostic: full flattens (wepp_mat_create, wepp_flat_create) this process has run. */
 uint64_t wepp_debug_flatten_count(void);
 

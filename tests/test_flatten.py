@@ -234,3 +234,30 @@ def test_window_streams_match_oracle(oracle):
     # both kinds of window stream were swept: the window's candidate crown (real nodes only), and the whole tree with
     # pseudo-nodes where the candidates were too many to be worth a crown
     assert checked > 300 and kinds[True] >= 5 and kinds[False] >= 5, kinds
+
+
+def test_flat_image_round_trips_through_a_file(tmp_path):
+    """wepp_flat_save / wepp_flat_load (one flatten per node when the ranks are processes): every array of the image
+    comes back byte for byte; a damaged or foreign file is refused."""
+    g = w.generate_tree(17, 30000, genome_len=6000, p_ambiguous=0.02, p_masked_node=0.004, root_mutations=2)
+    a = w.FlatView(g.tree)
+    path = str(tmp_path / "image.bin")
+    a.save(path)
+    b = w.FlatView.load(path)
+    assert bytes(a.stats) == bytes(b.stats) and a.cp_stride == b.cp_stride
+    for name in ("node_woff", "words", "rank2dfs", "dfs2bfs", "rank2bfs", "bfs2id", "dfs2id", "parent_dfs", "dfs_end", "num_leaves",
+                 "maxnest", "epp_word", "epp_node", "seed_sig", "wc_tau", "wc_nodes"):
+        assert np.array_equal(a.get(name), b.get(name)), name
+    fields = ("nkey", "nstat", "blk_node0", "blk_eoff", "blk_sum", "ev_word", "ev_meta", "ev_lb", "cp_off", "cp_word", "ix_head", "ix_ent",
+              "ix_nest", "nrec", "rq_pre", "rq_suf", "rq_dst", "sp")
+    for st in list(range(a.n_streams)) + ["w0", "w2", "c1.0"]:
+        for name in fields:
+            assert np.array_equal(a.get(name, stream=st), b.get(name, stream=st)), (st, name)
+    raw = open(path, "rb").read()
+    bad = str(tmp_path / "bad.bin")
+    open(bad, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(w.WeppError):
+        w.FlatView.load(bad)
+    open(bad, "wb").write(b"not an image" + raw[12:])
+    with pytest.raises(w.WeppError):
+        w.FlatView.load(bad)

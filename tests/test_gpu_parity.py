@@ -745,6 +745,24 @@ def test_pipeline_equals_unsplit_call(oracle):
     mat.close()
 
 
+def test_host_pipeline_with_few_workers(oracle, monkeypatch):
+    """wepp_place_batch's staging with ONE host worker (WEPP_HOST_THREADS=2: what a handle gets when eight of them
+    share sixteen cores): the chunks' offsets go up as soon as a chunk's own staging tasks are done, and with one
+    worker the tasks run strictly one after the other -- round 3 staged a chunk's END offset in the next chunk's first
+    task, so the copy could leave before it (found by tools/host_proxy.py as a fault in k_route).  Batches of different
+    sizes in turn (a stale offset of the call before is wrong for this one), each against the incremental checker."""
+    monkeypatch.setenv("WEPP_HOST_THREADS", "2")
+    g = w.generate_tree(35, 60_000, p_ambiguous=0.01, root_mutations=1)
+    inc = oracle.OracleTree(g.tree).incremental()
+    batches = [g.reads(36 + i, n, p_substitution=0.004, p_n=0.03) for i, n in enumerate((70_001, 131_075, 66_000, 99_999))]
+    wants = [inc.place_batch(b, nthreads=os.cpu_count() or 1) for b in batches]
+    mat = w.Mat(g.tree)
+    for rnd in range(3):
+        for b, want in zip(batches, wants):
+            assert_same(mat.place_batch(b), want, f"one host worker, round {rnd}, {b.n_reads} reads")
+    mat.close()
+
+
 def test_two_handles_two_host_threads(oracle):
     """include/wepp_place.h: different handles may be used concurrently from different host threads.
     Two handles on device 0, each placing its own contiguous shard of the batch from its own thread

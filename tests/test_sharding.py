@@ -38,7 +38,12 @@ def _worker(rank, world, port, out_path):
     g = w.generate_tree(31, 1500, genome_len=800, p_ambiguous=0.01, root_mutations=1)
     reads = g.reads(32, 41, p_substitution=0.004, p_n=0.01)
     mine = shard_reads(reads, rank, world)
-    fm = sm.FlatModel(w.FlatView(g.tree))
+    # one flatten per node: rank 0 flattens, rank 1 reads the image back (wepp_flat_save / wepp_flat_load)
+    from wepp_amd.sharding import shared_flat_image
+    before = w.flatten_count()
+    flat = shared_flat_image(g.tree, dist, rank, f"test_{port}", directory=os.path.dirname(out_path))
+    assert w.flatten_count() - before == (1 if rank == 0 else 0)
+    fm = sm.FlatModel(flat)
 
     class Local:
         pass
@@ -128,7 +133,8 @@ def _gpu_worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = w.generate_tree(33, 60_000, p_ambiguous=0.01, p_masked_node=0.002, root_mutations=1)
     reads = g.reads(34, 70_001, p_substitution=0.004, p_n=0.03, p_iupac=0.1)
-    mat = w.Mat(g.tree, device=0)
+    from wepp_amd.sharding import shared_flat_image
+    mat = w.Mat(g.tree, device=0, flat=shared_flat_image(g.tree, dist, rank, f"test_{port}", directory=os.path.dirname(out_path)))
     res = mat.place_batch(shard_reads(reads, rank, world))
     full = gather_results(res, dist)
     mat.close()
@@ -141,7 +147,7 @@ def _gpu_worker(rank, world, port, out_path):
 @pytest.mark.gpu
 def test_two_processes_on_the_gpu_equal_the_unsharded_oracle(tmp_path, oracle):
     """The N>1 path with the HIP library in BOTH processes (the CPU tests above put a Python model in its place): two
-    ranks, each flattening the tree, holding its own handle on device 0 and placing its contiguous half of 70 001
+    ranks sharing ONE flat image (rank 0 flattens, rank 1 reads it back), each holding its own handle on device 0 and placing its contiguous half of 70 001
     reads; rank 0 concatenates -- equal to the oracle's unsharded run."""
     out = str(tmp_path / "gathered_gpu.npz")
     port = 29500 + (os.getpid() % 2000) + 2

@@ -25,7 +25,7 @@ done
 SRC=$SCRATCH/wepp_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC -Wno-unused-parameter ${EXTRA[*]}"
 pids=()
-for f in flatmat gen errors flat_debug capi fitch_capi epp_capi; do
+for f in flatmat gen errors flat_debug flat_io capi fitch_capi epp_capi; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.cpp -o $OUT/$f.o & pids+=($!)
 done
 for f in $(cd $SRC && ls *.hip | sed 's/\.hip$//'); do

@@ -193,6 +193,8 @@ _SIGS = {
     ),
     "wepp_flat_scalars": (ctypes.c_int, [_V, ctypes.POINTER(MatStats), ctypes.POINTER(ctypes.c_uint32)]),
     "wepp_flat_destroy": (ctypes.c_int, [_V]),
+    "wepp_flat_save": (ctypes.c_int, [_V, ctypes.c_char_p]),
+    "wepp_flat_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_V)]),
     "wepp_mat_upload": (ctypes.c_int, [_V, ctypes.c_int, ctypes.POINTER(_V)]),
     "wepp_debug_flatten_count": (ctypes.c_uint64, []),
 }

@@ -6,6 +6,7 @@ Missing_Sample (src/usher_graph.hpp:34-54), *placing* is the per-sample loop
 of usher_common (src/usher_common.cpp:307-470).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -217,11 +218,15 @@ class FlatView:
 
     _DT = {"nkey": np.int64, "ev_meta": np.uint8, "ev_lb": np.uint8, "sp": np.uint8, "maxnest": np.uint8, "ix_nest": np.uint8}
 
-    def __init__(self, tree):
+    def __init__(self, tree, path=None):
+        """Flattens `tree`, or -- path given, tree None -- reads an image written by save()."""
         self._tree = tree
         self._h = ctypes.c_void_p()
-        d = tree.desc()
-        check(lib.wepp_flat_create(ctypes.byref(d), ctypes.byref(self._h)))
+        if tree is None:
+            check(lib.wepp_flat_load(os.fsencode(path), ctypes.byref(self._h)))
+        else:
+            d = tree.desc()
+            check(lib.wepp_flat_create(ctypes.byref(d), ctypes.byref(self._h)))
         st = _lib.MatStats()
         cs = ctypes.c_uint32()
         check(lib.wepp_flat_scalars(self._h, ctypes.byref(st), ctypes.byref(cs)))
@@ -231,6 +236,14 @@ class FlatView:
     @property
     def n_streams(self):
         return int(self.stats.n_streams)
+
+    def save(self, path):
+        """wepp_flat_save: the image as a file (one flatten per node: the other ranks FlatView(None, path))."""
+        check(lib.wepp_flat_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path):
+        return cls(None, path)
 
     def get(self, name, stream=None):
         """Host array `name`; stream fields take stream=i (default: whole-tree stream)."""

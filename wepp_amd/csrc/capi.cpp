@@ -22,8 +22,12 @@
 
 namespace {
 
+// handles alive in this process: a handle's host workers are its share of the cores the process may use
+std::atomic<uint32_t> g_handles_alive{0};
+
 void release(wepp_mat* h) {
     if (!h) return;
+    g_handles_alive.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     for (PlaceLane& L : h->lane) {
@@ -78,6 +82,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
 
     wepp_mat* h = new (std::nothrow) wepp_mat();
     if (!h) return set_error(WEPP_ENOMEM, "out of host memory");
+    g_handles_alive.fetch_add(1, std::memory_order_relaxed);
     h->device = device;
     h->bfs2id = f.bfs2id;
     h->dfs2id = f.dfs2id;
@@ -500,11 +505,20 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     }
     HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     // the host sizes the launches from the counters, and the GPU idles until it has: poll for them (a
-    // blocking wait adds its wake-up, ~15 us per call, to that idle time); after ~0.1 s of polling -- a long
-    // queue in front of this call -- wait blocking
+    // blocking wait adds its wake-up, ~15 us per call, to that idle time) ...
     {
+        // ... spinning for the first 50 us (the routing kernels of an idle stream take ~30), then yielding the core
+        // between queries -- eight ranks spinning on the cores of one container starve their own staging workers --,
+        // and after ~2 ms (a long queue in front of this call) waiting blocking
         hipError_t q = hipErrorNotReady;
-        for (int spin = 0; spin < 200000 && (q = hipStreamQuery(stream)) == hipErrorNotReady; spin++) {}
+        const auto t_poll = std::chrono::steady_clock::now();
+        for (;;) {
+            q = hipStreamQuery(stream);
+            if (q != hipErrorNotReady) break;
+            const auto waited = std::chrono::steady_clock::now() - t_poll;
+            if (waited > std::chrono::milliseconds(2)) break;
+            if (waited > std::chrono::microseconds(50)) std::this_thread::yield();
+        }
         (void)hipGetLastError();   // "not ready" is not an error: keep it out of the launchers' hipGetLastError()
         if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
     }
@@ -1043,8 +1057,12 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     // ---- sub-batches and tasks ----
     const bool big = n_reads >= (1u << 16);
     if (big && !mat->pool) {
-        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        mat->pool.reset(new HostPool(std::min<uint32_t>(15, hw > 1 ? hw - 1 : 1)));
+        // this handle's share of the host threads the process may use (affinity mask and cgroup quota, host_pool.hpp),
+        // one of them being the calling thread: the handles alive now split them (8 device threads of one C++ host
+        // process, or one handle per rank when every rank is a process with its own cpuset); WEPP_HOST_THREADS fixes it
+        const uint32_t share = mat->tun.host_threads ? mat->tun.host_threads
+                                                     : usable_host_threads() / std::max(1u, g_handles_alive.load(std::memory_order_relaxed));
+        mat->pool.reset(new HostPool(std::min<uint32_t>(15, share > 1 ? share - 1 : 1)));
     }
     const uint32_t pipe_env = mat->tun.pipe_sub_batches;
     const uint32_t pipe_knob = mat->pipe_sub_batches ? mat->pipe_sub_batches : pipe_env;
@@ -1086,10 +1104,6 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
             const uint32_t a = read_off[r], b = read_off[r + 1];
             off_bad |= (uint32_t)(b < a) | (uint32_t)(b > nw);
         }
-        if (pin_off) {
-            std::memcpy(pin_off + lo, read_off + lo, (size_t)(hi - lo) * 4);
-            if (hi == n_reads) pin_off[hi] = read_off[hi];
-        }
         if (off_bad) { check_exact(lo, hi, bad, what); return; }
         const uint32_t a0 = read_off[lo], b0 = read_off[hi];
         uint32_t zero = 0, descents = 0, at_starts = 0;
@@ -1123,6 +1137,16 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         const uint32_t ck = t / PS, part = t % PS;
         const uint32_t lo = chunk_lo(ck), hi = chunk_lo(ck + 1);
         const uint32_t a = lo + (uint32_t)((uint64_t)(hi - lo) * part / PS), b = lo + (uint32_t)((uint64_t)(hi - lo) * (part + 1) / PS);
+        // The offsets this task stages: its reads' [a, b), and -- the LAST part of a chunk -- the chunk's end offset too:
+        // a chunk's H2D copy takes the offsets [first read, last read + 1] and is enqueued as soon as the chunk's OWN
+        // tasks are done.  (Round 3 left the end offset to the first task of the NEXT chunk, which the launch thread
+        // does not wait for: with few host workers the copy went up before it was staged -- a stale or uninitialised
+        // offset for the read at every chunk boundary, wrong entries for that read or a fault in k_route.)  The first
+        // part of a later chunk leaves its first offset to the chunk before: every element has one writer.
+        if (pin_off) {
+            const uint32_t ca = (part == 0 && ck > 0) ? a + 1 : a, cb = (part + 1 == PS) ? b + 1 : b;
+            if (cb > ca) std::memcpy(pin_off + ca, read_off + ca, (size_t)(cb - ca) * 4);
+        }
         if (b > a) check(a, b, bad[t], what[t]);
         staged[ck].fetch_add(1, std::memory_order_release);
     };

@@ -3,9 +3,16 @@
 // these sleep on a condition variable between calls.  run() is called by one thread at a time (a handle is not
 // re-entrant); the caller works along.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#ifdef __linux__
+#include <sched.h>
+#endif
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -13,6 +20,35 @@
 #include <vector>
 
 namespace wepp {
+
+// Host threads this process may really use: the affinity mask (taskset, a container's cpuset) capped by the cgroup
+// CPU quota (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1).  std::thread::hardware_concurrency() sees
+// neither: eight ranks on a node each sizing a pool from it start 8 x 15 workers on the cores of one container.
+inline uint32_t usable_host_threads() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+#ifdef __linux__
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    auto quota = [&](const char* path_quota, const char* path_period) {
+        FILE* f = std::fopen(path_quota, "r");
+        if (!f) return;
+        char a[64] = {0}, b[64] = {0};
+        long long q = -1, p = -1;
+        if (path_period == nullptr) {                    // cgroup v2: "max 100000" or "<quota> <period>"
+            if (std::fscanf(f, "%63s %63s", a, b) == 2 && std::strcmp(a, "max") != 0) { q = std::atoll(a); p = std::atoll(b); }
+        } else if (std::fscanf(f, "%lld", &q) == 1) {
+            FILE* g = std::fopen(path_period, "r");
+            if (g) { if (std::fscanf(g, "%lld", &p) != 1) p = -1; std::fclose(g); }
+        }
+        std::fclose(f);
+        if (q > 0 && p > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (q + p - 1) / p));
+    };
+    quota("/sys/fs/cgroup/cpu.max", nullptr);
+    quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+#endif
+    return n;
+}
 
 class HostPool {
   public:

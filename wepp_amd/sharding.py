@@ -12,7 +12,31 @@ the haplotypes it maps to, so the per-haplotype arrays of the ranks must be SUMM
 real exchange step on these paths, an all-reduce (RCCL over xGMI on GPUs) of N doubles and
 N x 50 ints (epp_allreduce below).
 """
+import os
+
 import numpy as np
+
+
+def shared_flat_image(tree, dist=None, local_rank=0, tag="0", directory="/dev/shm"):
+    """ONE flatten per node when the ranks are processes of their own: local rank 0 flattens `tree` and leaves the
+    image in `directory` (wepp_flat_save), the other ranks of the node read it back (wepp_flat_load); the file is gone
+    when this returns.  Every rank gets a FlatView to upload (Mat(tree, device, flat=...)).  The reference re-expands
+    the tree per sample (src/usher_common.cpp:339)."""
+    from .api import FlatView
+    if dist is None or dist.get_world_size() == 1:
+        return FlatView(tree)
+    path = os.path.join(directory, f"wepp_flat_{tag}.bin")
+    flat = None
+    if local_rank == 0:
+        flat = FlatView(tree)
+        flat.save(path)
+    dist.barrier()
+    if local_rank != 0:
+        flat = FlatView.load(path)
+    dist.barrier()
+    if local_rank == 0:
+        os.remove(path)
+    return flat
 
 
 def shard_bounds(n_reads, rank, world):
