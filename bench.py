@@ -30,7 +30,7 @@ L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 (per XCD 4 MiB) ~34.5 TB/s aggr
 N_CUS = 256            # MI355X_MICROARCH.md chip-level parameters
 MAX_CLOCK_GHZ = 2.4    # max clock; a CU issues at most one vector instruction per cycle (4 SIMDs, one per 4 cycles)
 VALU_ISSUE_PEAK = N_CUS * MAX_CLOCK_GHZ   # G wave-instructions / s
-KERNEL_SOURCES = ("place_dev.hpp", "route_kernels.hip", "sweep_kernels.hip", "walk_kernels.hip", "seed_kernels.hip", "device_mat.hpp",
+KERNEL_SOURCES = ("place_dev.hpp", "route_kernels.hip", "sweep_kernels.hip", "walk_kernels.hip", "wave_kernels.hip", "seed_kernels.hip", "device_mat.hpp",
                   "flatmat.hpp", "flatmat.cpp", "capi.cpp", "sort_reads.hip")
 
 

@@ -622,7 +622,9 @@ def test_window_bound_on_fuzz_trees():
     import sys
     root = os.path.dirname(HERE)
     lib = os.path.join(root, "variants", "win64", "libwepp_place.so")
-    if not os.path.exists(lib):
+    csrc = os.path.join(root, "wepp_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".hpp")))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
         subprocess.run(["bash", os.path.join(root, "tools", "build_variant.sh"), "win64", "-DWEPP_WIN_SIZE=64", "-DWEPP_WIN_STRIDE=32"],
                        check=True, capture_output=True, timeout=1500)
     env = dict(os.environ, WEPP_PLACE_LIB=lib)
@@ -742,6 +744,50 @@ def test_pipeline_equals_unsplit_call(oracle):
         mat.place_batch(broken)
     again = mat.place_batch(reads)
     assert (again.score == whole.score).all() and (again.best_bfs_j == whole.best_bfs_j).all()
+    mat.close()
+
+
+def test_reads_with_many_events_vs_oracle(oracle):
+    """Reads whose positions are mutated many times in their stream: 17 - 256 events go to the wave-per-read walk
+    (wave_kernels.hip: lane = list entry, all-pairs instead of a walk), more to the walks cut into jobs.  A short genome
+    makes every list long (60 K nodes over 1 500 positions: ~40 mutations per position); reads of 1 - 12 entries with
+    concrete alleles, ambiguity codes and Ns, inside one genome window and across windows; masked and multi-allelic
+    nodes in the tree.  Against the incremental checker, and walks off = walks on."""
+    g = w.generate_tree(61, 60_000, genome_len=1500, p_ambiguous=0.02, p_masked_node=0.003, root_mutations=1)
+    rng = np.random.default_rng(9)
+    ref = {}
+    for p_, r_ in zip(g.tree.mut_pos, g.tree.mut_ref):
+        if p_ >= 0:
+            ref[int(p_)] = int(r_)
+    positions = np.array(sorted(ref))
+    samples = []
+    for i in range(6000):
+        k = int(rng.integers(1, 13))
+        if i % 2:
+            lo = int(rng.integers(0, len(positions) - 200))
+            pos = np.sort(rng.choice(positions[lo:lo + 200], size=min(k, 200), replace=False))
+        else:
+            pos = np.sort(rng.choice(positions, size=k, replace=False))
+        ents = []
+        for p_ in pos:
+            u = rng.random()
+            if u < 0.5:
+                ents.append((int(p_), ref[int(p_)], 1 << int(rng.integers(0, 4)), 0))
+            elif u < 0.7:
+                ents.append((int(p_), ref[int(p_)], int(rng.integers(1, 15)), 0))
+            else:
+                ents.append((int(p_), ref[int(p_)], 15, 1))
+        samples.append(ents)
+    reads = Reads.from_lists(samples)
+    mat = w.Mat(g.tree)
+    res = mat.place_batch(reads)
+    cls, _ = mat.last_plans(reads.n_reads)
+    assert (cls == w.PLAN_WALKC8).sum() + (cls == w.PLAN_WALKC16).sum() > 1000, np.bincount(cls).tolist()
+    assert_same(res, oracle.OracleTree(g.tree).incremental().place_batch(reads, nthreads=os.cpu_count() or 1), "reads with many events")
+    mat.set_use_walk(False)
+    r0 = mat.place_batch(reads)
+    for f in ("score", "best_bfs_j", "num_best", "flags"):
+        assert (getattr(r0, f) == getattr(res, f)).all(), f
     mat.close()
 
 

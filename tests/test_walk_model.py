@@ -47,6 +47,31 @@ def test_walk_model_matches_oracle_fuzz(oracle):
     assert by_entry > 0          # ranges decided by the entry's own pre-test byte (tests/conftest.py builds it for every stream)
 
 
+def test_all_pairs_walk_matches_oracle(oracle):
+    """The wave-per-read form (k_walk_wave: no walk, an all-pairs pass over the read's entries) gives the walk's
+    result, on the whole-tree stream and on the stream the read is routed to; small genomes make the lists long."""
+    rng = np.random.default_rng(33)
+    n = most = 0
+    for it in range(240):
+        genome = int(rng.choice([6, 12, 40]))
+        tree, ref = ft.random_tree(rng, n_nodes=int(rng.integers(30, 260)), genome=genome, p_masked=0.04, p_ambig=0.12, max_muts=3)
+        ot = oracle.OracleTree(tree)
+        fv = w.FlatView(tree)
+        models = [wm.WalkModel(fv, i) for i in range(fv.n_streams)]
+        tiers = sm.TieredModel(fv)
+        for _ in range(4):
+            S = ft.random_sample(rng, ref, genome=genome, max_k=int(rng.integers(0, 8)))
+            o = ot.place_sample(*_cols(S))
+            rs = _root_score(fv, S)
+            for m in (models[-1], models[tiers.route(S)]):
+                bs, br, cnt, hu = m.place_all_pairs(S, rs)
+                got = (bs, int(m.rank2bfs[br]), cnt, hu)
+                assert got == (o["score"], o["best_j"], o["num_best"], o["has_unique"]), (S, got, o, m.stream)
+                most = max(most, m.events_of(S))
+            n += 1
+    assert n == 960 and most > 64
+
+
 def test_chunked_walk_matches_oracle(oracle):
     """A read's walk cut into C independent jobs (start state from binary searches + the chains of
     enclosing entries), combined: same result for every C the longest list allows."""

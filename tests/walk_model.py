@@ -245,6 +245,84 @@ class WalkModel:
             pos = node + 1
         return bs, br, cnt, bhu
 
+    def place_all_pairs(self, S, root_score):
+        """Model of k_walk_wave (wepp_amd/csrc/wave_kernels.hip): no walk -- every entry of the read's lists learns from
+        an all-pairs pass what the sequential walk would know on arrival, with the kernel's wrapping differences."""
+        M = 0xFFFFFFFF
+        npos = len(self.ix_off) - 1
+        c0 = sum(1 for (_, sref, a, missing) in S if not missing and (a & sref) == 0)
+        ents = []                       # (node, end, d, adj, dcom) in the order of the concatenated lists
+        for j, (p, _, _, _) in enumerate(S):
+            if p >= npos:
+                continue
+            for q in range(int(self.ix_off[p]), int(self.ix_off[p + 1]) - 1):
+                node, end, w = int(self.ix_node[q]), int(self.ix_end[q]), int(self.ix_word[q])
+                d = enter_delta(w, S[j]) if (end > node + 1 or node == 0) else 0
+                a1, a2 = own_adjust(w, S[j])
+                assert -2 <= d <= 2 and -1 <= a1 <= 1 and -1 <= a2 <= 1       # (the kernel packs them into bytes, biased by 2)
+                ents.append((node, end, d, a1, a2))
+        bs, br, cnt, bhu = root_score + 1, 0xFFFFFFFF, 0, 0
+
+        def take(score, rank, k, hu):
+            nonlocal bs, br, cnt, bhu
+            if score < bs:
+                bs, br, cnt, bhu = score, rank, k, hu
+            elif score == bs:
+                cnt += k
+                if rank < br:
+                    br, bhu = rank, hu
+
+        def stretch(a, b, c):
+            m = self.range_min(a, b)
+            if m != SP_NONE and (m >= SP_CLAMP or m + c <= bs):
+                base, rank, k, hu = self.range_exact(a, b)
+                if k and base + c <= bs:
+                    take(base + c, rank, k, hu)
+
+        first_node = min((e[0] for e in ents), default=M)
+        for mg, (n, e, _, _, _) in enumerate(ents):
+            cb = cB = dsum = adj = dcom = 0
+            stopA = stopB = M
+            lower_same = lower_end = False
+            sA = n + 1
+            for g, (nl, el, dl, al, ml) in enumerate(ents):
+                nl1, span = nl + 1, (el - nl - 1) & M
+                if dl != 0:
+                    if ((n - nl1) & M) < span:
+                        cb += dl
+                    if ((e - nl1) & M) < span:
+                        cB += dl
+                if nl == n:
+                    dsum, adj, dcom = dsum + dl, adj + al, dcom + ml
+                    lower_same |= g < mg
+                lower_end |= el == e and g < mg
+                stopA = min(stopA, (nl - sA) & M, (el - sA) & M)
+                stopB = min(stopB, (2 * nl - 2 * e) & M, (2 * el - 1 - 2 * e) & M)
+            if not lower_same:
+                key, st = int(self.nkey[n]), int(self.nstat[n])
+                base, rank = key >> 32, key & 0xFFFFFFFF
+                root, masked, leaf = bool(st & NS_ROOT), bool(st & NS_MASKED), bool(st & NS_LEAF)
+                nmut, ncom0 = st & NS_CNT, (st >> 14) & NS_CNT
+                c = c0 + cb
+                if root:
+                    if base + c + dsum <= bs:
+                        take(base + c + dsum, rank, 1, 0)
+                elif not masked:
+                    score, ncom = base + c + adj, ncom0 + dcom
+                    elig = (ncom > 0) if leaf else (ncom > 0 or ncom == nmut)
+                    if elig and score <= bs:
+                        take(score, rank, 1, int(ncom < nmut))
+                eA = min(sA + stopA, self.n)
+                if sA < eA:
+                    stretch(sA, eA, c0 + cb + dsum)
+            if not lower_end:
+                eB = self.n if stopB >= 0x80000000 else min(e + ((stopB + 1) >> 1), self.n)
+                if e < eB:
+                    stretch(e, eB, c0 + cB)
+        if first_node != 0 and self.n > 0:
+            stretch(0, min(first_node, self.n), c0)
+        return bs, br, cnt, bhu
+
     def whole_stream(self):
         """The stream-wide aggregate (Stream::whole): what a read without any event in the stream takes."""
         return self.range_exact(0, self.n)

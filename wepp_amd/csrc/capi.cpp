@@ -40,6 +40,7 @@ void release(wepp_mat* h) {
             if (L.join_ev[i]) (void)hipEventDestroy(L.join_ev[i]);
         }
         if (L.fork_ev) (void)hipEventDestroy(L.fork_ev);
+        if (L.route_ev) (void)hipEventDestroy(L.route_ev);
     }
     if (h->io_in) (void)hipFree(h->io_in);
     if (h->io_out) (void)hipFree(h->io_out);
@@ -160,25 +161,20 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         if ((rc = up_stream(st, (uint32_t)i, i + 1 < f.streams.size(), ds)) != WEPP_OK) return rc;
         h->streams.push_back(ds);
         h->stream_bytes.push_back(st.stream_bytes());
-        {
-            DevWalk dw{};
-            dw.n = st.n;
-            dw.rq_blocks = st.rq_blocks;
-            dw.last_ent = (uint32_t)st.ix_ent.size() - 1;
-            dw.whole = st.whole;
-            dw.has_pre = st.ix_pre.empty() ? 0u : st.ix_pre[0];
-            UP(dw.ix_head, st.ix_head) UP(dw.ix_ent, st.ix_ent) UP(dw.ix_nest, st.ix_nest) UP(dw.nrec, st.nrec)
-            UP(dw.rq_pre, st.rq_pre) UP(dw.rq_suf, st.rq_suf) UP(dw.rq_dst, st.rq_dst) UP(dw.sp, st.sp)
-            h->walks.push_back(dw);
-        }
+        h->walks.push_back(DevWalk{});      // (a view into the walk arena, filled in below)
         d.tau[i] = st.tau;
         h->stats.stream_tau[i] = st.tau;
         h->stats.stream_nodes[i] = st.n;
         h->stats.stream_bytes_of[i] = st.stream_bytes();
     }
-    // ---- the window crowns' arena: the walk structures of all of them, array by array (device_mat.hpp: WcInfo) ----
+    // ---- the WALK ARENA: the walk structures (position index, range-query tables) of every stream -- the window crowns
+    // first, then the tree-wide streams -- concatenated array by array into ONE allocation per array (device_mat.hpp:
+    // WcInfo = the offsets of a stream's slices; entry indices are absolute in the arena).  Which stream a read walks is a
+    // per-READ value (k_route: wsid), so one launch of k_walk serves the reads of all streams, sized without a look at
+    // the routing counters. ----
     {
-        std::vector<WcInfo> info(f.wcrowns.size() * WC_MAX);
+        const size_t n_wc = f.wcrowns.size() * WC_MAX;
+        std::vector<WcInfo> info(n_wc + f.streams.size());
         std::vector<IxHead> a_head;
         std::vector<IxEnt> a_ent;
         std::vector<uint8_t> a_nest, a_sp;
@@ -189,12 +185,16 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
             for (const Stream& st : wc) {
                 tot_n += st.n; tot_ent += st.ix_ent.size(); tot_head += st.ix_head.size(); tot_sp += st.sp.size(); tot_dst += st.rq_dst.size();
             }
+        const size_t wc_n = tot_n, wc_ent = tot_ent, wc_head = tot_head, wc_sp = tot_sp, wc_dst = tot_dst;   // (the window crowns' share)
+        for (const Stream& st : f.streams) {
+            tot_n += st.n; tot_ent += st.ix_ent.size(); tot_head += st.ix_head.size(); tot_sp += st.sp.size(); tot_dst += st.rq_dst.size();
+        }
         if (tot_ent >= 0xFFFFFFF0ull || tot_n >= 0xFFFFFFF0ull || tot_head >= 0xFFFFFFF0ull || tot_dst >= 0xFFFFFFF0ull) {
             release(h);
-            return set_error(WEPP_ELIMIT, "window crowns exceed 2^32 index entries");
+            return set_error(WEPP_ELIMIT, "the walk structures exceed 2^32 index entries");
         }
-        a_head.reserve(tot_head); a_ent.reserve(tot_ent); a_nest.reserve(tot_head); a_sp.reserve(tot_sp);
-        a_nrec.reserve(tot_n); a_pre.reserve(tot_n); a_suf.reserve(tot_n); a_dst.reserve(tot_dst);
+        a_head.reserve(wc_head); a_ent.reserve(wc_ent); a_nest.reserve(wc_head); a_sp.reserve(wc_sp);
+        a_nrec.reserve(wc_n); a_pre.reserve(wc_n); a_suf.reserve(wc_n); a_dst.reserve(wc_dst);
         for (size_t w = 0; w < f.wcrowns.size(); w++)
             for (size_t i = 0; i < f.wcrowns[w].size(); i++) {
                 const Stream& st = f.wcrowns[w][i];
@@ -222,6 +222,57 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
                 h->wc_nodes += st.n;
                 h->wc_count++;
             }
+        // one device allocation per array; the window crowns' (rebased) concatenation goes to its front, every tree-wide
+        // stream's arrays are copied from the image into their slices, the entry indices of a slice rebased by a kernel
+        DevWalk arena{};                           // (n = 0: never a stream of its own)
+        auto dev_array = [&](auto*& out, size_t count, const auto& front) -> int {
+            using T = std::remove_cv_t<std::remove_reference_t<decltype(front[0])>>;
+            void* p = nullptr;
+            const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+            hipError_t e2 = hipMalloc(&p, bytes);
+            if (e2 != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e2));
+            h->allocs.push_back(p);
+            h->stats.device_bytes += bytes;
+            if (!front.empty()) HIP_TRY(hipMemcpy(p, front.data(), front.size() * sizeof(T), hipMemcpyHostToDevice));
+            out = (T*)p;
+            return WEPP_OK;
+        };
+        IxHead* g_head; IxEnt* g_ent; uint8_t *g_nest, *g_sp; NodeRec* g_nrec; SegNode *g_pre, *g_suf, *g_dst;
+#define ARR(ptr, count, front) if ((rc = dev_array(ptr, count, front)) != WEPP_OK) { release(h); return rc; }
+        ARR(g_head, tot_head, a_head) ARR(g_ent, tot_ent, a_ent) ARR(g_nest, tot_head, a_nest) ARR(g_sp, tot_sp, a_sp)
+        ARR(g_nrec, tot_n, a_nrec) ARR(g_pre, tot_n, a_pre) ARR(g_suf, tot_n, a_suf) ARR(g_dst, tot_dst, a_dst)
+#undef ARR
+        arena.ix_head = g_head; arena.ix_ent = g_ent; arena.ix_nest = g_nest; arena.sp = g_sp;
+        arena.nrec = g_nrec; arena.rq_pre = g_pre; arena.rq_suf = g_suf; arena.rq_dst = g_dst;
+        {
+            size_t o_n = wc_n, o_ent = wc_ent, o_head = wc_head, o_sp = wc_sp, o_dst = wc_dst;
+            for (size_t i = 0; i < f.streams.size(); i++) {
+                const Stream& st = f.streams[i];
+                WcInfo& wi = info[n_wc + i];
+                wi.n = st.n;
+                wi.rq_blocks = st.rq_blocks;
+                wi.last_ent = (uint32_t)(o_ent + st.ix_ent.size() - 1);
+                wi.has_pre = st.ix_pre.empty() ? 0u : st.ix_pre[0];
+                wi.node_off = (uint32_t)o_n; wi.head_off = (uint32_t)o_head; wi.nest_off = (uint32_t)o_head; wi.dst_off = (uint32_t)o_dst;
+                wi.sp_off = o_sp;
+                wi.tau = st.tau;
+                wi.whole = st.whole;
+#define CP(dst, off, vec) if (!vec.empty()) HIP_TRY(hipMemcpy(dst + off, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
+                CP(g_head, o_head, st.ix_head) CP(g_ent, o_ent, st.ix_ent) CP(g_nest, o_head, st.ix_nest) CP(g_sp, o_sp, st.sp)
+                CP(g_nrec, o_n, st.nrec) CP(g_pre, o_n, st.rq_pre) CP(g_suf, o_n, st.rq_suf) CP(g_dst, o_dst, st.rq_dst)
+#undef CP
+                if (o_ent) HIP_TRY(launch_rebase_index(g_head + o_head, (uint32_t)st.ix_head.size(), g_ent + o_ent, (uint32_t)st.ix_ent.size(), (uint32_t)o_ent, nullptr));
+                // the stream's own view (plan-wise users: k_route, the chunked walks): entry indices are absolute, so the
+                // entries are addressed from the arena's base; positions and nodes are the stream's own
+                DevWalk& dw = h->walks[i];
+                dw.n = st.n; dw.rq_blocks = st.rq_blocks; dw.last_ent = wi.last_ent; dw.has_pre = wi.has_pre; dw.whole = st.whole;
+                dw.ix_head = g_head + o_head; dw.ix_ent = g_ent; dw.ix_nest = g_nest + o_head; dw.nrec = g_nrec + o_n;
+                dw.rq_pre = g_pre + o_n; dw.rq_suf = g_suf + o_n; dw.rq_dst = g_dst + o_dst; dw.sp = g_sp + o_sp;
+                o_n += st.n; o_ent += st.ix_ent.size(); o_head += st.ix_head.size(); o_sp += st.sp.size(); o_dst += st.rq_dst.size();
+            }
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        d.tw_base = (uint32_t)n_wc;
         // ... and their sweep streams, for the reads that cannot walk (k_sweep_arena): the same kind of arena; every
         // stream keeps its own tail padding (the sweep loads past a block's events and prefetches summaries)
         {
@@ -268,9 +319,6 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
                 }
             UP(d.wc_streams, ws)
         }
-        DevWalk arena{};                           // (n = 0: never a stream of its own)
-        UP(arena.ix_head, a_head) UP(arena.ix_ent, a_ent) UP(arena.ix_nest, a_nest) UP(arena.nrec, a_nrec)
-        UP(arena.rq_pre, a_pre) UP(arena.rq_suf, a_suf) UP(arena.rq_dst, a_dst) UP(arena.sp, a_sp)
         UP(d.wc_info, info)
         d.wc_windows = (uint32_t)f.wcrowns.size();
         h->stats.n_window_crowns = h->wc_count;
@@ -318,6 +366,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&L.join_ev[i], hipEventDisableTiming);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L.route_ev, hipEventDisableTiming);
     }
     for (uint32_t i = 0; i < wepp_mat::kRing && e == hipSuccess; i++) {
         e = hipEventCreate(&h->ev0[i]);
@@ -430,7 +479,15 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     bool ws_moved = false;
     auto grow = [&](size_t need) -> int {
         if (need <= L.ws_bytes) return WEPP_OK;
-        if (L.ws) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(L.ws); L.ws = nullptr; L.ws_bytes = 0; }
+        // (the plain walks of this call may already run on their side stream, out of the lists in this workspace)
+        if (L.ws) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipStreamSynchronize(L.side[MAX_STREAMS - 1]));
+            for (uint32_t i : {MAX_STREAMS - 6, MAX_STREAMS - 7, MAX_STREAMS - 3}) HIP_TRY(hipStreamSynchronize(L.side[i]));
+            (void)hipFree(L.ws);
+            L.ws = nullptr;
+            L.ws_bytes = 0;
+        }
         // (half as much again: the partials of a batch of long reads vary by a third with the tile size its longest
         // read allows, and a regrowth costs a hipFree + hipMalloc of ~100 MB -- 16 ms -- plus a second routing pass)
         need += need / 2;
@@ -450,7 +507,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // fixed part of the workspace: list | root_score | slot in block | jobs | sort keys in/out | sorted lists |
     // sort temp of the whole-tree plan and of the four walk classes (their sorts run on different side streams)
     constexpr uint32_t N_SORTS = 5;
-    const size_t fixed_bytes = tier_bytes + 4 * list_bytes + (sort_reads ? 3 * list_bytes + N_SORTS * sort_temp : 0);
+    // (+ the chunked walk classes sized blind: first job of a read, and per class its reads, its job table, three partials per job)
+    constexpr size_t blind_bytes = 2 * ((size_t)BLIND_CHUNKED_READS * 4 + (size_t)BLIND_JOB_CAP * 16);
+    const size_t fixed_bytes = tier_bytes + 8 * list_bytes + blind_bytes + (sort_reads ? 3 * list_bytes + N_SORTS * sort_temp : 0);
     {
         // before routing only the fixed regions are needed; reserve a typical partial size too
         int rc = grow(fixed_bytes + (size_t)n_reads * 12 * 2);
@@ -459,6 +518,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     uint8_t* tier_of = nullptr;
     uint32_t *list = nullptr, *slot_in_blk = nullptr, *key_in = nullptr, *key_out = nullptr, *val_in = nullptr;
     uint32_t* job_n = nullptr;       // jobs of every read whose walk is cut into chunks (k_route)
+    uint32_t* wlist[2] = {nullptr, nullptr};   // the plain walk classes' reads that have events in their stream (k_route appends them)
+    uint32_t* wwlist = nullptr;                // reads with many events, a wave each (wave_kernels.hip)
+    uint32_t *b_first = nullptr, *b_clist[2] = {nullptr, nullptr}, *b_jobs[2] = {nullptr, nullptr};   // the chunked classes sized blind (k_route's tables)
+    int32_t* b_ps[2] = {nullptr, nullptr};
+    uint32_t *b_pr[2] = {nullptr, nullptr}, *b_pc[2] = {nullptr, nullptr};
     uint32_t* wsid = nullptr;        // the window crown (index into DevMAT::wc_info) of every read routed to slot WC_SLOT
     int32_t* root_score = nullptr;
     void* sort_tmp = nullptr;
@@ -469,6 +533,17 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         root_score = (int32_t*)p; p += list_bytes;
         slot_in_blk = (uint32_t*)p; p += list_bytes;
         job_n = (uint32_t*)p; p += list_bytes;
+        wlist[0] = (uint32_t*)p; p += list_bytes;
+        wlist[1] = (uint32_t*)p; p += list_bytes;
+        b_first = (uint32_t*)p; p += list_bytes;
+        wwlist = (uint32_t*)p; p += list_bytes;
+        for (uint32_t cc = 0; cc < 2; cc++) {
+            b_clist[cc] = (uint32_t*)p; p += (size_t)BLIND_CHUNKED_READS * 4;
+            b_jobs[cc] = (uint32_t*)p; p += (size_t)BLIND_JOB_CAP * 4;
+            b_ps[cc] = (int32_t*)p; p += (size_t)BLIND_JOB_CAP * 4;
+            b_pr[cc] = (uint32_t*)p; p += (size_t)BLIND_JOB_CAP * 4;
+            b_pc[cc] = (uint32_t*)p; p += (size_t)BLIND_JOB_CAP * 4;
+        }
         wsid = mat->d_wsid_of + plan_base;
         if (sort_reads) {
             key_in = (uint32_t*)p; p += list_bytes;
@@ -488,39 +563,99 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // whole-genome samples are seeded (seed_kernels.hip) when work skipping is on and the tree carries signatures
     const uint32_t seed_min_hard = (mat->use_seeds && mat->use_crowns && mat->dev.seed_chunks) ? tun.seed_min_hard : 0xFFFFFFFFu;
     // ---- route the reads to streams ------------------------------------------------------
+    const uint32_t ev_slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
+    constexpr uint32_t BLIND16_STREAM = MAX_STREAMS - 6;     // (side stream of the second plain walk class)
+    constexpr uint32_t PLAN_STREAM = MAX_STREAMS - 7;
+    // Streams of a call.  The caller's stream runs k_route and, right behind it (no cross-stream wait: ~25 us), the
+    // chunked walks of the first class -- the longest chain of the common case; the plain walks and the second chunked
+    // class start from the routing kernel's event on side streams; everything the HOST has to size -- k_scatter, the
+    // counters' copy, the sweeps, the planned walks -- lives on the plan stream `ps`, off the walks' path.  All of them
+    // join the caller's stream at the end.
+    const bool walking = mat->use_walk && walk_max_events;
+    hipStream_t ps = walking ? L.side[PLAN_STREAM] : stream;
+    // one walk class out of k_route's tables: the plain classes from their read lists, the chunked ones from their job tables
+    auto blind_class = [&](uint32_t cls, hipStream_t q, bool fork_q) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (fork_q) e = hipStreamWaitEvent(q, L.route_ev, 0);
+        if (e != hipSuccess) return e;
+        if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
+            e = launch_walk_blind(mat->dev, cls, cls == PLAN_WALK8 ? stack8 : stack16, n_reads, wlist[cls], tier_info + TI_WCUR + cls, d_read_off, d_read_word,
+                                  root_score, d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work, wsid, q);
+        } else {
+            const uint32_t cc = cls - PLAN_WALKC8;
+            WalkJobs jb{};
+            jb.job_first = b_first;
+            jb.skip = tier_info + TI_JOVER + cc;
+            jb.job_n = job_n;
+            jb.part_score = b_ps[cc];
+            jb.part_rank = b_pr[cc];
+            jb.part_cnt = b_pc[cc];
+            e = launch_walk_jobs_blind(mat->dev, cls, cc ? stack16 : stack8, jb, b_jobs[cc], tier_info + TI_JCUR + cc, b_clist[cc], tier_info + TI_CCUR + cc,
+                                       d_read_off, d_read_word, root_score, d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work, wsid, q);
+        }
+        return e;
+    };
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
         tier_info = L.d_info + L.info_idx * TI_WORDS;
         uint32_t* tier_info_next = L.d_info + (L.info_idx ^ 1u) * TI_WORDS;
-        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, mat->use_walk ? walk_max_events : 0u, job_events, stack8, stack16, seed_min_hard, tun.seed_min_nodes, job_n, tier_of, root_score, blk_counts,
-                             tier_info, slot_in_blk, tier_info_next, wsid, stream));
+        // k_route places the reads that have no event in their stream itself and lists the other plain walkers; their
+        // walks are launched from those lists at once, sized for the worst case, on a side stream -- the routing
+        // counters' trip to the host, the planning of the rarer classes and k_scatter are off their path
+        RouteDirect direct{};
+        if (walking) direct = RouteDirect{{wlist[0], wlist[1]}, {b_clist[0], b_clist[1]}, {b_jobs[0], b_jobs[1]}, b_first, wwlist,
+                                          d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work};
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, walking ? walk_max_events : 0u, job_events, stack8, stack16, seed_min_hard, tun.seed_min_nodes, job_n, tier_of, root_score, blk_counts,
+                             tier_info, slot_in_blk, tier_info_next, wsid, direct, stream));
         L.info_idx ^= 1u;
-        HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, stream));
+        HIP_TRY(hipEventRecord(mat->ev0[ev_slot], stream));        // (the timed span of a call: everything behind the routing kernel)
+        if (walking) {
+            HIP_TRY(hipEventRecord(L.route_ev, stream));
+            // Launched BLIND, sized for the worst case, before the routing counters are back: the two classes of reads with
+            // at most WALK8_K entries -- nearly every read of a sequencing run.  The plain walks go on the caller's stream, right
+            // behind k_route (no cross-stream wait: ~25 us); on a side stream the reads with many events, a wave each, and
+            // the chunked class (reads with even more events, cut into jobs: k_route has entered them into a job table; walk +
+            // combination leave at once when the class outgrew the table, TI_JOVER: the host's planned launch takes it).  The classes of 9 - 16 entries are launched from the
+            // same tables once the counters say they hold reads (blind_class below): two launches sized for a million
+            // reads that find a handful cost ~20 us of workgroup dispatch each, and eight API calls per device call.
+            HIP_TRY(blind_class(PLAN_WALK8, stream, false));
+            {   // the reads with many events, a wave per 64 of them (wave_kernels.hip), then what is left of the chunked class
+                hipStream_t q = L.side[MAX_STREAMS - 1];
+                HIP_TRY(hipStreamWaitEvent(q, L.route_ev, 0));
+                HIP_TRY(launch_walk_wave(mat->dev, wwlist, tier_info + TI_WWCUR, n_reads, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score, d_num_best,
+                                         d_flags, mat->d_work, wsid, q));
+                HIP_TRY(blind_class(PLAN_WALKC8, q, false));
+                HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
+            }
+            HIP_TRY(hipStreamWaitEvent(ps, L.route_ev, 0));
+        }
+        HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, ps));
         return WEPP_OK;
     };
+
     {
         int rc = route();
         if (rc != WEPP_OK) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(L.h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
     // the host sizes the launches from the counters, and the GPU idles until it has: poll for them (a
     // blocking wait adds its wake-up, ~15 us per call, to that idle time) ...
     {
-        // ... spinning for the first 50 us (the routing kernels of an idle stream take ~30), then yielding the core
+        // ... spinning for the first 200 us (the routing kernel of a million reads takes ~45, behind the reads' H2D), then yielding the core
         // between queries -- eight ranks spinning on the cores of one container starve their own staging workers --,
         // and after ~2 ms (a long queue in front of this call) waiting blocking
         hipError_t q = hipErrorNotReady;
         const auto t_poll = std::chrono::steady_clock::now();
         for (;;) {
-            q = hipStreamQuery(stream);
+            q = hipStreamQuery(ps);
             if (q != hipErrorNotReady) break;
             const auto waited = std::chrono::steady_clock::now() - t_poll;
             if (waited > std::chrono::milliseconds(2)) break;
-            if (waited > std::chrono::microseconds(50)) std::this_thread::yield();
+            if (waited > std::chrono::microseconds(200)) std::this_thread::yield();
         }
         (void)hipGetLastError();   // "not ready" is not an error: keep it out of the launchers' hipGetLastError()
-        if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(stream));
+        if (q != hipSuccess) HIP_TRY(hipStreamSynchronize(ps));
     }
     const uint32_t* info = L.h_info;
     for (uint32_t cc = 0; cc < 2; cc++) {
@@ -529,6 +664,13 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         mat->job_events[cc] = je <= WALK_JOB_EVENTS ? je : ((je + 15u) & ~15u);       // (what the NEXT call's k_route cuts this class's walks into)
     }
 
+    const bool blind_walks = mat->use_walk && walk_max_events;       // (launched behind k_route, joined below)
+    bool late16[2] = {false, false};
+    if (blind_walks) {
+        // the classes of 9 - 16 entries, from k_route's tables like the others, when they hold reads
+        if (info[TI_WCUR + 1]) { HIP_TRY(blind_class(PLAN_WALK16, L.side[BLIND16_STREAM], true)); HIP_TRY(hipEventRecord(L.join_ev[BLIND16_STREAM], L.side[BLIND16_STREAM])); late16[0] = true; }
+        if (info[TI_CCUR + 1] && !info[TI_JOVER + 1]) { HIP_TRY(blind_class(PLAN_WALKC16, L.side[MAX_STREAMS - 3], true)); HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 3], L.side[MAX_STREAMS - 3])); late16[1] = true; }
+    }
     // ---- plan the launches ---------------------------------------------------------
     struct Plan { uint32_t t, count, off, T, ntiles, nchunks, bpc, ent_cap, key_cap, lds_bytes; bool s_in_lds, dense, window, win_table; size_t part_off; const uint32_t* lst; const DevStream* st; uint64_t sbytes; };
     Plan plans[MAX_PLANS];
@@ -537,8 +679,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     const uint32_t bm_bytes = mat->dev.bm_words * 4;
     if (bm_bytes > 128 * 1024) return set_error(WEPP_ELIMIT, "position bitmap does not fit in LDS");
     // walk plans (device_mat.hpp): the reads of one (class, stream) that walk their own events
-    WalkPlans walk[2]{}, walkc[2]{};
-    uint32_t walk_off[2][MAX_STREAMS] = {}, walkc_off[2] = {0, 0};   // list offsets of the walk plans
+    WalkPlans walkc[2]{};
+    uint32_t walkc_off[2] = {0, 0};   // list offsets of the chunked walk plans
     uint64_t walk_reads = 0, n_jobs[2] = {0, 0};
     uint32_t walkc_reads[2] = {0, 0};
     uint32_t arena_n = 0, arena_off = 0, arena_maxk = 1;
@@ -565,6 +707,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             // the reads with many events: their walks are cut into jobs (below); the plans of a chunked class
             // are the streams, the jobs of stream t numbered behind those of the streams before it
             const uint32_t cc = cls - PLAN_WALKC8;
+            if (blind_walks && !info[TI_JOVER + cc]) { walk_reads += count; continue; }     // (launched blind behind k_route)
             WalkPlans& wc = walkc[cc];
             WalkPlanDev& d = wc.p[wc.n];
             d.tier = t;
@@ -580,15 +723,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             continue;
         }
         if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
-            WalkPlans& wp = walk[cls];
-            WalkPlanDev& d = wp.p[wp.n];
-            d.tier = t;
-            d.n_list = count;
-            walk_off[cls][wp.n] = info[TI_OFF + id];
-            d.list = nullptr;
-            d.wave_end = (wp.n ? wp.p[wp.n - 1].wave_end : 0u) + walk_plan_waves(count);
-            wp.n++;
-            walk_reads += count;
+            walk_reads += count;            // (placed by k_route itself or by the blind walk launches behind it)
             continue;
         }
         if (cls == PLAN_SWEEP && t == WC_SLOT) {
@@ -669,8 +804,6 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     }
     char* part_base = (char*)L.ws + fixed_bytes;
     // (the workspace may have moved above: every pointer into it is taken from here on)
-    for (uint32_t cls = 0; cls < 2; cls++)
-        for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = list + walk_off[cls][k];
     for (uint32_t cc = 0; cc < 2; cc++)
         for (uint32_t k = 0; k < walkc[cc].n; k++) walkc[cc].p[k].list = list + walkc_off[cc];
     const bool debug_plans = tun.debug_plans;
@@ -683,8 +816,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                     p.lds_bytes, p.ent_cap, p.key_cap, p.part_off);
         // the reads that sweep the whole tree go by first listed position (sort_reads.hip)
         if (sort_reads && !p.window && p.t + 1 == ns && p.count >= SORT_MIN_READS) {
-            HIP_TRY(launch_first_pos(list + p.off, p.count, d_read_off, d_read_word, key_in + p.off, stream));
-            HIP_TRY(launch_sort_reads(key_in + p.off, key_out + p.off, list + p.off, val_in + p.off, p.count, sort_tmp, sort_temp, stream));
+            HIP_TRY(launch_first_pos(list + p.off, p.count, d_read_off, d_read_word, key_in + p.off, ps));
+            HIP_TRY(launch_sort_reads(key_in + p.off, key_out + p.off, list + p.off, val_in + p.off, p.count, sort_tmp, sort_temp, ps));
             p.lst = val_in + p.off;
         }
     }
@@ -693,8 +826,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // The plain (short-read) plans are fused into ONE launch, longest chunks first; dense
     // and out-of-LDS plans get their own launch on a side stream forked from / joined into
     // `stream`.  Every plan's finalize follows its sweep.
-    const uint32_t slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
-    HIP_TRY(hipEventRecord(mat->ev0[slot], stream));
+    const uint32_t slot = ev_slot;
     uint64_t passes = 0, bytes = 0;
     auto parts = [&](const Plan& p, int32_t*& ps, uint32_t*& pr, uint32_t*& pc) {
         ps = (int32_t*)(part_base + p.part_off);
@@ -712,16 +844,22 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         bytes += (uint64_t)plans[i].ntiles * plans[i].sbytes;
     }
     std::sort(order, order + n_plain, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
-    const bool walks = walk[0].n || walk[1].n || walkc[0].n || walkc[1].n;
+    const bool walks = walkc[0].n || walkc[1].n;
     if (n_jobs[0] + n_jobs[1] >= (1ull << 31)) return set_error(WEPP_ELIMIT, "too many walk jobs in one call; split the batch");
     for (uint32_t cls = 0; cls < 2; cls++)
-        if (walk[cls].n) passes += walk[cls].p[walk[cls].n - 1].wave_end;   // a walk "pass" = one wave of 64 reads
+        passes += (info[TI_WCUR + cls] + 63) / 64;      // a walk "pass" = one wave of 64 reads
+    passes += (info[TI_RESOLVED] + 63) / 64 + info[TI_WWCUR] + info[TI_WWCUR + 1];
+    for (uint32_t cc = 0; cc < 2; cc++)
+        if (blind_walks && !info[TI_JOVER + cc]) {
+            passes += (info[TI_JCUR + cc] + 63) / 64;
+            bytes += (uint64_t)info[TI_CCUR + cc] * 40 + (uint64_t)info[TI_JCUR + cc] * 16;      // (job table, partials, the combination's reads and results)
+        }
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
-    const uint32_t n_walk_chains = ((walk[0].n || walk[1].n) ? 1u : 0u) + ((walkc[0].n || walkc[1].n) ? 1u : 0u);
+    const uint32_t n_walk_chains = (walkc[0].n || walkc[1].n) ? 1u : 0u;
     const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u) + (seed_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
     const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
-    if (fork) HIP_TRY(hipEventRecord(L.fork_ev, stream));
+    if (fork) HIP_TRY(hipEventRecord(L.fork_ev, ps));
     // the side streams join the caller's stream only after everything has been launched: a join in between
     // would make the launches behind it wait for the side stream's kernels
     uint32_t joins[2 * MAX_STREAMS], n_joins = 0;     // (a stream may be listed twice: waiting twice for its event is harmless)
@@ -747,27 +885,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     if (walks) {
         // the walks write the final per-read results themselves; the plain ones, the chunked ones and the
         // sweeps run side by side (the walks wait on memory most of the time)
-        hipStream_t q = fork ? L.side[MAX_STREAMS - 1] : stream;
-        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
-        for (uint32_t cls = 0; cls < 2; cls++) {
-            if (!walk[cls].n) continue;
-            // (the plain classes keep the caller's order unless WEPP_WALK_SORT_PLAIN=1: their reads have at most 16
-            // events each, mostly on streams the L2s hold anyway, and a sort of 1 M reads costs 0.15 ms of a 0.3 ms step)
-            const bool sort_plain = tun.walk_sort_plain;
-            bool sorted = false;
-            if (sort_plain) {
-                int rc = sort_class(cls, 1 + cls, q, sorted);
-                if (rc != WEPP_OK) return rc;
-            }
-            if (sorted)
-                for (uint32_t k = 0; k < walk[cls].n; k++) walk[cls].p[k].list = val_in + walk_off[cls][k];
-            HIP_TRY(launch_walk(mat->dev, walk[cls], cls, info[TI_OPEN + cls], d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
-                                d_num_best, d_flags, mat->d_work, wsid, q));
-        }
-        if (fork) {
-            HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
-            joins[n_joins++] = MAX_STREAMS - 1;
-        }
+        hipStream_t q = ps;
         if (walkc[0].n || walkc[1].n) {
             // chunked walks, per class: jobs per read in list order -> exclusive scan -> the walk (a partial per
             // job; a job finds its read by bisection in the scanned offsets) -> one combination per read.
@@ -831,7 +949,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     }
     for (uint32_t k = 0; k < n_other; k++) {
         const Plan& p = plans[others[k]];
-        hipStream_t q = fork ? L.side[k % OTHER_SIDE_STREAMS] : stream;
+        hipStream_t q = fork ? L.side[k % OTHER_SIDE_STREAMS] : ps;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         int32_t* ps; uint32_t *pr, *pc;
         parts(p, ps, pr, pc);
@@ -849,7 +967,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     if (arena_n) {
         if (arena_maxk > MAX_TILE_ENTRIES) return set_error(WEPP_ELIMIT, "a read inside one genome window lists more than 8192 positions");
         const uint32_t cap = (arena_maxk + 63) & ~63u;
-        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 1] : stream;      // (the last of the sweeps' side streams)
+        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 1] : ps;      // (the last of the sweeps' side streams)
         if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         int32_t* ps = (int32_t*)(part_base + arena_part);
         uint32_t *pr = (uint32_t*)(ps + (size_t)arena_n * ARENA_CHUNKS), *pc = pr + (size_t)arena_n * ARENA_CHUNKS;
@@ -868,7 +986,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     if (seed_n) {
         if (seed_maxk > SEED_MAX_ENTRIES) return set_error(WEPP_EDEVICE, "routing seeded a sample with too many entries");
         const uint32_t cap = (seed_maxk + 63) & ~63u;
-        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 2] : stream;
+        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 2] : ps;
         if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         if (debug_plans) fprintf(stderr, "[plan] seed count=%u maxk=%u chunks=%u lds=%u\n", seed_n, seed_maxk, mat->dev.seed_chunks, seed_lds_bytes(mat->dev, cap));
         HIP_TRY(launch_seed(mat->dev, mat->streams.back(), list + seed_off, seed_n, cap, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
@@ -903,11 +1021,19 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             lds_max = std::max(lds_max, p.lds_bytes);
         }
         pl.n = n_plain;
-        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, stream));
+        HIP_TRY(launch_sweep_multi(mat->dev, pl, d_read_off, d_read_word, root_score, lds_max, ps));
         HIP_TRY(launch_finalize_multi(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags,
-                                      stream));
+                                      ps));
     }
-    for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[joins[i]], 0));
+    for (uint32_t i = 0; i < n_joins; i++) HIP_TRY(hipStreamWaitEvent(ps, L.join_ev[joins[i]], 0));
+    if (blind_walks) {
+        // the plan stream and the blind walks' side streams join the caller's stream
+        HIP_TRY(hipEventRecord(L.join_ev[PLAN_STREAM], ps));
+        HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[PLAN_STREAM], 0));
+        HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[MAX_STREAMS - 1], 0));
+        if (late16[0]) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[BLIND16_STREAM], 0));
+        if (late16[1]) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[MAX_STREAMS - 3], 0));
+    }
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
     mat->n_timed++;
     mat->last_passes = passes;
@@ -1163,38 +1289,49 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         const size_t a = lo + (hi - lo) * part / PO, b = lo + (hi - lo) * (part + 1) / PO;
         std::memcpy((uint32_t*)dst[i] + a, po + (size_t)i * n_reads + a, (b - a) * 4);
     };
-    const std::function<void(uint32_t)> task = [&](uint32_t t) { if (t < n_stage) stage_task(t); else copy_task(t - n_stage); };
+    double t_launched = 0;
 
     // ---- the launch sequence (this thread): H2D, kernels, D2H of every sub-batch ----
     int rc = WEPP_OK;
     std::string rc_msg;
     double t_launch[wepp_mat::kPipeMax] = {};
     bool rejected = false;
+    // the words of sub-batch k go up chunk by chunk, each as soon as its reads are checked and staged; up_ok[k] = none of its
+    // reads was rejected.  A sub-batch's upload is enqueued BEFORE the device call of the one before it: that call keeps
+    // the launch thread until its routing counters are back, and the copy engine works meanwhile.
+    bool up_ok[wepp_mat::kPipeMax] = {};
+    hipError_t up_he[wepp_mat::kPipeMax] = {};
+    auto upload = [&](uint32_t k) {
+        const uint32_t* src_off = in_pinned ? read_off : pin_off;
+        const uint32_t* src_word = in_pinned ? read_word : pin_word;
+        hipError_t he = hipSuccess;
+        bool ok = rc == WEPP_OK && !rejected;
+        for (uint32_t ck = k * CPS; ck < (k + 1) * CPS && ok && he == hipSuccess; ck++) {
+            while (staged[ck].load(std::memory_order_acquire) < PS) std::this_thread::yield();
+            for (uint32_t t = ck * PS; t < (ck + 1) * PS && ok; t++) ok = bad[t] == 0xFFFFFFFFu;
+            if (!ok) break;
+            const uint32_t clo = chunk_lo(ck), chi = chunk_lo(ck + 1);
+            const uint32_t w0 = read_off[clo], w1 = read_off[chi];
+            // (offset `clo` went up with the chunk before: the kernels of the sub-batch before may be reading it)
+            const uint32_t o0 = ck ? clo + 1 : clo;
+            he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(chi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+            if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+        }
+        if (ok && he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d);
+        if (!ok) rejected = true;      // nothing of a rejected batch reaches a kernel, and nothing behind it is worth placing
+        up_ok[k] = ok;
+        up_he[k] = he;
+    };
     auto launch_all = [&]() {
+        upload(0);
         for (uint32_t k = 0; k < S; k++) {
             const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
-            const uint32_t* src_off = in_pinned ? read_off : pin_off;
-            const uint32_t* src_word = in_pinned ? read_word : pin_word;
-            hipError_t he = hipSuccess;
-            bool ok = rc == WEPP_OK && !rejected;
-            // the sub-batch's chunks go up one by one, each as soon as its reads are checked and staged
-            for (uint32_t ck = k * CPS; ck < (k + 1) * CPS && ok && he == hipSuccess; ck++) {
-                while (staged[ck].load(std::memory_order_acquire) < PS) std::this_thread::yield();
-                for (uint32_t t = ck * PS; t < (ck + 1) * PS && ok; t++) ok = bad[t] == 0xFFFFFFFFu;
-                if (!ok) break;
-                const uint32_t clo = chunk_lo(ck), chi = chunk_lo(ck + 1);
-                const uint32_t w0 = read_off[clo], w1 = read_off[chi];
-                // (offset `clo` went up with the chunk before: the kernels of the sub-batch before may be reading it)
-                const uint32_t o0 = ck ? clo + 1 : clo;
-                he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(chi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
-                if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
-            }
-            if (!ok) {       // nothing of a rejected batch reaches a kernel, and nothing behind it is worth placing
-                rejected = true;
+            if (k + 1 < S) upload(k + 1);
+            hipError_t he = up_he[k];
+            if (!up_ok[k]) {
                 launched[k].store(-1, std::memory_order_release);
                 continue;
             }
-            if (he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d);
             const uint32_t ln = k % wepp_mat::kLanes;             // (sub-batches alternate between the handle's two lanes)
             hipStream_t cs = mat->pipe_compute[ln];
             if (he == hipSuccess) he = hipStreamWaitEvent(cs, mat->pipe_up[k], 0);
@@ -1223,9 +1360,19 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         }
     };
     if (big) {
-        mat->pool->start(n_stage + n_copy, task);
+        // two rounds on the pool: the staging tasks while this thread launches; the copy-out tasks once every sub-batch's
+        // copies are enqueued.  (One round of both had the workers that ran out of staging tasks spin -- yield in a loop
+        // -- for their sub-batch's launch: fifteen spinning threads beside the launch thread, on a container of sixteen
+        // cores, delayed the thread they were waiting for.)
+        const std::function<void(uint32_t)> stage_only = [&](uint32_t t) { stage_task(t); };
+        mat->pool->start(n_stage, stage_only);
         launch_all();
         mat->pool->finish();
+        if (dbg_time) t_launched = since();
+        if (n_copy) {
+            const std::function<void(uint32_t)> copy_only = [&](uint32_t t) { copy_task(t); };
+            mat->pool->run(n_copy, copy_only);
+        }
     } else {
         for (uint32_t t = 0; t < n_stage; t++) stage_task(t);
         launch_all();
@@ -1263,7 +1410,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         fprintf(stderr, "[place_batch] %u reads in %u sub-batches (%s in, %s out): D2H of sub-batch k enqueued at", n_reads, S,
                 in_pinned ? "caller-pinned" : "staged", any_staged_out ? "staged" : "caller-pinned");
         for (uint32_t k = 0; k < S; k++) fprintf(stderr, " %.3f", t_launch[k]);
-        fprintf(stderr, " ms; total %.3f ms\n", since());
+        fprintf(stderr, " ms; every launch enqueued at %.3f ms; total %.3f ms\n", t_launched, since());
     }
     return WEPP_OK;
 }
@@ -1497,7 +1644,7 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     uint32_t* tier_info_next = mat->lane[0].d_info + (mat->lane[0].info_idx ^ 1u) * TI_WORDS;
     uint32_t* blk_counts = mat->lane[0].d_info + 2 * TI_WORDS;
     HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns ? 3 : 0, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
-                         0xFFFFFFFFu, 0u, d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, nullptr));
+                         0xFFFFFFFFu, 0u, d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, RouteDirect{}, nullptr));
     mat->lane[0].info_idx ^= 1u;
     HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
     HIP_TRY(hipMemcpy(mat->lane[0].h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -88,6 +88,7 @@ struct DevMAT {
     const WcInfo* wc_info;        // [wc_windows * WC_MAX] the window crowns of every genome window, increasing tau
     const DevStream* wc_streams;  // [wc_windows * WC_MAX] their sweep streams (k_sweep_arena)
     uint32_t wc_windows;          // 0: none built
+    uint32_t tw_base;             // wc_info[tw_base + t] = tree-wide stream t as a slice of the same arena (what a read that walks it gets as wsid)
     uint32_t win_n[MAX_WINDOWS];  // nodes of window w's stream when it is a crown (all the window's candidates, flatmat.hpp), 0xFFFFFFFF when the whole tree
     // seed signatures (flatmat.hpp): nibble (position, chunk of the whole-tree stream); seed_chunks == 0: none built
     const uint32_t* seed_sig;
@@ -148,7 +149,7 @@ constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of 
 // waves of a walk plan are padded to a multiple of this, so that every plan starts at a workgroup index that is a
 // multiple of the XCD count and its waves can be dealt to the XCDs in contiguous runs (k_walk)
 constexpr uint32_t WALK_PLAN_ALIGN = WALK_XCDS * WALK_WAVES;
-inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
+__host__ __device__ inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
 constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
@@ -166,6 +167,8 @@ struct WalkPlanDev {
 // what a chunked walk needs beside its plans
 struct WalkJobs {
     uint32_t n_list, pad;        // reads of the class
+    const uint32_t* job_first;   // blind launches (k_route's tables): [n_reads] first job of a read; job j belongs to read blind_list[j]
+    const uint32_t* skip;        // blind launches: != 0 -> the class was left to the host's planned launch: leave at once
     const uint32_t* job_off;     // [n_list] first job of the read at a list position (ascending: a job finds its read by bisection)
     const uint32_t* job_n;       // [n_reads] jobs of a read (by read index)
     int32_t* part_score;         // [jobs]
@@ -180,6 +183,12 @@ struct WalkPlans {
 hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const uint32_t* d_read_off,
                        const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score,
                        uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
+// the plain walks of one class sized BLIND: the reads are list[0 .. *count) (k_route's list and cursor, both on the device),
+// the grid is the worst case (max_reads lanes), every read walks the arena slice wsid names; waves beyond the count leave
+hipError_t launch_walk_blind(const DevMAT& m, uint32_t cls, uint32_t stack_rows, uint32_t max_reads, const uint32_t* list, const uint32_t* count,
+                             const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j,
+                             int32_t* score, uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
+                             hipStream_t stream);
 // the chunked walks of one call: job counts gathered into list order (scan input), the walk itself (partials per job) and the combination per read
 hipError_t launch_gather_jobs(const uint32_t* list, uint32_t n_list, const uint32_t* job_n, uint32_t* out, hipStream_t stream);
 hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint32_t open_max, const WalkJobs& jb, const uint32_t* d_read_off,
@@ -188,6 +197,17 @@ hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, 
 hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t n_list, const WalkJobs& jb,
                                 const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t* best_bfs_j,
                                 int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
+// the reads with many events: list[0 .. count[0]) a wave each, list[n_reads - count[1] .. n_reads) a block each (k_route's
+// two-ended list and its cursors), a persistent grid
+hipError_t launch_walk_wave(const DevMAT& m, const uint32_t* list, const uint32_t* count, uint32_t n_reads, const uint32_t* d_read_off,
+                            const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best,
+                            uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
+// a chunked class sized blind: jobs[0 .. *n_jobs) (k_route's table), partials into jb.part_*, then the combination over
+// clist[0 .. *n_class); both leave at once when *jb.skip != 0
+hipError_t launch_walk_jobs_blind(const DevMAT& m, uint32_t cls, uint32_t stack_rows, const WalkJobs& jb, const uint32_t* jobs, const uint32_t* n_jobs,
+                                  const uint32_t* clist, const uint32_t* n_class, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                                  const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags,
+                                  unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream);
 hipError_t scan_u32_temp_bytes(uint32_t n, size_t* bytes);
 hipError_t launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, void* temp, size_t temp_bytes,
                                      hipStream_t stream);
@@ -207,7 +227,10 @@ struct SweepPlans {
     SweepPlanDev p[MAX_STREAMS];
 };
 
-constexpr uint32_t ROUTE_BLOCKS = 256;    // grid of k_route / k_scatter (contiguous slices of the reads); 1024 blocks: route
+#ifndef WEPP_ROUTE_BLOCKS
+#define WEPP_ROUTE_BLOCKS 256
+#endif
+constexpr uint32_t ROUTE_BLOCKS = WEPP_ROUTE_BLOCKS;    // grid of k_route / k_scatter (contiguous slices of the reads); 1024 blocks: route
                                           // 30 -> 22 us but the per-block prefix over earlier blocks in k_scatter 29 -> 92 us
 constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chains of dependent loads overlap
 
@@ -215,11 +238,31 @@ constexpr uint32_t ROUTE_THREADS = 1024;  // 16 waves per CU: the per-read chain
 // the counters the next call will use (they must be zero before its k_route)
 // seed_min_hard / seed_min_nodes: a read left to the sweeps with at least that many reference-excluding entries, on a
 // tree-wide stream of at least that many nodes, becomes a seeded sample (seed_min_hard == 0xFFFFFFFF: none does)
+// What k_route does beside the plan of every read when `direct` is given (a placement call; wepp_best_nodes only
+// routes): a read that walks (plain classes) and has NO event in its stream -- none of its positions is mutated there
+// -- is placed on the spot: the stream-wide aggregate is its answer (results into direct.best_bfs_j ...); the other
+// plain walkers are appended to their class's list (direct.wlist[cls], cursor in tier_info[TI_WCUR + cls]), from which
+// k_walk is launched WITHOUT waiting for the routing counters to reach the host.
+struct RouteDirect {
+    uint32_t* wlist[2];          // [n_reads] each, or nullptr: no direct placement / lists
+    uint32_t* clist[2];          // [BLIND_CHUNKED_READS] the chunked classes' reads
+    uint32_t* jobs[2];           // [BLIND_JOB_CAP] read of every job of a chunked class
+    uint32_t* job_first;         // [n_reads] first job of a chunked read in its class's table
+    uint32_t* wwlist;            // [n_reads] reads with WALK_MAX_EVENTS < events <= WAVE_WALK_MAX_EVENTS (wave_kernels.hip): <= 64 from the front, more from the back
+    uint32_t* best_bfs_j;
+    int32_t* score;
+    uint32_t* num_best;
+    uint32_t* flags;
+    unsigned long long* work_counter;
+};
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
                         uint32_t seed_min_hard, uint32_t seed_min_nodes,
                         uint32_t* job_n, uint8_t* tier_of, int32_t* root_score, uint32_t* blk_counts,
-                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, uint32_t* wsid, hipStream_t stream);
+                        uint32_t* tier_info, uint32_t* slot_in_blk, uint32_t* tier_info_next, uint32_t* wsid, const RouteDirect& direct,
+                        hipStream_t stream);
+// entry indices of a stream's slice of the walk arena (IxHead::off, IxEnt::up) made absolute: += ent_off
+hipError_t launch_rebase_index(IxHead* heads, uint32_t n_heads, IxEnt* ents, uint32_t n_ents, uint32_t ent_off, hipStream_t stream);
 // the seeded samples of one call: a workgroup per sample writes its final results (seed_kernels.hip)
 uint32_t seed_lds_bytes(const DevMAT& m, uint32_t ent_cap);
 hipError_t seed_set_max_lds(uint32_t bytes);
@@ -331,6 +374,18 @@ hipError_t sweep_set_max_lds(uint32_t bytes);
 constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI_JOBS = 3 * MAX_PLANS + 1,
                    TI_OPEN = TI_JOBS + 2 * MAX_STREAMS,      // [4] deepest stack of the walk classes (WALK8, WALK16, WALKC8, WALKC16)
                    TI_EVENTS = TI_OPEN + 4,                  // [2] events (in units of 64) of the reads of the two chunked classes
-                   TI_WORDS = TI_EVENTS + 2;
+                   TI_WCUR = TI_EVENTS + 2,                  // [2] reads k_route appended to the plain walk classes' lists (the walks' grids are sized blind)
+                   TI_RESOLVED = TI_WCUR + 2,                // [1] reads k_route placed itself (no event in their stream: the stream-wide aggregate is the answer)
+                   TI_JCUR = TI_RESOLVED + 1,                // [2] jobs k_route entered into the chunked classes' job tables (their walks are sized blind too)
+                   TI_CCUR = TI_JCUR + 2,                    // [2] reads it entered into the chunked classes' lists
+                   TI_JOVER = TI_CCUR + 2,                   // [2] != 0: the class outgrew its blind tables (or is large enough to be sorted): the host plans it
+                   TI_WWCUR = TI_JOVER + 2,                  // [2] reads k_route listed for the walk without a walk (wave_kernels.hip): <= 64 events, more
+                   TI_WORDS = TI_WWCUR + 2;
+// the chunked walk classes sized blind: tables of this many jobs / reads per class; a class that outgrows them (N-rich
+// batches on the tree-wide streams: millions of jobs, which the planned path also sorts by position) is left to the host
+constexpr uint32_t BLIND_JOB_CAP = 1u << 20, BLIND_CHUNKED_READS = 32768;
+// a read with more than WALK_MAX_EVENTS and at most this many events is placed by a wave of its own, lane = list entry
+// (wave_kernels.hip); beyond, its walk is cut into jobs (the chunked classes).  A multiple of 64.
+constexpr uint32_t WAVE_WALK_MAX_EVENTS = 256;
 
 }  // namespace wepp

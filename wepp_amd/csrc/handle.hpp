@@ -34,6 +34,7 @@ struct PlaceLane {
     // the launch chains of a call are independent: they run concurrently on side streams
     hipStream_t side[MAX_STREAMS] = {};
     hipEvent_t fork_ev = nullptr, join_ev[MAX_STREAMS] = {};
+    hipEvent_t route_ev = nullptr;    // behind k_route: the plain walks start from here on their side stream, before the host has the counters
 };
 
 struct wepp_mat {

@@ -14,6 +14,14 @@
 
 namespace wepp {
 
+#ifdef WEPP_ROUTE_STATS   // (profiling build, tools/build_variant.sh: clock ticks of block 0's first wave by phase of k_route)
+__device__ unsigned long long g_route_stats[16];
+#define ROUTE_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_route_stats[i] += now_ - last_; last_ = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ROUTE_STAMP(i)
+#endif
+
 // -----------------------------------------------------------------------------
 // k_route: theta(read) = score(root) + |S| -> index of the smallest stream whose
 // tau covers it.  Per-(block, tier) counts go to blk_counts, per-tier totals and
@@ -30,8 +38,21 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                                                           uint32_t* __restrict__ tier_info,
                                                           uint32_t* __restrict__ slot_in_blk,
                                                           uint32_t* __restrict__ tier_info_next,
-                                                          uint32_t* __restrict__ wsid) {
-    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2];
+                                                          uint32_t* __restrict__ wsid, RouteDirect direct) {
+#ifdef WEPP_ROUTE_STATS
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2], resolved_of[1];
+    // the window crowns' routing table -- bound and size of every crown of every genome window -- in LDS: a read's scan of
+    // its window's crowns used to be a chain of loads from the 80-byte records of the device table
+    __shared__ int32_t wc_tau[MAX_WINDOWS * WC_MAX];
+    __shared__ uint32_t wc_n[MAX_WINDOWS * WC_MAX];
+    for (uint32_t i = threadIdx.x; i < m.wc_windows * WC_MAX; i += blockDim.x) { wc_tau[i] = m.wc_info[i].tau; wc_n[i] = m.wc_info[i].n; }
+    __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2];
+    if (threadIdx.x < 2) { cj_count[threadIdx.x] = 0; cl_count[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) ww_count[0] = ww_count[1] = 0;
+    if (threadIdx.x == 0) resolved_of[0] = 0;
+    if (threadIdx.x < 2) wl_count[threadIdx.x] = 0;
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
     // (two fill kernels, ~10 us) in front of every call
     if (blockIdx.x == 0 && threadIdx.x < TI_WORDS) tier_info_next[threadIdx.x] = 0;
@@ -40,12 +61,20 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     if (threadIdx.x < 2) events_of[threadIdx.x] = 0;
     if (threadIdx.x < 2 * MAX_STREAMS) jobs_of[threadIdx.x] = 0;
     __syncthreads();
+    ROUTE_STAMP(0);      // prologue
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
     // four reads per thread and round: their offsets, then their first two words, are requested together
     // (one read after the other, every read cost its thread three memory round trips in a row)
-    for (uint32_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4 * blockDim.x) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // (every thread of the block runs the same number of rounds: the walkers' list slots are reserved per block and round)
+    for (uint32_t rbase = lo; rbase < hi; rbase += 4 * blockDim.x) {
+      const uint32_t r0 = rbase + threadIdx.x;
       uint32_t so4[4], k4[4], fw[4][2];
+      uint32_t app4[4] = {0, 0, 0, 0}, aslot4[4] = {0, 0, 0, 0};     // plain walk class + 1 and slot among the block's walkers of the class
+      uint32_t cj4[4] = {0, 0, 0, 0}, cjs4[4] = {0, 0, 0, 0}, cls4[4] = {0, 0, 0, 0}, cnj4[4] = {0, 0, 0, 0};   // chunked class + 1, job / list slot in the block, jobs
+      uint32_t ww4[4] = {0, 0, 0, 0};                                   // slot + 1 among the block's wave-per-read reads
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
           const uint32_t r = r0 + u * blockDim.x;
@@ -56,11 +85,16 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
       for (uint32_t u = 0; u < 4; u++)
 #pragma unroll
           for (uint32_t j = 0; j < 2; j++) fw[u][j] = k4[u] > j ? read_word[so4[u] + j] : 0u;
+      ROUTE_STAMP(1);    // offsets and first words
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
         const uint32_t r = r0 + u * blockDim.x;
-        if (r >= hi) break;
-        const uint32_t so = so4[u], k = k4[u];
+        const bool valid = r < hi;
+        uint32_t t_id = 0, append = 0;         // plan id; 1 / 2: joins the list of the plain walk class 8 / 16 (direct mode)
+        bool resolved = false;
+        const uint32_t k = k4[u];
+        if (valid) {
+        const uint32_t so = so4[u];
         int c = 0;
         auto count = [&](uint32_t sw) { if (!rw_missing(sw)) c += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0; };
         if (k > 0) count(fw[u][0]);
@@ -124,10 +158,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             if (in_win && wi < m.wc_windows) {
                 const int rs = m.root_base + c;
                 for (uint32_t i = 0; i < WC_MAX; i++) {
-                    const WcInfo* q = m.wc_info + wi * WC_MAX + i;
-                    const uint32_t qn = q->n;
+                    const uint32_t qn = wc_n[wi * WC_MAX + i];
                     if (!qn) break;
-                    if (rs <= q->tau) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
+                    if (rs <= wc_tau[wi * WC_MAX + i]) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
                 }
             }
         }
@@ -142,13 +175,47 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             if (cls == PLAN_SWEEP) cls = classify(m.walks[t].ix_head, m.walks[t].ix_nest, nj, open_max, events);
             if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
                 // the deepest stack a walk of the class can need in this call: its kernel's LDS request
-                atomicMax(&open_of[cls], open_max);
+                if (open_max > open_of[cls]) atomicMax(&open_of[cls], open_max);
+                // every stream is a slice of the walk arena: the read walks the slice wsid names (a window crown's, set
+                // above, or its tree-wide stream's)
+                if (t != WC_SLOT) wsid[r] = m.tw_base + t;
+                if (direct.wlist[0]) {
+                    if (events == 0) {
+                        // none of the read's positions is mutated in its stream: every node scores base + c, and the
+                        // stream-wide aggregate is the answer (what k_walk finds without a single range query) -- the
+                        // root is in every stream and always competes, so the aggregate never loses to the bound
+                        const SegNode whole = m.wc_info[t == WC_SLOT ? sid : m.tw_base + t].whole;
+                        if (direct.best_bfs_j) direct.best_bfs_j[r] = m.rank2bfs[whole.rank < m.N ? whole.rank : 0u];
+                        if (direct.score) direct.score[r] = whole.base + c;
+                        if (direct.num_best) direct.num_best[r] = whole.cnt;
+                        if (direct.flags) direct.flags[r] = whole.hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+                        resolved = true;
+                    } else append = cls == PLAN_WALK8 ? 1u : 2u;
+                }
             } else if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
                 const uint32_t small = cls == PLAN_WALKC8 ? 1u : 0u;
-                job_n[r] = nj;
+                if (t != WC_SLOT) wsid[r] = m.tw_base + t;
+                if (direct.wwlist && events <= WAVE_WALK_MAX_EVENTS) {
+                    // many events, but few enough for ONE wave to hold them all (lane = list entry, wave_kernels.hip):
+                    // no jobs; the read keeps its chunked class in the diagnostics
+                    job_n[r] = 0;
+                    // (<= 64: a wave of its own, listed from the front; more: the four waves of a block, listed from the back)
+                    const uint32_t big = events > 64u ? 1u : 0u;
+                    ww4[u] = ((atomicAdd(&ww_count[big], 1u) + 1u) << 1) | big;
+                    nj = 0;
+                    events = 0;
+                } else {
+                    job_n[r] = nj;
+                }
+                if (nj && direct.jobs[0]) {      // (few reads: an LDS atomic each)
+                    cj4[u] = small ? 1u : 2u;
+                    cnj4[u] = nj;
+                    cjs4[u] = atomicAdd(&cj_count[small ? 0 : 1], nj);
+                    cls4[u] = atomicAdd(&cl_count[small ? 0 : 1], 1u);
+                }
                 atomicAdd(&events_of[small ? 0 : 1], events);
                 atomicAdd(&jobs_of[(small ? 0u : MAX_STREAMS) + t], nj);
-                atomicMax(&open_of[small ? 2 : 3], open_max);
+                if (open_max > open_of[small ? 2 : 3]) atomicMax(&open_of[small ? 2 : 3], open_max);
             }
         }
         // (use_crowns & 2 -- wepp_best_nodes, which lists nodes and so takes streams of real nodes only: every read
@@ -171,11 +238,93 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             cls = PLAN_SEED;
             t = 0;
         }
-        t = plan_id(cls, t);
-        tier_of[r] = (uint8_t)t;
-        slot_in_blk[r] = atomicAdd(&cnt[t], 1u);     // position among this block's reads of the plan (k_scatter)
-        atomicMax(&mx[t], k);
+        t_id = plan_id(cls, t);
+        tier_of[r] = (uint8_t)t_id;
+        if (k > mx[t_id]) atomicMax(&mx[t_id], k);
+        }   // valid
+        ROUTE_STAMP(2);  // the reads' routing
+        // ---- counters, one LDS atomic per wave and distinct value instead of one per read (all lanes take part) ----
+        // position among this block's reads of the plan (k_scatter): the reads of a wave that share a plan take
+        // consecutive slots
+        {
+            unsigned long long todo = __ballot(valid);
+            uint32_t slot = 0;
+            while (todo) {
+                const int first = __builtin_ctzll(todo);
+                const uint32_t tt = (uint32_t)__builtin_amdgcn_readlane((int)t_id, first);
+                const unsigned long long peers = __ballot(valid && t_id == tt);
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(&cnt[tt], (uint32_t)__popcll(peers));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                if (valid && t_id == tt) slot = base + (uint32_t)__popcll(peers & lt_mask);
+                todo &= ~peers;
+            }
+            if (valid) slot_in_blk[r] = slot;
+        }
+        {
+            const unsigned long long rm = __ballot(resolved);
+            if (rm && lane == (uint32_t)__builtin_ctzll(rm)) atomicAdd(&resolved_of[0], (uint32_t)__popcll(rm));
+        }
+        // the plain walkers' lists: a slot among the block's walkers of the class now, the block's range in the list below
+        if (direct.wlist[0]) {
+#pragma unroll
+            for (uint32_t cc = 0; cc < 2; cc++) {
+                const unsigned long long mk = __ballot(append == cc + 1);
+                if (!mk) continue;
+                const int first = __builtin_ctzll(mk);
+                uint32_t base = 0;
+                if ((int)lane == first) base = atomicAdd(&wl_count[cc], (uint32_t)__popcll(mk));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                if (append == cc + 1) { app4[u] = cc + 1; aslot4[u] = base + (uint32_t)__popcll(mk & lt_mask); }
+            }
+        }
+        ROUTE_STAMP(3);  // counters and slots
       }
+      // ... one global atomic per block, round and class reserves the block's range of the class's list (a global atomic
+      // per wave, ~60 K of them on one address per million reads, made k_route six times slower)
+      if (direct.wlist[0]) {
+          __syncthreads();
+          if (threadIdx.x < 2) {
+              const uint32_t cc = threadIdx.x;
+              wl_base[cc] = wl_count[cc] ? atomicAdd(&tier_info[TI_WCUR + cc], wl_count[cc]) : 0u;
+              wl_count[cc] = 0;
+              // the chunked classes' job tables and lists: the block's ranges, or -- a table outgrown -- the class is
+              // flagged and left to the host's planned launch (the blind kernels leave at once)
+              c_ok[cc] = 0;
+              if (cl_count[cc] && direct.jobs[0]) {
+                  cj_base[cc] = atomicAdd(&tier_info[TI_JCUR + cc], cj_count[cc]);
+                  cl_base[cc] = atomicAdd(&tier_info[TI_CCUR + cc], cl_count[cc]);
+                  if (cj_base[cc] + cj_count[cc] > BLIND_JOB_CAP || cl_base[cc] + cl_count[cc] > BLIND_CHUNKED_READS) tier_info[TI_JOVER + cc] = 1u;
+                  else c_ok[cc] = 1;
+              }
+              cj_count[cc] = 0;
+              cl_count[cc] = 0;
+              if (cc == 0) {
+                  for (uint32_t b = 0; b < 2; b++) {
+                      ww_base[b] = ww_count[b] ? atomicAdd(&tier_info[TI_WWCUR + b], ww_count[b]) : 0u;
+                      ww_count[b] = 0;
+                  }
+              }
+          }
+          __syncthreads();
+#pragma unroll
+          for (uint32_t u = 0; u < 4; u++) {
+              const uint32_t r = r0 + u * blockDim.x;
+              if (app4[u]) direct.wlist[app4[u] - 1][wl_base[app4[u] - 1] + aslot4[u]] = r;
+              if (ww4[u]) {
+                  const uint32_t big = ww4[u] & 1u, at = ww_base[big] + (ww4[u] >> 1) - 1u;
+                  direct.wwlist[big ? n_reads - 1u - at : at] = r;
+              }
+              if (cj4[u] && c_ok[cj4[u] - 1]) {
+                  const uint32_t cc = cj4[u] - 1, j0 = cj_base[cc] + cjs4[u];
+                  direct.clist[cc][cl_base[cc] + cls4[u]] = r;
+                  direct.job_first[r] = j0;
+                  for (uint32_t c2 = 0; c2 < cnj4[u]; c2++) direct.jobs[cc][j0 + c2] = r;
+              }
+          }
+          __syncthreads();        // (c_ok and the bases are rewritten in the next round)
+      }
+      ROUTE_STAMP(4);    // the lists: barrier, reservation, writes
     }
     __syncthreads();
     if (threadIdx.x < MAX_PLANS) {
@@ -188,6 +337,28 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
     if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
     if (threadIdx.x < 2 && events_of[threadIdx.x]) atomicAdd(&tier_info[TI_EVENTS + threadIdx.x], (events_of[threadIdx.x] + 63) >> 6);
+    if (threadIdx.x == 0 && resolved_of[0]) {
+        atomicAdd(&tier_info[TI_RESOLVED], resolved_of[0]);
+        // what a resolved read asked memory for: its offsets and words, a list head per entry, the aggregate, the result
+        if (direct.work_counter) atomicAdd(direct.work_counter + WALK_COUNTERS + (blockIdx.x & (WALK_COUNTERS - 1)), 48ull * resolved_of[0]);
+    }
+    ROUTE_STAMP(5);      // epilogue
+#ifdef WEPP_ROUTE_STATS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_route_stats[6] += 1;
+#endif
+}
+#ifdef WEPP_ROUTE_STATS
+extern "C" int wepp_debug_route_stats(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_route_stats), sizeof(g_route_stats));
+}
+#endif
+
+// entry indices of one stream's slice of the walk arena made absolute (capi.cpp: the tree-wide streams are copied from
+// the image into their slices as they are)
+__global__ void k_rebase_index(IxHead* __restrict__ heads, uint32_t n_heads, IxEnt* __restrict__ ents, uint32_t n_ents, uint32_t ent_off) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_heads) heads[i].off += ent_off;
+    if (i < n_ents && ents[i].up != IX_NONE) ents[i].up += ent_off;
 }
 
 // -----------------------------------------------------------------------------
@@ -276,10 +447,17 @@ hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint3
                         int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
                         uint32_t seed_min_hard, uint32_t seed_min_nodes, uint32_t* job_n, uint8_t* tier_of,
                         int32_t* root_score, uint32_t* blk_counts, uint32_t* tier_info, uint32_t* slot_in_blk,
-                        uint32_t* tier_info_next, uint32_t* wsid, hipStream_t stream) {
+                        uint32_t* tier_info_next, uint32_t* wsid, const RouteDirect& direct, hipStream_t stream) {
     hipLaunchKernelGGL(k_route, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, m, d_read_off, d_read_word,
                        n_reads, use_crowns, walk_max_events, job_events, std::min(stack8, WALK8_STACK), std::min(stack16, WALK16_STACK),
-                       seed_min_hard, seed_min_nodes, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next, wsid);
+                       seed_min_hard, seed_min_nodes, job_n, tier_of, root_score, blk_counts, tier_info, slot_in_blk, tier_info_next, wsid, direct);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebase_index(IxHead* heads, uint32_t n_heads, IxEnt* ents, uint32_t n_ents, uint32_t ent_off, hipStream_t stream) {
+    const uint32_t n = std::max(n_heads, n_ents);
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_rebase_index, dim3((n + 255) / 256), dim3(256), 0, stream, heads, n_heads, ents, n_ents, ent_off);
     return hipGetLastError();
 }
 

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
                                               const int32_t* __restrict__ root_score, uint32_t* __restrict__ best_bfs_j,
                                               int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best,
                                               uint32_t* __restrict__ flags, unsigned long long* __restrict__ work_counter,
-                                              const uint32_t* __restrict__ wsid) {
+                                              const uint32_t* __restrict__ wsid, const uint32_t* __restrict__ blind_list,
+                                              const uint32_t* __restrict__ blind_count) {
     // wave-private LDS: the allele fields of the read words, 16 bits each [KW / 2][64]; the list cursors [KW][64];
     // the interval stack [sd_rows][64] -- sd_rows = the deepest stack a read of this launch can need (k_route's
     // maximum of open_max over the class, <= SD).  The walk waits on memory: what it gains from a wave more
@@ -46,7 +47,15 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     // the read word of list j rebuilt from its 9 allele bits (the position is not needed again)
     auto sword = [&](int j) -> uint32_t { return ((S16[(j >> 1) * 64 + lane] >> ((j & 1) * 16)) & 0x1FFu) << 20; };
     const uint32_t unit = blockIdx.x * WALK_WAVES + wv;
-    if (unit >= pl.p[pl.n - 1].wave_end) return;
+    // BLIND (plain walks of a placement call): the launch was sized for the worst case before the routing counters
+    // reached the host; the reads are k_route's list blind_list[0 .. *blind_count) and every read walks the arena slice
+    // wsid names.  Waves beyond the count leave at once.
+    // (chunked classes sized blind: blind_list = k_route's job table, job j belongs to read blind_list[j], its chunk is
+    // j - jb.job_first[read]; a class the host plans instead -- *jb.skip != 0 -- leaves at once)
+    const bool blind = blind_count != nullptr;
+    if (CHUNKED && blind && *jb.skip) return;
+    const uint32_t n_blind = blind ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*blind_count) : 0u;
+    if (unit >= (blind ? walk_plan_waves(n_blind) : pl.p[pl.n - 1].wave_end)) return;
 #ifdef WEPP_WALK_STATS   // (profiling build: wave cycles by phase into the work counters, tools/walk_probe.py prints them)
     unsigned long long ts_[6];
     ts_[0] = __builtin_amdgcn_s_memtime();
@@ -59,8 +68,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     // range pre-test -- are counted per wave with a population count of the lanes that issue them
     uint32_t lane_bytes = 0, n_ent = 0, n_spb = 0;
     uint32_t pi = 0;
-    while (pi + 1 < pl.n && unit >= pl.p[pi].wave_end) pi++;
-    const WalkPlanDev& q = pl.p[pi];
+    if (!blind) while (pi + 1 < pl.n && unit >= pl.p[pi].wave_end) pi++;
+    WalkPlanDev q = pl.p[pi];
+    if (blind) { q.tier = WC_SLOT; q.n_list = n_blind; q.wave_end = walk_plan_waves(n_blind); q.job0 = 0; q.list = blind_list; }
     // Workgroups are handed to the eight XCDs round-robin (workgroup b runs on XCD b % 8), each with its own L2.  A
     // plan's waves start at a workgroup index that is a multiple of 8 and their number is a multiple of 16
     // (walk_plan_waves), so the plan's workgroup i is on XCD i % 8: XCD x takes the x-th CONTIGUOUS eighth of the
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     // (Per plan, not per launch: the plans of a launch differ in cost per read by orders of magnitude.)
     uint32_t tile;
     {
-        const uint32_t first = pi ? pl.p[pi - 1].wave_end : 0u;
+        const uint32_t first = (pi && !blind) ? pl.p[pi - 1].wave_end : 0u;
         const uint32_t wgs = (q.wave_end - first) / WALK_WAVES, wg = (unit - first) / WALK_WAVES;
         tile = ((wg % WALK_XCDS) * (wgs / WALK_XCDS) + wg / WALK_XCDS) * WALK_WAVES + wv;
     }
@@ -77,7 +87,15 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk(DevMAT m, WalkPlans pl
     const bool have = slot < q.n_list;
     // plain: a lane = a read of the plan's list.  CHUNKED: a lane = a job = (read, chunk of its walk)
     uint32_t rd = 0, chunk = 0, n_chunks = 1, job = 0;
-    if (CHUNKED) {
+    if (CHUNKED && blind) {
+        if (have) {
+            job = slot;
+            rd = blind_list[job];
+            chunk = job - jb.job_first[rd];
+            n_chunks = jb.job_n[rd];
+            lane_bytes += 4 + 4 + 4;
+        }
+    } else if (CHUNKED) {
         // the read a job belongs to = the last list position whose first job is <= job (job_off ascends).
         // The wave's jobs are consecutive: its first job is located by a bisection on wave-uniform values
         // (scalar loads), the other lanes' reads lie within the next 64 list positions, whose offsets go to
@@ -501,12 +519,17 @@ __global__ void k_gather_jobs(const uint32_t* __restrict__ list, uint32_t n_list
 // by the whole wave (lane-strided loads, butterfly reduction).  part_cnt = (count << 1) | has_unique.
 __global__ __launch_bounds__(256) void k_finalize_jobs(DevMAT m, const uint32_t* __restrict__ list, uint32_t n_list, WalkJobs jb,
                                 uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score,
-                                uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
+                                uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags, const uint32_t* __restrict__ n_list_dev) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (blind: the class's reads are k_route's list of *n_list_dev reads, a read's jobs start at jb.job_first[read])
+    if (n_list_dev) {
+        if (*jb.skip) return;
+        n_list = *n_list_dev;
+    }
     const bool valid = i < n_list;
     const uint32_t r = valid ? list[i] : 0u;
-    const uint32_t j0 = valid ? jb.job_off[i] : 0u, nj = valid ? jb.job_n[r] : 0u;
+    const uint32_t j0 = valid ? (n_list_dev ? jb.job_first[r] : jb.job_off[i]) : 0u, nj = valid ? jb.job_n[r] : 0u;
     int bs = 0x7FFFFFFF;
     uint32_t br = 0xFFFFFFFFu, cnt = 0, bhu = 0;
     auto take = [&](int& b, uint32_t& rk, uint32_t& ct, uint32_t& h, int s, uint32_t pr, uint32_t pc, uint32_t ph) {
@@ -551,7 +574,8 @@ __global__ __launch_bounds__(256) void k_finalize_jobs(DevMAT m, const uint32_t*
         }
         if ((int)lane == l) { bs = ws; br = wr; cnt = wc; bhu = wh; }
     }
-    if (valid) {
+    // (a read of the class without jobs was placed by a wave of its own, wave_kernels.hip: nothing to combine)
+    if (valid && nj) {
         if (best_bfs_j) best_bfs_j[r] = m.rank2bfs[br < m.N ? br : 0u];
         if (score) score[r] = bs;
         if (num_best) num_best[r] = cnt;
@@ -579,11 +603,35 @@ hipError_t launch_walk(const DevMAT& m, const WalkPlans& pl, uint32_t cls, uint3
     if (cls == PLAN_WALK8) {
         const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl,
-                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     } else {
         const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl,
-                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid);
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_blind(const DevMAT& m, uint32_t cls, uint32_t stack_rows, uint32_t max_reads, const uint32_t* list, const uint32_t* count,
+                             const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score, uint32_t* best_bfs_j,
+                             int32_t* score, uint32_t* num_best, uint32_t* flags, unsigned long long* work_counter, const uint32_t* wsid,
+                             hipStream_t stream) {
+    if (max_reads == 0) return hipSuccess;
+    const uint32_t waves = walk_plan_waves(max_reads);
+    const dim3 grid(waves / WALK_WAVES), block(64 * WALK_WAVES);
+    WalkPlans pl{};
+    pl.n = 1;
+    const WalkJobs none{};
+    if (cls == PLAN_WALK8) {
+        const uint32_t sd = walk_stack_rows(stack_rows, WALK8_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, false>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl,
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid, list, count);
+    } else {
+        const uint32_t sd = walk_stack_rows(stack_rows, WALK16_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, false>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl,
+                           none, sd, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, wsid, list, count);
     }
     return hipGetLastError();
 }
@@ -604,12 +652,12 @@ hipError_t launch_walk_jobs(const DevMAT& m, const WalkPlans& pl, uint32_t cls, 
         const uint32_t sd = walk_stack_rows(open_max, WALK8_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
                            sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, work_counter, wsid);
+                           (uint32_t*)nullptr, work_counter, wsid, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     } else {
         const uint32_t sd = walk_stack_rows(open_max, WALK16_STACK);
         hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
                            sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, work_counter, wsid);
+                           (uint32_t*)nullptr, work_counter, wsid, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     return hipGetLastError();
 }
@@ -619,7 +667,33 @@ hipError_t launch_finalize_jobs(const DevMAT& m, const uint32_t* list, uint32_t 
                                 int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
     hipLaunchKernelGGL(k_finalize_jobs, dim3((n_list + 255) / 256), dim3(256), 0, stream, m, list, n_list, jb,
-                       best_bfs_j, score, num_best, flags);
+                       best_bfs_j, score, num_best, flags, (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_jobs_blind(const DevMAT& m, uint32_t cls, uint32_t stack_rows, const WalkJobs& jb, const uint32_t* jobs, const uint32_t* n_jobs,
+                                  const uint32_t* clist, const uint32_t* n_class, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                                  const int32_t* root_score, uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags,
+                                  unsigned long long* work_counter, const uint32_t* wsid, hipStream_t stream) {
+    const uint32_t waves = walk_plan_waves(BLIND_JOB_CAP);
+    const dim3 grid(waves / WALK_WAVES), block(64 * WALK_WAVES);
+    WalkPlans pl{};
+    pl.n = 1;
+    if (cls == PLAN_WALKC8) {
+        const uint32_t sd = walk_stack_rows(stack_rows, WALK8_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK8_K, (int)WALK8_STACK, true>), grid, block, walk_lds_bytes(WALK8_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, work_counter, wsid, jobs, n_jobs);
+    } else {
+        const uint32_t sd = walk_stack_rows(stack_rows, WALK16_STACK);
+        hipLaunchKernelGGL((k_walk<(int)WALK16_K, (int)WALK16_STACK, true>), grid, block, walk_lds_bytes(WALK16_K, sd), stream, m, pl, jb,
+                           sd, d_read_off, d_read_word, root_score, (uint32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, work_counter, wsid, jobs, n_jobs);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_finalize_jobs, dim3((BLIND_CHUNKED_READS + 255) / 256), dim3(256), 0, stream, m, clist, 0u, jb,
+                       best_bfs_j, score, num_best, flags, n_class);
     return hipGetLastError();
 }
 
