@@ -17,6 +17,6 @@ out = (ctypes.c_ulonglong * 16)()
 lib.wepp_debug_route_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 rc = lib.wepp_debug_route_stats(out)
 v = list(out)
-n = max(v[6], 1)
-names = ["prologue", "offsets+words", "routing", "counters+slots", "lists", "epilogue"]
-print("launches", v[6], {nm: round(v[i] / n, 1) for i, nm in enumerate(names)}, "ticks per launch (s_memtime)")
+n = max(v[9], 1)
+names = ["prologue", "offsets+words", "A: counts, root", "A: tree-wide stream", "A: window crown", "A: first loads", "B: class, plan, counters", "lists", "epilogue"]
+print("launches", v[9], {nm: round(v[i] / n, 1) for i, nm in enumerate(names)}, "ticks per launch (s_memtime)")

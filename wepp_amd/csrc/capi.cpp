@@ -155,6 +155,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
         h->stats.window_stream_nodes += f.wstreams[i].n;
     }
     d.n_windows = (uint32_t)f.wstreams.size();
+    if (!h->wstreams.empty()) UP(h->d_wstreams, h->wstreams)
     for (size_t i = 0; i < f.streams.size(); i++) {
         const Stream& st = f.streams[i];
         DevStream ds;
@@ -211,6 +212,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
                 wi.sp_off = a_sp.size();
                 wi.tau = st.tau;
                 wi.whole = st.whole;
+                wi.whole_bfs = f.rank2bfs[st.whole.rank < f.N ? st.whole.rank : 0u];
                 for (IxHead hd : st.ix_head) { hd.off += ent_off; a_head.push_back(hd); }
                 for (IxEnt e : st.ix_ent) { if (e.up != IX_NONE) e.up += ent_off; a_ent.push_back(e); }
                 a_nest.insert(a_nest.end(), st.ix_nest.begin(), st.ix_nest.end());
@@ -257,6 +259,7 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
                 wi.sp_off = o_sp;
                 wi.tau = st.tau;
                 wi.whole = st.whole;
+                wi.whole_bfs = f.rank2bfs[st.whole.rank < f.N ? st.whole.rank : 0u];
 #define CP(dst, off, vec) if (!vec.empty()) HIP_TRY(hipMemcpy(dst + off, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
                 CP(g_head, o_head, st.ix_head) CP(g_ent, o_ent, st.ix_ent) CP(g_nest, o_head, st.ix_nest) CP(g_sp, o_sp, st.sp)
                 CP(g_nrec, o_n, st.nrec) CP(g_pre, o_n, st.rq_pre) CP(g_suf, o_n, st.rq_suf) CP(g_dst, o_dst, st.rq_dst)
@@ -628,6 +631,12 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 HIP_TRY(blind_class(PLAN_WALKC8, q, false));
                 HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
             }
+            if (tun.blind16) {
+                // ... and the plain walks of 9 - 16 entries on a stream of their own: launched once the counters have
+                // reached the host they started when the walks of 1 - 8 entries ended, ~15 us of a 170 us step
+                HIP_TRY(blind_class(PLAN_WALK16, L.side[BLIND16_STREAM], true));
+                HIP_TRY(hipEventRecord(L.join_ev[BLIND16_STREAM], L.side[BLIND16_STREAM]));
+            }
             HIP_TRY(hipStreamWaitEvent(ps, L.route_ev, 0));
         }
         HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, ps));
@@ -668,7 +677,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     bool late16[2] = {false, false};
     if (blind_walks) {
         // the classes of 9 - 16 entries, from k_route's tables like the others, when they hold reads
-        if (info[TI_WCUR + 1]) { HIP_TRY(blind_class(PLAN_WALK16, L.side[BLIND16_STREAM], true)); HIP_TRY(hipEventRecord(L.join_ev[BLIND16_STREAM], L.side[BLIND16_STREAM])); late16[0] = true; }
+        if (tun.blind16) late16[0] = true;
+        else if (info[TI_WCUR + 1]) { HIP_TRY(blind_class(PLAN_WALK16, L.side[BLIND16_STREAM], true)); HIP_TRY(hipEventRecord(L.join_ev[BLIND16_STREAM], L.side[BLIND16_STREAM])); late16[0] = true; }
         if (info[TI_CCUR + 1] && !info[TI_JOVER + 1]) { HIP_TRY(blind_class(PLAN_WALKC16, L.side[MAX_STREAMS - 3], true)); HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 3], L.side[MAX_STREAMS - 3])); late16[1] = true; }
     }
     // ---- plan the launches ---------------------------------------------------------
@@ -686,6 +696,18 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     uint32_t arena_n = 0, arena_off = 0, arena_maxk = 1;
     uint32_t seed_n = 0, seed_off = 0, seed_maxk = 1;
     size_t arena_part = 0;
+    // the window plans share ONE launch (k_sweep_windows): their chunks are sized for the tiles of all of them together
+    // (sized per plan, each window asked for enough waves to fill the chip on its own: 1.2 kb reads, 30 windows -- 9
+    // workgroups per tile, each rebuilding the tile's table to sweep two blocks of the window's stream)
+    const bool fuse_windows = !tun.sweep_unfused && !tun.windows_unfused && mat->d_wstreams;
+    auto tile_reads = [&](uint32_t maxk) { uint32_t Tp = T; while (Tp > 1 && (uint64_t)Tp * maxk > MAX_TILE_ENTRIES) Tp >>= 1; return Tp; };
+    auto takes_table = [&](uint32_t maxk) { return maxk <= MAX_TILE_ENTRIES && maxk >= DENSE_MIN_READ_WORDS && mat->dev.max_pos <= DENSE_MAX_POS; };
+    uint64_t win_tiles = 0;
+    if (fuse_windows)
+        for (uint32_t id = 0; id < MAX_PLANS; id++) {
+            const uint32_t count = info[TI_COUNT + id], maxk = std::max<uint32_t>(1, info[TI_MAXK + id]);
+            if (count && plan_class(id) == PLAN_WIN && takes_table(maxk)) win_tiles += (count + tile_reads(maxk) - 1) / tile_reads(maxk);
+        }
     for (uint32_t id = 0; id < MAX_PLANS; id++) {
         const uint32_t count = info[TI_COUNT + id];
         if (!count) continue;
@@ -771,6 +793,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         // balance the chip better -- 1.2 kb reads 132 -> 120 ms per 200 K at 16384, the same at 32768)
         const uint32_t target_waves_dense = tun.target_waves_dense;
         uint32_t nchunks = std::max<uint32_t>(1, ((p.dense ? target_waves_dense : target_waves) + p.ntiles - 1) / p.ntiles);
+        if (p.win_table && fuse_windows) nchunks = std::max<uint32_t>(1, (uint32_t)((target_waves_dense + win_tiles - 1) / win_tiles));
         // ... and chunks no longer than what stays in an XCD's L2 while the tiles sweep it: the waves of
         // a launch are ordered chunk-major (all tiles of chunk 0, then of chunk 1, ...), so the ~4 K
         // resident waves walk the same ~1.5 MB of the stream together instead of drifting apart over
@@ -837,8 +860,10 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // WEPP_SWEEP_UNFUSED=1 (profiling aid): one launch per plan, back to back on `stream`, so that a
     // kernel trace shows the time of every stream's sweep; results are identical
     const bool unfused = tun.sweep_unfused;
+    uint32_t wins[MAX_WINDOWS], n_wins = 0;
     for (uint32_t i = 0; i < np; i++) {
         if (plans[i].s_in_lds && !plans[i].dense && !unfused && n_plain < MAX_STREAMS) order[n_plain++] = i;
+        else if (plans[i].win_table && fuse_windows && n_wins < MAX_WINDOWS) wins[n_wins++] = i;
         else others[n_other++] = i;
         passes += plans[i].ntiles;                                   // every tile sweeps its stream once
         bytes += (uint64_t)plans[i].ntiles * plans[i].sbytes;
@@ -857,7 +882,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     for (uint32_t cc = 0; cc < 2; cc++)
         if (walkc[cc].n) passes += walkc[cc].p[walkc[cc].n - 1].wave_end;
     const uint32_t n_walk_chains = (walkc[0].n || walkc[1].n) ? 1u : 0u;
-    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u) + (seed_n ? 1u : 0u);     // launch chains beside the fused plain sweeps
+    const uint32_t n_chains = n_other + n_walk_chains + (arena_n ? 1u : 0u) + (seed_n ? 1u : 0u) + (n_wins ? 1u : 0u);     // launch chains beside the fused plain sweeps
     const bool fork = !unfused && (n_chains > 0) && (n_plain > 0 || n_chains > 1);
     if (fork) HIP_TRY(hipEventRecord(L.fork_ev, ps));
     // the side streams join the caller's stream only after everything has been launched: a join in between
@@ -962,6 +987,36 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             // the last launch on every side stream joins the caller's stream
             HIP_TRY(hipEventRecord(L.join_ev[k % OTHER_SIDE_STREAMS], q));
             joins[n_joins++] = k % OTHER_SIDE_STREAMS;
+        }
+    }
+    if (n_wins) {
+        // longest chunks first: the workgroups of the largest windows' streams start first
+        std::sort(wins, wins + n_wins, [&](uint32_t a, uint32_t b) { return plans[a].bpc > plans[b].bpc; });
+        WinPlans pl{};
+        uint32_t wg = 0, fin = 0, lds_max = 0;
+        for (uint32_t k = 0; k < n_wins; k++) {
+            const Plan& p = plans[wins[k]];
+            WinPlanDev& d = pl.p[k];
+            d.sid = (uint32_t)(p.st - mat->wstreams.data());
+            d.list = p.lst;
+            d.n_list = p.count; d.T = p.T; d.ntiles = p.ntiles; d.bpc = p.bpc; d.ent_cap = p.ent_cap; d.win_base = p.key_cap; d.nchunks = p.nchunks;
+            parts(p, d.part_score, d.part_rank, d.part_cnt);
+            wg += p.ntiles * (p.nchunks / DENSE_WAVES_PER_WG);
+            d.wg_end = wg;
+            fin += finalize_blocks(p.count, p.nchunks);
+            d.fin_end = fin;
+            lds_max = std::max(lds_max, p.lds_bytes);
+        }
+        pl.n = n_wins;
+        hipStream_t q = fork ? L.side[OTHER_SIDE_STREAMS - 3] : ps;
+        if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
+        HIP_TRY(launch_sweep_windows(mat->dev, mat->d_wstreams, pl, d_read_off, d_read_word, root_score, lds_max, q));
+        HIP_TRY(launch_finalize_windows(mat->dev, pl, d_read_off, d_read_word, d_best_bfs_j, d_score, d_num_best, d_flags, q));
+        if (fork) {
+            HIP_TRY(hipEventRecord(L.join_ev[OTHER_SIDE_STREAMS - 3], q));
+            bool listed = false;
+            for (uint32_t i = 0; i < n_joins; i++) listed = listed || joins[i] == OTHER_SIDE_STREAMS - 3;
+            if (!listed) joins[n_joins++] = OTHER_SIDE_STREAMS - 3;
         }
     }
     if (arena_n) {

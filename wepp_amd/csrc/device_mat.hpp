@@ -64,7 +64,7 @@ struct WcInfo {
     uint32_t node_off, head_off, nest_off, dst_off;   // into nrec / rq_pre / rq_suf, ix_head, ix_nest, rq_dst
     unsigned long long sp_off;                    // into sp
     int32_t tau;
-    uint32_t pad;
+    uint32_t whole_bfs;                           // BFS index of whole.rank (k_route places reads without events from its table)
     SegNode whole;
 };
 
@@ -227,6 +227,22 @@ struct SweepPlans {
     SweepPlanDev p[MAX_STREAMS];
 };
 
+// the window plans of one call (reads with many entries inside one genome window, a tile of them sweeps the window's
+// stream), fused into one launch (k_sweep_windows): the streams are named by their index in the handle's device array
+struct WinPlanDev {
+    uint32_t sid, n_list, T, ntiles, bpc, ent_cap, win_base, nchunks;
+    uint32_t wg_end, fin_end;   // first sweep workgroup / finalize block after this plan
+    const uint32_t* list;
+    int32_t* part_score;
+    uint32_t* part_rank;
+    uint32_t* part_cnt;
+};
+struct WinPlans {
+    uint32_t n;
+    WinPlanDev p[MAX_WINDOWS];
+};
+static_assert(sizeof(WinPlans) <= 3584, "the window plans travel as a kernel argument");
+
 #ifndef WEPP_ROUTE_BLOCKS
 #define WEPP_ROUTE_BLOCKS 256
 #endif
@@ -333,6 +349,11 @@ hipError_t launch_sweep_arena(const DevMAT& m, const DevStream* wc_streams, cons
                               const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list, uint32_t n_list,
                               uint32_t ent_cap, uint32_t lds_bytes, int32_t* part_score, uint32_t* part_rank, uint32_t* part_cnt,
                               hipStream_t stream);
+// every window plan of a call in one launch, and their combination in one
+hipError_t launch_sweep_windows(const DevMAT& m, const DevStream* d_wstreams, const WinPlans& pl, const uint32_t* d_read_off,
+                                const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_finalize_windows(const DevMAT& m, const WinPlans& pl, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                                   uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream);
 hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint32_t* d_read_off,
                               const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes,
                               hipStream_t stream);

@@ -56,6 +56,7 @@ struct wepp_mat {
     static constexpr size_t D_WORK_BYTES = (2 * WALK_COUNTERS + D_WORK_EXTRA) * sizeof(unsigned long long);
     std::vector<uint64_t> stream_bytes;
     std::vector<DevStream> wstreams;  // window streams (PLAN_WIN)
+    const DevStream* d_wstreams = nullptr;  // ... and the same records on the device (k_sweep_windows names a stream by its index)
     std::vector<uint64_t> wstream_bytes;
     wepp_mat_stats stats{};
     std::vector<uint32_t> bfs2id;

@@ -18,8 +18,11 @@ namespace wepp {
 __device__ unsigned long long g_route_stats[16];
 #define ROUTE_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_route_stats[i] += now_ - last_; last_ = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ROUTE_STAMP_NW(i) do { __builtin_amdgcn_sched_barrier(0); { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_route_stats[i] += now_ - last_; last_ = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ROUTE_STAMP(i)
+#define ROUTE_STAMP_NW(i)
 #endif
 
 // -----------------------------------------------------------------------------
@@ -43,11 +46,18 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
     __shared__ uint32_t cnt[MAX_PLANS], mx[MAX_PLANS], jobs_of[2 * MAX_STREAMS], open_of[4], events_of[2], resolved_of[1];
-    // the window crowns' routing table -- bound and size of every crown of every genome window -- in LDS: a read's scan of
-    // its window's crowns used to be a chain of loads from the 80-byte records of the device table
-    __shared__ int32_t wc_tau[MAX_WINDOWS * WC_MAX];
-    __shared__ uint32_t wc_n[MAX_WINDOWS * WC_MAX];
-    for (uint32_t i = threadIdx.x; i < m.wc_windows * WC_MAX; i += blockDim.x) { wc_tau[i] = m.wc_info[i].tau; wc_n[i] = m.wc_info[i].n; }
+    // the routing table of every stream a read can walk -- the window crowns of every genome window, then the tree-wide
+    // streams (wc_info[tw_base + t]) -- in LDS: bound, size, where its position index starts in the arena, and its
+    // stream-wide aggregate (what a read without events in it is placed by).  Read from the 80-byte records of the
+    // device table, every one of these was a load of its own in the read's chain of dependent loads.
+    constexpr uint32_t RT_MAX = MAX_WINDOWS * WC_MAX + MAX_STREAMS;
+    __shared__ int32_t wc_tau[RT_MAX], rt_wbase[RT_MAX];
+    __shared__ uint32_t wc_n[RT_MAX], rt_head[RT_MAX], rt_nest[RT_MAX], rt_wbfs[RT_MAX], rt_wcnt[RT_MAX];
+    for (uint32_t i = threadIdx.x; i < m.tw_base + m.n_streams && i < RT_MAX; i += blockDim.x) {
+        const WcInfo q = m.wc_info[i];
+        wc_tau[i] = q.tau; wc_n[i] = q.n; rt_head[i] = q.head_off; rt_nest[i] = q.nest_off;
+        rt_wbase[i] = q.whole.base; rt_wbfs[i] = q.whole_bfs; rt_wcnt[i] = (q.whole.cnt << 1) | (q.whole.hu ? 1u : 0u);
+    }
     __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2];
     if (threadIdx.x < 2) { cj_count[threadIdx.x] = 0; cl_count[threadIdx.x] = 0; }
     if (threadIdx.x == 0) ww_count[0] = ww_count[1] = 0;
@@ -64,6 +74,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     ROUTE_STAMP(0);      // prologue
     const uint32_t per = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n_reads, lo + per);
+    const IxHead* __restrict__ ar_head = m.walks[WC_SLOT].ix_head;      // the walk arena: every stream's index is a slice of it
+    const uint8_t* __restrict__ ar_nest = m.walks[WC_SLOT].ix_nest;
+    const uint32_t root_w0 = m.node_woff[0], root_w1 = m.node_woff[1];
     // four reads per thread and round: their offsets, then their first two words, are requested together
     // (one read after the other, every read cost its thread three memory round trips in a row)
     const uint32_t lane = threadIdx.x & 63;
@@ -86,6 +99,76 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
 #pragma unroll
           for (uint32_t j = 0; j < 2; j++) fw[u][j] = k4[u] > j ? read_word[so4[u] + j] : 0u;
       ROUTE_STAMP(1);    // offsets and first words
+      // ---- phase A, the four reads one after the other: root score, tree-wide stream, window crown -- words and LDS
+      // tables only -- and the loads the classification below starts with (the list heads and nesting depths of the
+      // read's first two positions in the stream it will most likely walk), requested for all four before any is used:
+      // read by read, every read cost its thread a memory round trip of its own, one after the other
+      int c4[4] = {0, 0, 0, 0};
+      uint32_t nh4[4] = {0, 0, 0, 0}, t4[4] = {0, 0, 0, 0}, sid4[4] = {NONE, NONE, NONE, NONE}, wi4[4] = {0, 0, 0, 0}, inwin4[4] = {0, 0, 0, 0};
+      uint32_t pre_nest[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pre_o0[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pre_o1[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t r = r0 + u * blockDim.x;
+        const uint32_t k = k4[u], so = so4[u];
+        if (r < hi) {
+            int c = 0;
+            auto count = [&](uint32_t sw) { if (!rw_missing(sw)) c += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0; };
+            if (k > 0) count(fw[u][0]);
+            if (k > 1) count(fw[u][1]);
+            for (uint32_t j = 2; j < k; j++) count(read_word[so + j]);
+            nh4[u] = (uint32_t)c;              // entries whose alleles exclude their reference base (seed_kernels.hip)
+            for (uint32_t w = root_w0; w < root_w1; w++) {   // the root's own mutations
+                const uint32_t tw = m.words[w];
+                uint32_t sw = NONE;
+                if (k <= 2) {
+                    if (k > 0 && w_pos(fw[u][0]) == w_pos(tw)) sw = fw[u][0];
+                    if (k > 1 && w_pos(fw[u][1]) == w_pos(tw)) sw = fw[u][1];
+                } else sw = find_entry(read_word, so, k, w_pos(tw));
+                if (sw != NONE) c += enter_delta(tw, sw);
+            }
+            c4[u] = c;
+            ROUTE_STAMP_NW(2);  // entry counts, the root's mutations
+            root_score[r] = m.root_base + c;   // the root always competes: an upper bound of the best score
+            const int theta = m.root_base + c + (int)k;
+            uint32_t t = m.n_streams - 1;
+            if (use_crowns)
+                for (uint32_t i = 0; i + 1 < m.n_streams; i++)
+                    if (theta <= m.tau[i]) { t = i; break; }
+            t4[u] = t;
+            ROUTE_STAMP_NW(3);  // tree-wide stream
+            // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
+            // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
+            if (use_crowns && k > 0) {
+                const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 2 ? read_word[so + k - 1] : k == 2 ? fw[u][1] : fw[u][0]);
+                const uint32_t wi = p_lo / WIN_STRIDE;
+                wi4[u] = wi;
+                inwin4[u] = p_hi < wi * WIN_STRIDE + WIN_SIZE ? 1u : 0u;      // all listed positions inside genome window wi
+                if (inwin4[u] && wi < m.wc_windows) {
+                    const int rs = m.root_base + c;
+                    for (uint32_t i = 0; i < WC_MAX; i++) {
+                        const uint32_t qn = wc_n[wi * WC_MAX + i];
+                        if (!qn) break;
+                        if (rs <= wc_tau[wi * WC_MAX + i]) { if (qn < wc_n[m.tw_base + t]) sid4[u] = wi * WC_MAX + i; break; }
+                    }
+                }
+            }
+            ROUTE_STAMP_NW(4);  // window crown
+            if (walk_max_events && k <= WALK16_K) {
+                const uint32_t tab = sid4[u] != NONE ? sid4[u] : m.tw_base + t;
+#pragma unroll
+                for (uint32_t j = 0; j < 2; j++) {
+                    const uint32_t p = w_pos(fw[u][j]);
+                    if (j < k && p <= m.max_pos) {
+                        pre_nest[u][j] = (uint32_t)ar_nest[rt_nest[tab] + p];
+                        pre_o0[u][j] = ar_head[rt_head[tab] + p].off;
+                        pre_o1[u][j] = ar_head[rt_head[tab] + p + 1].off;
+                    }
+                }
+            }
+        }
+      }
+      ROUTE_STAMP(5);    // the first loads of the classification
+      // ---- phase B: class and plan of every read ----
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
         const uint32_t r = r0 + u * blockDim.x;
@@ -95,37 +178,31 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         const uint32_t k = k4[u];
         if (valid) {
         const uint32_t so = so4[u];
-        int c = 0;
-        auto count = [&](uint32_t sw) { if (!rw_missing(sw)) c += ((rw_mut(sw) & rw_ref(sw)) == 0) ? 1 : 0; };
-        if (k > 0) count(fw[u][0]);
-        if (k > 1) count(fw[u][1]);
-        for (uint32_t j = 2; j < k; j++) count(read_word[so + j]);
-        const uint32_t n_hard = (uint32_t)c;   // entries whose alleles exclude their reference base (seed_kernels.hip)
-        for (uint32_t w = m.node_woff[0]; w < m.node_woff[1]; w++) {   // the root's own mutations
-            const uint32_t tw = m.words[w];
-            const uint32_t sw = find_entry(read_word, so, k, w_pos(tw));
-            if (sw != NONE) c += enter_delta(tw, sw);
-        }
-        root_score[r] = m.root_base + c;       // the root always competes: an upper bound of the best score
-        const int theta = m.root_base + c + (int)k;
-        uint32_t t = m.n_streams - 1;
-        if (use_crowns)
-            for (uint32_t i = 0; i + 1 < m.n_streams; i++)
-                if (theta <= m.tau[i]) { t = i; break; }
+        const int c = c4[u];
+        const uint32_t n_hard = nh4[u];
+        uint32_t t = t4[u];
+        const uint32_t sid = sid4[u], wi = wi4[u];
+        const bool in_win = inwin4[u] != 0;
+        const uint32_t pre_tab = sid != NONE ? sid : m.tw_base + t;     // the stream phase A asked about
         // how the read is placed (device_mat.hpp): by walking its own events when it lists few positions and
         // the intervals it can hold open at once fit the walk's stack, by a sweep of the stream otherwise
         // A walk runs a read's events one after the other: reads with many events in their stream (a
         // frequently mutated position) are left to the sweeps, whose cost does not depend on it.
         uint32_t cls = PLAN_SWEEP;
-        // how a read with at most WALK16_K entries would walk a stream whose position index starts at (ix_head,
-        // ix_nest): plain, cut into jobs, or not at all (more open intervals than a walk's stack holds)
-        auto classify = [&](const IxHead* ix_head, const uint8_t* ix_nest, uint32_t& nj_out, uint32_t& open_out, uint32_t& ev_out) -> uint32_t {
+        // how a read with at most WALK16_K entries would walk the stream of routing-table entry `tab` (its position index
+        // is a slice of the arena): plain, cut into jobs, or not at all (more open intervals than a walk's stack holds)
+        auto classify = [&](uint32_t tab, uint32_t& nj_out, uint32_t& open_out, uint32_t& ev_out) -> uint32_t {
+            const IxHead* ix_head = ar_head + rt_head[tab];
+            const uint8_t* ix_nest = ar_nest + rt_nest[tab];
             uint32_t open_max = 0, events = 0, longest = 0;
             for (uint32_t j = 0; j < k; j++) {
-                const uint32_t p = w_pos(j < 2 ? fw[u][j] : read_word[so + j]);
+                const uint32_t p = w_pos(j == 0 ? fw[u][0] : j == 1 ? fw[u][1] : read_word[so + j]);
                 if (p <= m.max_pos) {
-                    open_max += (uint32_t)ix_nest[p];
-                    const uint32_t len = ix_head[p + 1].off - ix_head[p].off - 1u;      // (every list ends in a sentinel)
+                    uint32_t nest, o0, o1;
+                    if (j < 2 && tab == pre_tab) { nest = j ? pre_nest[u][1] : pre_nest[u][0]; o0 = j ? pre_o0[u][1] : pre_o0[u][0]; o1 = j ? pre_o1[u][1] : pre_o1[u][0]; }
+                    else { nest = (uint32_t)ix_nest[p]; o0 = ix_head[p].off; o1 = ix_head[p + 1].off; }
+                    open_max += nest;
+                    const uint32_t len = o1 - o0 - 1u;      // (every list ends in a sentinel)
                     events += len;
                     longest = max(longest, len);
                 }
@@ -147,32 +224,13 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             nj_out = min((events + je - 1) / je, longest);
             return small ? PLAN_WALKC8 : PLAN_WALKC16;
         };
-        // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
-        // every node that can win or tie -- far fewer than the tree-wide crown of theta = root score + |S|
-        uint32_t sid = NONE, wi = 0;
-        bool in_win = false;                   // all listed positions inside genome window wi
-        if (use_crowns && k > 0) {
-            const uint32_t p_lo = w_pos(fw[u][0]), p_hi = w_pos(k > 1 ? read_word[so + k - 1] : fw[u][0]);
-            wi = p_lo / WIN_STRIDE;
-            in_win = p_hi < wi * WIN_STRIDE + WIN_SIZE;
-            if (in_win && wi < m.wc_windows) {
-                const int rs = m.root_base + c;
-                for (uint32_t i = 0; i < WC_MAX; i++) {
-                    const uint32_t qn = wc_n[wi * WC_MAX + i];
-                    if (!qn) break;
-                    if (rs <= wc_tau[wi * WC_MAX + i]) { if (qn < m.walks[t].n) sid = wi * WC_MAX + i; break; }
-                }
-            }
-        }
         if (walk_max_events && k <= WALK16_K) {
             uint32_t nj = 0, open_max = 0, events = 0;
             if (sid != NONE) {
-                const WcInfo* q = m.wc_info + sid;
-                const DevWalk& ar = m.walks[WC_SLOT];
-                cls = classify(ar.ix_head + q->head_off, ar.ix_nest + q->nest_off, nj, open_max, events);
+                cls = classify(sid, nj, open_max, events);
                 if (cls != PLAN_SWEEP) { wsid[r] = sid; t = WC_SLOT; }
             }
-            if (cls == PLAN_SWEEP) cls = classify(m.walks[t].ix_head, m.walks[t].ix_nest, nj, open_max, events);
+            if (cls == PLAN_SWEEP) cls = classify(m.tw_base + t, nj, open_max, events);
             if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
                 // the deepest stack a walk of the class can need in this call: its kernel's LDS request
                 if (open_max > open_of[cls]) atomicMax(&open_of[cls], open_max);
@@ -184,11 +242,11 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                         // none of the read's positions is mutated in its stream: every node scores base + c, and the
                         // stream-wide aggregate is the answer (what k_walk finds without a single range query) -- the
                         // root is in every stream and always competes, so the aggregate never loses to the bound
-                        const SegNode whole = m.wc_info[t == WC_SLOT ? sid : m.tw_base + t].whole;
-                        if (direct.best_bfs_j) direct.best_bfs_j[r] = m.rank2bfs[whole.rank < m.N ? whole.rank : 0u];
-                        if (direct.score) direct.score[r] = whole.base + c;
-                        if (direct.num_best) direct.num_best[r] = whole.cnt;
-                        if (direct.flags) direct.flags[r] = whole.hu ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
+                        const uint32_t at = t == WC_SLOT ? sid : m.tw_base + t;
+                        if (direct.best_bfs_j) direct.best_bfs_j[r] = rt_wbfs[at];
+                        if (direct.score) direct.score[r] = rt_wbase[at] + c;
+                        if (direct.num_best) direct.num_best[r] = rt_wcnt[at] >> 1;
+                        if (direct.flags) direct.flags[r] = (rt_wcnt[at] & 1u) ? WEPP_FLAG_HAS_UNIQUE_DEV : 0u;
                         resolved = true;
                     } else append = cls == PLAN_WALK8 ? 1u : 2u;
                 }
@@ -221,8 +279,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         // (use_crowns & 2 -- wepp_best_nodes, which lists nodes and so takes streams of real nodes only: every read
         // inside a window whose stream is the window's candidate crown takes it when it is the smaller one)
         if (cls == PLAN_SWEEP && in_win && wi < m.n_windows &&
-            ((use_crowns & 2) ? m.win_n[wi] < m.walks[t].n
-                              : k > WIN_MIN_ENTRIES ? (m.win_n[wi] < m.walks[t].n || t + 1 == m.n_streams) : (sid == NONE && t + 1 == m.n_streams))) {
+            ((use_crowns & 2) ? m.win_n[wi] < wc_n[m.tw_base + t]
+                              : k > WIN_MIN_ENTRIES ? (m.win_n[wi] < wc_n[m.tw_base + t] || t + 1 == m.n_streams) : (sid == NONE && t + 1 == m.n_streams))) {
             // many entries, all inside one genome window: a tile of such reads sweeps the window's stream -- the window's
             // candidates (a crown of a few thousand nodes, whatever the root score) or, for the reads no crown serves,
             // the whole tree as the window sees it
@@ -232,7 +290,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             // it cannot walk (more than WALK16_K entries or too deep a stack): waves of its own sweep its window crown (k_sweep_arena)
             wsid[r] = sid;
             t = WC_SLOT;
-        } else if (cls == PLAN_SWEEP && n_hard >= seed_min_hard && m.seed_chunks && k <= SEED_MAX_ENTRIES && m.walks[t].n >= seed_min_nodes) {
+        } else if (cls == PLAN_SWEEP && n_hard >= seed_min_hard && m.seed_chunks && k <= SEED_MAX_ENTRIES && wc_n[m.tw_base + t] >= seed_min_nodes) {
             // a whole-genome sample (no window holds it, too many entries to walk): the chunk signatures rule out nearly
             // all of the tree for it, whatever its tree-wide bound admits (seed_kernels.hip)
             cls = PLAN_SEED;
@@ -242,7 +300,6 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         tier_of[r] = (uint8_t)t_id;
         if (k > mx[t_id]) atomicMax(&mx[t_id], k);
         }   // valid
-        ROUTE_STAMP(2);  // the reads' routing
         // ---- counters, one LDS atomic per wave and distinct value instead of one per read (all lanes take part) ----
         // position among this block's reads of the plan (k_scatter): the reads of a wave that share a plan take
         // consecutive slots
@@ -278,7 +335,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 if (append == cc + 1) { app4[u] = cc + 1; aslot4[u] = base + (uint32_t)__popcll(mk & lt_mask); }
             }
         }
-        ROUTE_STAMP(3);  // counters and slots
+        ROUTE_STAMP(6);  // class, plan, counters and slots
       }
       // ... one global atomic per block, round and class reserves the block's range of the class's list (a global atomic
       // per wave, ~60 K of them on one address per million reads, made k_route six times slower)
@@ -310,21 +367,22 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
 #pragma unroll
           for (uint32_t u = 0; u < 4; u++) {
               const uint32_t r = r0 + u * blockDim.x;
-              if (app4[u]) direct.wlist[app4[u] - 1][wl_base[app4[u] - 1] + aslot4[u]] = r;
+              if (app4[u]) (app4[u] == 1 ? direct.wlist[0] : direct.wlist[1])[wl_base[app4[u] - 1] + aslot4[u]] = r;     // (no indexing of the argument's arrays: that would copy them to scratch)
               if (ww4[u]) {
                   const uint32_t big = ww4[u] & 1u, at = ww_base[big] + (ww4[u] >> 1) - 1u;
                   direct.wwlist[big ? n_reads - 1u - at : at] = r;
               }
               if (cj4[u] && c_ok[cj4[u] - 1]) {
                   const uint32_t cc = cj4[u] - 1, j0 = cj_base[cc] + cjs4[u];
-                  direct.clist[cc][cl_base[cc] + cls4[u]] = r;
+                  (cc ? direct.clist[1] : direct.clist[0])[cl_base[cc] + cls4[u]] = r;
                   direct.job_first[r] = j0;
-                  for (uint32_t c2 = 0; c2 < cnj4[u]; c2++) direct.jobs[cc][j0 + c2] = r;
+                  uint32_t* jt = cc ? direct.jobs[1] : direct.jobs[0];
+                  for (uint32_t c2 = 0; c2 < cnj4[u]; c2++) jt[j0 + c2] = r;
               }
           }
           __syncthreads();        // (c_ok and the bases are rewritten in the next round)
       }
-      ROUTE_STAMP(4);    // the lists: barrier, reservation, writes
+      ROUTE_STAMP(7);    // the lists: barrier, reservation, writes
     }
     __syncthreads();
     if (threadIdx.x < MAX_PLANS) {
@@ -342,9 +400,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         // what a resolved read asked memory for: its offsets and words, a list head per entry, the aggregate, the result
         if (direct.work_counter) atomicAdd(direct.work_counter + WALK_COUNTERS + (blockIdx.x & (WALK_COUNTERS - 1)), 48ull * resolved_of[0]);
     }
-    ROUTE_STAMP(5);      // epilogue
+    ROUTE_STAMP(8);      // epilogue
 #ifdef WEPP_ROUTE_STATS
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_route_stats[6] += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_route_stats[9] += 1;
 #endif
 }
 #ifdef WEPP_ROUTE_STATS

@@ -910,6 +910,22 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void k_sweep_multi(SweepPlans pl,
                                   q.part_rank, q.part_cnt);
 }
 
+// all the window plans of one placement call in ONE launch (1.2 kb reads: ~30 windows, each with too few tiles to fill
+// the chip on its own): a workgroup = one tile of one window and DENSE_WAVES chunks of the window's stream, the plans in
+// the order of the kernel argument (capi.cpp: longest chunks first)
+__global__ __launch_bounds__(64 * DENSE_WAVES) void k_sweep_windows(const DevStream* __restrict__ wstreams, WinPlans pl, uint32_t bm_words,
+                                                                    uint32_t max_pos, const uint32_t* __restrict__ read_off,
+                                                                    const uint32_t* __restrict__ read_word,
+                                                                    const int32_t* __restrict__ root_score) {
+    uint32_t p = 0;
+    while (p + 1 < pl.n && blockIdx.x >= pl.p[p].wg_end) p++;
+    const WinPlanDev& q = pl.p[p];
+    const uint32_t wg0 = p ? pl.p[p - 1].wg_end : 0;
+    const DevStream st = wstreams[q.sid];
+    sweep_tile<true, true, true>(st, blockIdx.x - wg0, 0u, bm_words, max_pos, q.ent_cap, q.win_base, read_off, read_word, root_score,
+                                 q.list, q.n_list, q.T, q.ntiles, q.bpc, q.part_score, q.part_rank, q.part_cnt);
+}
+
 // -----------------------------------------------------------------------------
 // finalize: combine the chunks of a read, map the winner back to the
 // reference's BFS index and recompute its has_unique flag
@@ -1003,6 +1019,25 @@ __global__ void k_finalize_multi(DevMAT m, SweepPlans pl, const uint32_t* __rest
 #undef FIN
 }
 
+__global__ void k_finalize_windows(DevMAT m, WinPlans pl, const uint32_t* __restrict__ read_off,
+                                   const uint32_t* __restrict__ read_word, uint32_t* __restrict__ best_bfs_j,
+                                   int32_t* __restrict__ score, uint32_t* __restrict__ num_best,
+                                   uint32_t* __restrict__ flags) {
+    uint32_t p = 0;
+    while (p + 1 < pl.n && blockIdx.x >= pl.p[p].fin_end) p++;
+    const WinPlanDev& q = pl.p[p];
+    const uint32_t blk = blockIdx.x - (p ? pl.p[p - 1].fin_end : 0);
+#define FIN(L) finalize_reads<L>(m, blk, read_off, read_word, q.list, q.n_list, q.nchunks, q.part_score, q.part_rank, \
+                                 q.part_cnt, best_bfs_j, score, num_best, flags)
+    switch (finalize_lanes_per_read(q.nchunks)) {
+        case 1: FIN(1); break;
+        case 4: FIN(4); break;
+        case 16: FIN(16); break;
+        default: FIN(64); break;
+    }
+#undef FIN
+}
+
 // -----------------------------------------------------------------------------
 // launchers (called from capi.cpp)
 // -----------------------------------------------------------------------------
@@ -1047,6 +1082,22 @@ hipError_t launch_sweep_multi(const DevMAT& m, const SweepPlans& pl, const uint3
     hipLaunchKernelGGL(k_sweep_multi, dim3((units + SWEEP_WAVES - 1) / SWEEP_WAVES), dim3(64 * SWEEP_WAVES),
                        lds_bytes * SWEEP_WAVES, stream, pl, m.bm_words, m.max_pos, lds_bytes / 4, d_read_off, d_read_word,
                        root_score);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_windows(const DevMAT& m, const DevStream* d_wstreams, const WinPlans& pl, const uint32_t* d_read_off,
+                                const uint32_t* d_read_word, const int32_t* root_score, uint32_t lds_bytes, hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sweep_windows, dim3(pl.p[pl.n - 1].wg_end), dim3(64 * DENSE_WAVES), lds_bytes, stream, d_wstreams, pl, m.bm_words,
+                       m.max_pos, d_read_off, d_read_word, root_score);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_windows(const DevMAT& m, const WinPlans& pl, const uint32_t* d_read_off, const uint32_t* d_read_word,
+                                   uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags, hipStream_t stream) {
+    if (pl.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_windows, dim3(pl.p[pl.n - 1].fin_end), dim3(256), 0, stream, m, pl, d_read_off, d_read_word, best_bfs_j,
+                       score, num_best, flags);
     return hipGetLastError();
 }
 
@@ -1096,6 +1147,8 @@ hipError_t sweep_set_max_lds(uint32_t bytes) {
     e = hipFuncSetAttribute((const void*)k_sweep_arena, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_sweep_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_sweep_windows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_sweep<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }

@@ -30,6 +30,8 @@ struct PlaceTunables {
     uint32_t target_waves_dense = 16384; // WEPP_TARGET_WAVES_DENSE
     uint64_t chunk_bytes = SWEEP_CHUNK_BYTES;   // WEPP_CHUNK_BYTES
     bool sweep_unfused = false;          // WEPP_SWEEP_UNFUSED=1: one sweep launch per plan, back to back
+    bool blind16 = false;                // WEPP_BLIND16=1: the plain walks of 9 - 16 entries launched blind behind k_route too (measured: they start when the walks of 1 - 8 entries end either way)
+    bool windows_unfused = false;        // WEPP_WINDOWS_UNFUSED=1: one launch per window plan, chunks sized per plan (round 3's form; results identical)
     // seeds: whole-genome samples
     bool seed = true;                    // WEPP_SEED=0: whole-genome samples take the tile sweeps
     uint32_t seed_min_hard = SEED_MIN_HARD;          // WEPP_SEED_MIN_HARD
@@ -57,6 +59,8 @@ struct PlaceTunables {
         t.target_waves_dense = (uint32_t)env::u64("WEPP_TARGET_WAVES_DENSE", 16384, 1, 1u << 24);
         t.chunk_bytes = env::u64("WEPP_CHUNK_BYTES", SWEEP_CHUNK_BYTES, 4096, 1ull << 40);
         t.sweep_unfused = env::is_set("WEPP_SWEEP_UNFUSED") && env::flag("WEPP_SWEEP_UNFUSED", false);
+        t.blind16 = env::flag("WEPP_BLIND16", false);
+        t.windows_unfused = env::is_set("WEPP_WINDOWS_UNFUSED") && env::flag("WEPP_WINDOWS_UNFUSED", false);
         t.seed = env::flag("WEPP_SEED", true);
         t.seed_min_hard = (uint32_t)env::u64("WEPP_SEED_MIN_HARD", SEED_MIN_HARD, 0, 0xFFFFu);
         t.seed_min_nodes = (uint32_t)env::u64("WEPP_SEED_MIN_NODES", SEED_MIN_STREAM_NODES, 0, 0xFFFFFFFFu);
