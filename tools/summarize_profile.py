@@ -19,7 +19,7 @@ placement call (sweeps, walks, their job tables and finalizes); routing is exclu
 import collections, csv, glob, json, os, shutil, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-PLACE = ("k_sweep", "k_walk", "k_finalize", "k_gather_jobs", "k_first_pos", "rocprim", "block_id_wrapper", "radix", "scan")
+PLACE = ("k_sweep", "k_walk", "k_seed", "k_finalize", "k_gather_jobs", "k_first_pos", "rocprim", "block_id_wrapper", "radix", "scan")
 
 
 def is_place(name):

@@ -57,8 +57,8 @@ void release(wepp_mat* h) {
     }
     for (uint32_t i = 0; i < 4 * wepp_mat::kPipeMax; i++)
         if (h->pipe_out[i]) (void)hipEventDestroy(h->pipe_out[i]);
-    if (h->pipe_h2d) (void)hipStreamDestroy(h->pipe_h2d);
-    if (h->pipe_d2h) (void)hipStreamDestroy(h->pipe_d2h);
+    for (hipStream_t st : h->pipe_h2d) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : h->pipe_d2h) if (st) (void)hipStreamDestroy(st);
     for (hipStream_t st : h->pipe_compute)
         if (st) (void)hipStreamDestroy(st);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -460,19 +460,30 @@ namespace {
 // The placement of one batch whose reads are on the device.  plan_base / plan_total: the batch is reads
 // [plan_base, plan_base + n_reads) of a call of plan_total reads (a sub-batch of wepp_place_batch's pipeline; a
 // direct wepp_place_batch_device call is the whole: base 0, total n_reads) -- where its plan ids go in d_plan_of.
+// the plan id and walk-slice id of every read of a call (wepp_mat_last_plans / _crowns read them back): grow-only
+int ensure_plan_buffers(wepp_mat_t* mat, uint32_t plan_total) {
+    if (plan_total <= mat->plan_of_bytes) return WEPP_OK;
+    if (mat->d_plan_of) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->d_plan_of); mat->d_plan_of = nullptr; mat->plan_of_bytes = 0; }
+    if (mat->d_wsid_of) { (void)hipFree(mat->d_wsid_of); mat->d_wsid_of = nullptr; }
+    const size_t need = (size_t)plan_total + plan_total / 4 + 256;
+    hipError_t e = hipMalloc((void**)&mat->d_plan_of, need);
+    if (e == hipSuccess) e = hipMalloc((void**)&mat->d_wsid_of, need * 4);
+    if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc plan ids: ") + hipGetErrorString(e));
+    mat->plan_of_bytes = need;
+    return WEPP_OK;
+}
+
+// Two sub-batches of one wepp_place_batch may be inside this function at once, on two host threads and two lanes (each
+// lane has its own workspace, counters, side streams and events): what they share on the handle is read-only here but
+// for the event ring (a slot claimed atomically), the job-size hint (atomic) and the call statistics (stat_mu).
 int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                  uint32_t* d_best_bfs_j, int32_t* d_score, uint32_t* d_num_best, uint32_t* d_flags, hipStream_t stream,
                  uint32_t plan_base, uint32_t plan_total, uint32_t lane_idx = 0) {
     PlaceLane& L = mat->lane[lane_idx];
-    if (plan_total > mat->plan_of_bytes) {
-        // (only ever at the first sub-batch of a call: plan_total is the whole call's)
-        if (mat->d_plan_of) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(mat->d_plan_of); mat->d_plan_of = nullptr; mat->plan_of_bytes = 0; }
-        if (mat->d_wsid_of) { (void)hipFree(mat->d_wsid_of); mat->d_wsid_of = nullptr; }
-        const size_t need = (size_t)plan_total + plan_total / 4 + 256;
-        hipError_t e = hipMalloc((void**)&mat->d_plan_of, need);
-        if (e == hipSuccess) e = hipMalloc((void**)&mat->d_wsid_of, need * 4);
-        if (e != hipSuccess) return set_error(WEPP_ENOMEM, std::string("hipMalloc plan ids: ") + hipGetErrorString(e));
-        mat->plan_of_bytes = need;
+    {
+        // (a pipelined wepp_place_batch has sized them for the whole call before its sub-batches start, on one thread)
+        const int prc = ensure_plan_buffers(mat, plan_total);
+        if (prc != WEPP_OK) return prc;
     }
     const uint32_t T = mat->tile_reads;
     const uint32_t ns = mat->dev.n_streams;
@@ -566,7 +577,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // whole-genome samples are seeded (seed_kernels.hip) when work skipping is on and the tree carries signatures
     const uint32_t seed_min_hard = (mat->use_seeds && mat->use_crowns && mat->dev.seed_chunks) ? tun.seed_min_hard : 0xFFFFFFFFu;
     // ---- route the reads to streams ------------------------------------------------------
-    const uint32_t ev_slot = (uint32_t)(mat->n_timed % wepp_mat::kRing);
+    const uint32_t ev_slot = (uint32_t)(mat->n_timed.fetch_add(1, std::memory_order_relaxed) % wepp_mat::kRing);
     constexpr uint32_t BLIND16_STREAM = MAX_STREAMS - 6;     // (side stream of the second plain walk class)
     constexpr uint32_t PLAN_STREAM = MAX_STREAMS - 7;
     // Streams of a call.  The caller's stream runs k_route and, right behind it (no cross-stream wait: ~25 us), the
@@ -1090,13 +1101,21 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         if (late16[1]) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[MAX_STREAMS - 3], 0));
     }
     HIP_TRY(hipEventRecord(mat->ev1[slot], stream));
-    mat->n_timed++;
-    mat->last_passes = passes;
-    mat->last_bytes = bytes;
-    mat->acc_passes += passes;
-    mat->acc_bytes += bytes;
-    mat->last_n_reads = plan_base + n_reads == plan_total ? plan_total : 0;   // (complete once the last sub-batch is in)
-    mat->last_walk_reads = (plan_base ? mat->last_walk_reads : 0) + walk_reads;
+    {
+        std::lock_guard<std::mutex> lk(mat->stat_mu);
+        mat->last_passes = passes;
+        mat->last_bytes = bytes;
+        mat->acc_passes += passes;
+        mat->acc_bytes += bytes;
+        if (plan_total == n_reads) {            // a call of its own
+            mat->last_n_reads = n_reads;
+            mat->last_walk_reads = walk_reads;
+        } else {                                // a sub-batch (wepp_place_batch reset the sums): complete once every one is in, in any order
+            mat->plan_reads_in += n_reads;
+            mat->last_walk_reads += walk_reads;
+            mat->last_n_reads = mat->plan_reads_in == plan_total ? plan_total : 0;
+        }
+    }
     return WEPP_OK;
 }
 }  // namespace
@@ -1186,11 +1205,13 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
 
     hipError_t e = hipSuccess;
-    if (!mat->pipe_h2d) {
-        e = hipStreamCreateWithFlags(&mat->pipe_h2d, hipStreamNonBlocking);
+    if (!mat->pipe_h2d[0]) {
+        for (hipStream_t& st : mat->pipe_h2d)
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         for (hipStream_t& st : mat->pipe_compute)
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mat->pipe_d2h, hipStreamNonBlocking);
+        for (hipStream_t& st : mat->pipe_d2h)
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         for (uint32_t i = 0; i < wepp_mat::kPipeMax && e == hipSuccess; i++) {
             e = hipEventCreateWithFlags(&mat->pipe_up[i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&mat->pipe_done[i], hipEventDisableTiming);
@@ -1252,13 +1273,19 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     // which two calls cannot overlap -- so a batch is only cut into several calls when each keeps >= 2 M reads
     // (measured, profiles/r3_experiments/pcie_pipeline.txt: 1 M reads in 2 / 4 / 8 calls 1.41 / 1.98 / 3.07 ms against
     // 1.28 in one).  C copy chunks >= S: the reads are checked, staged and sent up chunk by chunk, whatever S.
-    uint32_t S = !big || per_node_scores ? 1u : pipe_knob ? pipe_knob : std::max<uint32_t>(1u, n_reads >> 21);
+    // (round 4: with two launch threads a call of half a million reads or more goes as two halves, 1.08 -> 1.00 ms per
+    // 1 M reads; three or four are slower again: the host's HIP calls per device call are what runs out)
+    const bool can_pair = big && mat->pool && mat->pool->workers() >= 2;
+    uint32_t S = !big || per_node_scores ? 1u : pipe_knob ? pipe_knob : std::max<uint32_t>((can_pair && n_reads >= (1u << 19)) ? 2u : 1u, n_reads >> 21);
     S = std::min<uint32_t>(S, wepp_mat::kPipeMax);
-    const uint32_t C = big ? S * ((4 + S - 1) / S) : 1;                        // copy chunks (a multiple of S, >= 4)
+    const uint32_t min_chunks = mat->tun.pipe_min_chunks;
+    const uint32_t C = big ? S * ((min_chunks + S - 1) / S) : 1;               // copy chunks (a multiple of S, >= 4 unless WEPP_PIPE_MIN_CHUNKS says otherwise)
     const uint32_t CPS = C / S;                                                // chunks per sub-batch
     const uint32_t threads = big ? mat->pool->workers() + 1 : 1;
     const uint32_t PS = big ? std::max(1u, (4 * threads + C - 1) / C) : 1;     // staging parts per chunk
     const uint32_t PO = big ? 4 : 1;                                           // copy-out parts per (sub-batch, array)
+    // (several sub-batches, every result array wanted and none in memory the caller pinned: one copy per sub-batch)
+    const bool merged_out = S > 1 && dst[0] && dst[1] && dst[2] && dst[3] && !out_pinned[0] && !out_pinned[1] && !out_pinned[2] && !out_pinned[3];
     auto chunk_lo = [&](uint32_t c) { return (uint32_t)((uint64_t)n_reads * c / C); };
     auto sub_lo = [&](uint32_t k) { return chunk_lo(k * CPS); };
     const uint32_t n_stage = C * PS, n_copy = any_staged_out ? S * 4 * PO : 0;
@@ -1338,7 +1365,7 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         while ((st = launched[k].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
         if (st < 0) return;
         (void)hipSetDevice(mat->device);                              // (a worker thread starts on device 0)
-        copy_err[t] = hipEventSynchronize(mat->pipe_out[k * 4 + i]);  // this array of the sub-batch has landed (the next one is on the bus)
+        copy_err[t] = hipEventSynchronize(mat->pipe_out[k * 4 + (merged_out ? 0u : i)]);  // this array of the sub-batch has landed (the next one is on the bus)
         if (copy_err[t] != hipSuccess) return;
         const size_t lo = sub_lo(k), hi = sub_lo(k + 1);
         const size_t a = lo + (hi - lo) * part / PO, b = lo + (hi - lo) * (part + 1) / PO;
@@ -1346,42 +1373,54 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
     };
     double t_launched = 0;
 
-    // ---- the launch sequence (this thread): H2D, kernels, D2H of every sub-batch ----
-    int rc = WEPP_OK;
-    std::string rc_msg;
+    // ---- the launch sequence: H2D, kernels, D2H of every sub-batch ----
+    // TWO launchers when the call has several sub-batches and the pool at least two workers: this thread takes the
+    // even sub-batches (lane 0), a pool worker the odd ones (lane 1).  A device call keeps its host thread until its
+    // routing counters are back (place_device polls for them); on one thread the kernels of sub-batch k + 1 were only
+    // enqueued once call k had returned, so the lanes never overlapped (1 M reads in 2 / 4 calls: 1.04 / 1.10 ms against
+    // 1.05 in one).  Every launcher uploads its own sub-batches, the one after the next before the device call of this one.
+    const bool two_launchers = big && S > 1 && mat->pool && mat->pool->workers() >= 2;
+    struct Launcher { int rc = WEPP_OK; std::string msg; };
+    Launcher launcher[2];
     double t_launch[wepp_mat::kPipeMax] = {};
-    bool rejected = false;
-    // the words of sub-batch k go up chunk by chunk, each as soon as its reads are checked and staged; up_ok[k] = none of its
-    // reads was rejected.  A sub-batch's upload is enqueued BEFORE the device call of the one before it: that call keeps
-    // the launch thread until its routing counters are back, and the copy engine works meanwhile.
+    std::atomic<bool> rejected{false};
     bool up_ok[wepp_mat::kPipeMax] = {};
     hipError_t up_he[wepp_mat::kPipeMax] = {};
-    auto upload = [&](uint32_t k) {
+    // the words of sub-batch k go up chunk by chunk, each as soon as its reads are checked and staged; up_ok[k] = none
+    // of its reads was rejected
+    auto upload = [&](uint32_t k, const Launcher& me) {
         const uint32_t* src_off = in_pinned ? read_off : pin_off;
         const uint32_t* src_word = in_pinned ? read_word : pin_word;
         hipError_t he = hipSuccess;
-        bool ok = rc == WEPP_OK && !rejected;
+        bool ok = me.rc == WEPP_OK && !rejected.load(std::memory_order_acquire);
         for (uint32_t ck = k * CPS; ck < (k + 1) * CPS && ok && he == hipSuccess; ck++) {
             while (staged[ck].load(std::memory_order_acquire) < PS) std::this_thread::yield();
+            // (the first offset of a sub-batch is staged with the chunk before it)
+            if (ck == k * CPS && ck > 0) while (staged[ck - 1].load(std::memory_order_acquire) < PS) std::this_thread::yield();
             for (uint32_t t = ck * PS; t < (ck + 1) * PS && ok; t++) ok = bad[t] == 0xFFFFFFFFu;
             if (!ok) break;
             const uint32_t clo = chunk_lo(ck), chi = chunk_lo(ck + 1);
             const uint32_t w0 = read_off[clo], w1 = read_off[chi];
-            // (offset `clo` went up with the chunk before: the kernels of the sub-batch before may be reading it)
-            const uint32_t o0 = ck ? clo + 1 : clo;
-            he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(chi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
-            if (he == hipSuccess && w1 > w0) he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d);
+            // offset `clo` went up with the chunk before (the kernels of the sub-batch before may be reading it) -- but
+            // the first chunk of a SUB-BATCH sends its own too: the chunk before belongs to the other launcher, whose
+            // copy may not be enqueued yet (the same four bytes written twice)
+            const uint32_t o0 = (ck && ck != k * CPS) ? clo + 1 : clo;
+            he = hipMemcpyAsync(d_off + o0, src_off + o0, (size_t)(chi + 1 - o0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d[k % wepp_mat::kLanes]);
+            if (he == hipSuccess && w1 > w0)
+                he = hipMemcpyAsync(d_word + w0, src_word + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, mat->pipe_h2d[k % wepp_mat::kLanes]);
         }
-        if (ok && he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d);
-        if (!ok) rejected = true;      // nothing of a rejected batch reaches a kernel, and nothing behind it is worth placing
+        if (ok && he == hipSuccess) he = hipEventRecord(mat->pipe_up[k], mat->pipe_h2d[k % wepp_mat::kLanes]);
+        if (!ok) rejected.store(true, std::memory_order_release);      // nothing of a rejected batch reaches a kernel, and nothing behind it is worth placing
         up_ok[k] = ok;
         up_he[k] = he;
     };
-    auto launch_all = [&]() {
-        upload(0);
-        for (uint32_t k = 0; k < S; k++) {
+    auto launch_from = [&](uint32_t first, uint32_t step, Launcher& me) {
+        if (first >= S) return;
+        (void)hipSetDevice(mat->device);                              // (a worker thread starts on device 0)
+        upload(first, me);
+        for (uint32_t k = first; k < S; k += step) {
             const uint32_t lo = sub_lo(k), hi = sub_lo(k + 1);
-            if (k + 1 < S) upload(k + 1);
+            if (k + step < S) upload(k + step, me);
             hipError_t he = up_he[k];
             if (!up_ok[k]) {
                 launched[k].store(-1, std::memory_order_release);
@@ -1394,19 +1433,27 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
                 // (the offsets of a sub-batch index the whole call's word array: no rebasing)
                 const int prc = place_device(mat, d_off + lo, d_word, hi - lo, d_out + lo, (int32_t*)(d_out + n_reads) + lo,
                                              d_out + 2 * (size_t)n_reads + lo, d_out + 3 * (size_t)n_reads + lo, cs, lo, n_reads, ln);
-                if (prc != WEPP_OK) { rc = prc; rc_msg = wepp_last_error(); launched[k].store(-1, std::memory_order_release); continue; }
+                if (prc != WEPP_OK) { me.rc = prc; me.msg = wepp_last_error(); launched[k].store(-1, std::memory_order_release); continue; }
             }
             if (he == hipSuccess) he = hipEventRecord(mat->pipe_done[k], cs);
-            if (he == hipSuccess) he = hipStreamWaitEvent(mat->pipe_d2h, mat->pipe_done[k], 0);
+            hipStream_t ds = mat->pipe_d2h[ln];
+            if (he == hipSuccess) he = hipStreamWaitEvent(ds, mat->pipe_done[k], 0);
+            if (merged_out) {
+                // the four result arrays of the sub-batch in ONE (2-D) copy into the staging buffer, which has the device
+                // buffer's layout: a copy and an event are host calls of ~5 us each, and the host's calls are what a
+                // call split into sub-batches runs out of
+                if (he == hipSuccess) he = hipMemcpy2DAsync(po + lo, (size_t)n_reads * 4, d_out + lo, (size_t)n_reads * 4, (size_t)(hi - lo) * 4, 4, hipMemcpyDeviceToHost, ds);
+                if (he == hipSuccess) he = hipEventRecord(mat->pipe_out[k * 4], ds);
+            } else
             for (int i = 0; i < 4 && he == hipSuccess; i++) {
                 if (!dst[i]) continue;
                 uint32_t* to = out_pinned[i] ? (uint32_t*)dst[i] : po + (size_t)i * n_reads;
-                he = hipMemcpyAsync(to + lo, d_out + (size_t)i * n_reads + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, mat->pipe_d2h);
-                if (he == hipSuccess) he = hipEventRecord(mat->pipe_out[k * 4 + i], mat->pipe_d2h);   // an array is moved out while the next one comes down
+                he = hipMemcpyAsync(to + lo, d_out + (size_t)i * n_reads + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, ds);
+                if (he == hipSuccess) he = hipEventRecord(mat->pipe_out[k * 4 + i], ds);   // an array is moved out while the next one comes down
             }
             if (he != hipSuccess) {
-                rc = hip_fail(he, "H2D / kernels / D2H of a sub-batch");
-                rc_msg = wepp_last_error();
+                me.rc = hip_fail(he, "H2D / kernels / D2H of a sub-batch");
+                me.msg = wepp_last_error();
                 launched[k].store(-1, std::memory_order_release);
                 continue;
             }
@@ -1414,14 +1461,27 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
             if (dbg_time) t_launch[k] = since();
         }
     };
+    {
+        // (the sub-batches' plan ids land in one array sized for the call: grown here, before two threads would)
+        const int prc = S > 1 ? ensure_plan_buffers(mat, n_reads) : WEPP_OK;
+        if (prc != WEPP_OK) return prc;
+        std::lock_guard<std::mutex> lk(mat->stat_mu);
+        mat->plan_reads_in = 0;
+        mat->last_walk_reads = 0;
+        mat->last_n_reads = 0;
+    }
     if (big) {
-        // two rounds on the pool: the staging tasks while this thread launches; the copy-out tasks once every sub-batch's
-        // copies are enqueued.  (One round of both had the workers that ran out of staging tasks spin -- yield in a loop
-        // -- for their sub-batch's launch: fifteen spinning threads beside the launch thread, on a container of sixteen
-        // cores, delayed the thread they were waiting for.)
-        const std::function<void(uint32_t)> stage_only = [&](uint32_t t) { stage_task(t); };
-        mat->pool->start(n_stage, stage_only);
-        launch_all();
+        // two rounds on the pool: the staging tasks (and the second launcher, first in line) while this thread launches;
+        // the copy-out tasks once every sub-batch's copies are enqueued.  (One round of both had the workers that ran
+        // out of staging tasks spin -- yield in a loop -- for their sub-batch's launch: fifteen spinning threads beside
+        // the launch thread, on a container of sixteen cores, delayed the thread they were waiting for.)
+        const uint32_t extra = two_launchers ? 1u : 0u;
+        const std::function<void(uint32_t)> stage_only = [&](uint32_t t) {
+            if (t < extra) launch_from(1, 2, launcher[1]);
+            else stage_task(t - extra);
+        };
+        mat->pool->start(n_stage + extra, stage_only);
+        launch_from(0, two_launchers ? 2 : 1, launcher[0]);
         mat->pool->finish();
         if (dbg_time) t_launched = since();
         if (n_copy) {
@@ -1430,15 +1490,19 @@ extern "C" int wepp_place_batch(wepp_mat_t* mat, const uint32_t* read_off, const
         }
     } else {
         for (uint32_t t = 0; t < n_stage; t++) stage_task(t);
-        launch_all();
+        launch_from(0, 1, launcher[0]);
         for (uint32_t t = 0; t < n_copy; t++) copy_task(t);
     }
+    int rc = launcher[0].rc != WEPP_OK ? launcher[0].rc : launcher[1].rc;
+    std::string rc_msg = launcher[0].rc != WEPP_OK ? launcher[0].msg : launcher[1].msg;
     // everything this call put on the handle's streams has finished before it returns -- also after an error, and
     // when no result array was asked for (the staging buffers belong to the next call then)
     {
-        hipError_t s1 = hipStreamSynchronize(mat->pipe_d2h), s2 = hipStreamSynchronize(mat->pipe_compute[0]), s3 = hipStreamSynchronize(mat->pipe_h2d);
-        const hipError_t s4 = hipStreamSynchronize(mat->pipe_compute[1]);
-        const hipError_t se = s1 != hipSuccess ? s1 : s2 != hipSuccess ? s2 : s3 != hipSuccess ? s3 : s4;
+        hipError_t se = hipSuccess;
+        for (hipStream_t st : {mat->pipe_d2h[0], mat->pipe_d2h[1], mat->pipe_compute[0], mat->pipe_compute[1], mat->pipe_h2d[0], mat->pipe_h2d[1]}) {
+            const hipError_t r = hipStreamSynchronize(st);
+            if (se == hipSuccess) se = r;
+        }
         if (se != hipSuccess && rc == WEPP_OK) { rc = hip_fail(se, "placement kernels / copies"); rc_msg = wepp_last_error(); }
     }
     for (uint32_t t = 0; t < n_stage; t++) {

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -48,7 +50,7 @@ struct wepp_mat {
     PlaceTunables tun;                // the environment's knobs, read once when the handle was created (tunables.hpp)
     int use_walk = 1;                 // reads with few entries walk their own events (WEPP_WALK=0: sweeps only)
     int use_seeds = 1;                // whole-genome samples go by chunk signatures (WEPP_SEED=0: tile sweeps)
-    uint32_t job_events[2] = {WALK_JOB_EVENTS, WALK_JOB_EVENTS};   // events per job of the chunked classes in the next call
+    std::atomic<uint32_t> job_events[2] = {{WALK_JOB_EVENTS}, {WALK_JOB_EVENTS}};   // events per job of the chunked classes in the next call (a hint: the two launch threads of a pipelined call read and write it freely)
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
     unsigned long long* d_work = nullptr;   // [WALK_COUNTERS] loop iterations of the walks, [WALK_COUNTERS] bytes the walks / seeds asked memory for,
                                             // [D_WORK_EXTRA] seeded samples, chunks they evaluated, chunks in all, most per sample, histogram -- since the last timing reset
@@ -89,7 +91,7 @@ struct wepp_mat {
     // pipe_compute and the results of k-2 come down on pipe_d2h; one event per sub-batch and stage
     static constexpr uint32_t kPipeMax = 8;
     uint32_t pipe_sub_batches = 0;    // 0: chosen per call (one device call per 2 M reads, at most 8)
-    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr, pipe_compute[kLanes] = {};
+    hipStream_t pipe_h2d[kLanes] = {}, pipe_d2h[kLanes] = {}, pipe_compute[kLanes] = {};     // (a set per lane: the two launch threads of a call do not share a stream)
     hipEvent_t pipe_up[kPipeMax] = {}, pipe_done[kPipeMax] = {}, pipe_out[4 * kPipeMax] = {};   // (pipe_out: one per sub-batch and result array)
     void* pin_out = nullptr;          // pinned staging of the results (the reads' staging is `pin`)
     size_t pin_out_bytes = 0;
@@ -101,7 +103,9 @@ struct wepp_mat {
     PlaceLane lane[2];
     static constexpr uint32_t kRing = 64;
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
-    uint64_t n_timed = 0;             // placement calls since the last timing reset
+    std::atomic<uint64_t> n_timed{0}; // placement calls since the last timing reset (a call claims its slot of the event ring when it starts)
+    std::mutex stat_mu;               // the counters below: the sub-batches of a pipelined wepp_place_batch finish on two host threads
+    uint64_t plan_reads_in = 0;       // reads of the sub-batches of the current call that have been planned
     uint64_t last_passes = 0, last_bytes = 0;
     uint64_t acc_passes = 0, acc_bytes = 0;   // the same summed over the calls since the last timing reset
     uint64_t last_walk_reads = 0;     // reads of the most recent call that walked their own events (k_walk)

@@ -38,6 +38,7 @@ struct PlaceTunables {
     uint32_t seed_min_nodes = SEED_MIN_STREAM_NODES; // WEPP_SEED_MIN_NODES
     // host pipeline of wepp_place_batch
     uint32_t pipe_sub_batches = 0;       // WEPP_PIPE_SUBBATCHES
+    uint32_t pipe_min_chunks = 4;        // WEPP_PIPE_MIN_CHUNKS: copy chunks of a host-buffer batch (rounded up to a multiple of its sub-batches)
     uint32_t host_threads = 0;           // WEPP_HOST_THREADS (0: cores this process may use / handles alive)
     // diagnostics
     bool debug_plans = false, debug_timing = false, walk_debug = false;
@@ -65,6 +66,7 @@ struct PlaceTunables {
         t.seed_min_hard = (uint32_t)env::u64("WEPP_SEED_MIN_HARD", SEED_MIN_HARD, 0, 0xFFFFu);
         t.seed_min_nodes = (uint32_t)env::u64("WEPP_SEED_MIN_NODES", SEED_MIN_STREAM_NODES, 0, 0xFFFFFFFFu);
         t.pipe_sub_batches = (uint32_t)env::u64("WEPP_PIPE_SUBBATCHES", 0, 1, 8);
+        t.pipe_min_chunks = (uint32_t)env::u64("WEPP_PIPE_MIN_CHUNKS", 4, 1, 64);
         t.host_threads = (uint32_t)env::u64("WEPP_HOST_THREADS", 0, 1, 256);
         t.debug_plans = env::is_set("WEPP_DEBUG_PLANS");
         t.debug_timing = env::is_set("WEPP_DEBUG_TIMING");
