@@ -650,7 +650,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             }
             HIP_TRY(hipStreamWaitEvent(ps, L.route_ev, 0));
         }
-        HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, ps));
+        HIP_TRY(launch_scatter(tier_of, slot_in_blk, n_reads, blk_counts, tier_info, list, walking, ps));
         return WEPP_OK;
     };
 
@@ -702,7 +702,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // walk plans (device_mat.hpp): the reads of one (class, stream) that walk their own events
     WalkPlans walkc[2]{};
     uint32_t walkc_off[2] = {0, 0};   // list offsets of the chunked walk plans
-    uint64_t walk_reads = 0, n_jobs[2] = {0, 0};
+    uint64_t walk_reads = (uint64_t)info[TI_WCUR] + info[TI_WCUR + 1] + info[TI_RESOLVED], n_jobs[2] = {0, 0};     // (the plain walk classes: placed by k_route itself or by the blind walks behind it)
     uint32_t walkc_reads[2] = {0, 0};
     uint32_t arena_n = 0, arena_off = 0, arena_maxk = 1;
     uint32_t seed_n = 0, seed_off = 0, seed_maxk = 1;
@@ -755,10 +755,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
             walk_reads += count;
             continue;
         }
-        if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
-            walk_reads += count;            // (placed by k_route itself or by the blind walk launches behind it)
-            continue;
-        }
+        if (cls == PLAN_WALK8 || cls == PLAN_WALK16) continue;     // (never counted: k_route places or lists them itself, see walk_reads below)
         if (cls == PLAN_SWEEP && t == WC_SLOT) {
             // the reads that sweep their window crown, one wave each (k_sweep_arena); one partial per read
             arena_n = count;
@@ -1765,7 +1762,7 @@ extern "C" int wepp_best_nodes(wepp_mat_t* mat, const uint32_t* read_off, const 
     HIP_TRY(launch_route(dm, d_off, d_word, n_reads, mat->use_crowns ? 3 : 0, 0u, WALK_JOB_EVENTS | (WALK_JOB_EVENTS << 16), WALK8_ROWS, WALK16_ROWS,
                          0xFFFFFFFFu, 0u, d_jobs, d_plan, d_root, blk_counts, tier_info, d_slot, tier_info_next, d_jobs, RouteDirect{}, nullptr));
     mat->lane[0].info_idx ^= 1u;
-    HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, nullptr));
+    HIP_TRY(launch_scatter(d_plan, d_slot, n_reads, blk_counts, tier_info, d_list, false, nullptr));
     HIP_TRY(hipMemcpy(mat->lane[0].h_info, tier_info, TI_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const uint32_t* info = mat->lane[0].h_info;
     const bool debug_plans = mat->tun.debug_plans;

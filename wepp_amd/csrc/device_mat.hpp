@@ -304,7 +304,7 @@ hipError_t launch_sort_reads(const uint32_t* keys_in, uint32_t* keys_out, const 
                              uint32_t n, void* temp, size_t temp_bytes, hipStream_t stream, uint32_t key_bits = SORT_KEY_BITS);
 // scatter: read indices grouped by tier into `list` (tier t occupies [tier_off[t], tier_off[t+1]))
 hipError_t launch_scatter(const uint8_t* tier_of, const uint32_t* slot_in_blk, uint32_t n_reads, const uint32_t* blk_counts,
-                          uint32_t* tier_info, uint32_t* list, hipStream_t stream);
+                          uint32_t* tier_info, uint32_t* list, bool skip_plain_walks, hipStream_t stream);
 hipError_t launch_sweep(const DevMAT& m, const DevStream& st, const uint32_t* d_read_off,
                         const uint32_t* d_read_word, const int32_t* root_score, const uint32_t* list,
                         uint32_t n_list, uint32_t T,

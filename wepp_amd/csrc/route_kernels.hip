@@ -58,6 +58,35 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         wc_tau[i] = q.tau; wc_n[i] = q.n; rt_head[i] = q.head_off; rt_nest[i] = q.nest_off;
         rt_wbase[i] = q.whole.base; rt_wbfs[i] = q.whole_bfs; rt_wcnt[i] = (q.whole.cnt << 1) | (q.whole.hu ? 1u : 0u);
     }
+    // the two scans of a read -- the first tree-wide stream whose bound covers theta, the first crown of its window whose
+    // bound covers its root score -- as table lookups: the bounds are small integers (tree-wide: the flattener's theta
+    // levels; window crowns: base(root) + 0 .. WC_MAX_DTAU, then "any"), so theta and root score - base(root) index
+    // them.  (tab_ok == 0 -- a bound the tables do not reach -- leaves the scans in place.)
+    constexpr uint32_t TT_MAX = 64, WT_D = 8;
+    __shared__ uint8_t t_tab[TT_MAX], sid_tab[MAX_WINDOWS * WT_D];
+    __shared__ uint32_t tab_ok[1];
+    if (threadIdx.x == 0) tab_ok[0] = (m.n_streams >= 2 && m.tau[m.n_streams - 2] < (int32_t)TT_MAX && m.tau[0] >= 0) ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x < TT_MAX) {
+        uint32_t t = m.n_streams - 1;
+        for (uint32_t i = 0; i + 1 < m.n_streams; i++)
+            if ((int32_t)threadIdx.x <= m.tau[i]) { t = i; break; }
+        t_tab[threadIdx.x] = (uint8_t)t;
+    }
+    if (threadIdx.x < m.wc_windows * WT_D && threadIdx.x < MAX_WINDOWS * WT_D) {
+        const uint32_t wi = threadIdx.x / WT_D, d = threadIdx.x % WT_D;
+        // d < WT_D - 1: root score = base(root) + d exactly; d == WT_D - 1: that or more -- only a crown without a
+        // bound serves those, which the table can say as long as every bounded crown's bound is below base(root) + d
+        // (from the LDS copies of the bounds: the barrier above)
+        uint32_t pick = 0xFFu;
+        for (uint32_t i = 0; i < WC_MAX; i++) {
+            const int32_t tau = wc_tau[wi * WC_MAX + i];
+            if (!wc_n[wi * WC_MAX + i]) break;
+            if (tau != 0x7FFFFFFF && (tau < m.root_base || tau >= m.root_base + (int32_t)(WT_D - 1))) atomicAnd(&tab_ok[0], 0u);
+            if (pick == 0xFFu && m.root_base + (int32_t)d <= tau) pick = i;
+        }
+        sid_tab[threadIdx.x] = (uint8_t)pick;
+    }
     __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2];
     if (threadIdx.x < 2) { cj_count[threadIdx.x] = 0; cl_count[threadIdx.x] = 0; }
     if (threadIdx.x == 0) ww_count[0] = ww_count[1] = 0;
@@ -77,6 +106,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     const IxHead* __restrict__ ar_head = m.walks[WC_SLOT].ix_head;      // the walk arena: every stream's index is a slice of it
     const uint8_t* __restrict__ ar_nest = m.walks[WC_SLOT].ix_nest;
     const uint32_t root_w0 = m.node_woff[0], root_w1 = m.node_woff[1];
+    const bool use_tabs = tab_ok[0] != 0;
     // four reads per thread and round: their offsets, then their first two words, are requested together
     // (one read after the other, every read cost its thread three memory round trips in a row)
     const uint32_t lane = threadIdx.x & 63;
@@ -128,12 +158,14 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             }
             c4[u] = c;
             ROUTE_STAMP_NW(2);  // entry counts, the root's mutations
-            root_score[r] = m.root_base + c;   // the root always competes: an upper bound of the best score
             const int theta = m.root_base + c + (int)k;
             uint32_t t = m.n_streams - 1;
-            if (use_crowns)
-                for (uint32_t i = 0; i + 1 < m.n_streams; i++)
-                    if (theta <= m.tau[i]) { t = i; break; }
+            if (use_crowns) {
+                if (use_tabs) t = theta < 0 ? 0u : theta < (int)TT_MAX ? (uint32_t)t_tab[theta] : m.n_streams - 1;
+                else
+                    for (uint32_t i = 0; i + 1 < m.n_streams; i++)
+                        if (theta <= m.tau[i]) { t = i; break; }
+            }
             t4[u] = t;
             ROUTE_STAMP_NW(3);  // tree-wide stream
             // a read inside one genome window: the window crown its ROOT score admits (flatmat.hpp: wcrowns) holds
@@ -145,11 +177,15 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
                 inwin4[u] = p_hi < wi * WIN_STRIDE + WIN_SIZE ? 1u : 0u;      // all listed positions inside genome window wi
                 if (inwin4[u] && wi < m.wc_windows) {
                     const int rs = m.root_base + c;
-                    for (uint32_t i = 0; i < WC_MAX; i++) {
-                        const uint32_t qn = wc_n[wi * WC_MAX + i];
-                        if (!qn) break;
-                        if (rs <= wc_tau[wi * WC_MAX + i]) { if (qn < wc_n[m.tw_base + t]) sid4[u] = wi * WC_MAX + i; break; }
-                    }
+                    if (use_tabs) {
+                        const uint32_t i = sid_tab[wi * WT_D + (uint32_t)min(max(c, 0), (int)WT_D - 1)];
+                        if (i != 0xFFu && wc_n[wi * WC_MAX + i] < wc_n[m.tw_base + t]) sid4[u] = wi * WC_MAX + i;
+                    } else
+                        for (uint32_t i = 0; i < WC_MAX; i++) {
+                            const uint32_t qn = wc_n[wi * WC_MAX + i];
+                            if (!qn) break;
+                            if (rs <= wc_tau[wi * WC_MAX + i]) { if (qn < wc_n[m.tw_base + t]) sid4[u] = wi * WC_MAX + i; break; }
+                        }
                 }
             }
             ROUTE_STAMP_NW(4);  // window crown
@@ -298,25 +334,32 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         }
         t_id = plan_id(cls, t);
         tier_of[r] = (uint8_t)t_id;
-        if (k > mx[t_id]) atomicMax(&mx[t_id], k);
+        // (the root always competes: an upper bound of the best score.  Stored here, behind the loads of both phases: a
+        // store in front of a load makes the wait for the load a wait for the store's acknowledgement too)
+        root_score[r] = m.root_base + c;
+        if (!(resolved || append) && k > mx[t_id]) atomicMax(&mx[t_id], k);
         }   // valid
         // ---- counters, one LDS atomic per wave and distinct value instead of one per read (all lanes take part) ----
         // position among this block's reads of the plan (k_scatter): the reads of a wave that share a plan take
         // consecutive slots
+        // (the reads k_route has placed or listed for the blind walks itself -- nearly all of a sequencing run -- take no
+        // slot: nobody reads their plan's list, k_scatter skips them, and the loop below runs once per plan AMONG THE
+        // OTHERS of the wave, i.e. not at all for most waves)
         {
-            unsigned long long todo = __ballot(valid);
+            const bool listed = valid && !(resolved || append);
+            unsigned long long todo = __ballot(listed);
             uint32_t slot = 0;
             while (todo) {
                 const int first = __builtin_ctzll(todo);
                 const uint32_t tt = (uint32_t)__builtin_amdgcn_readlane((int)t_id, first);
-                const unsigned long long peers = __ballot(valid && t_id == tt);
+                const unsigned long long peers = __ballot(listed && t_id == tt);
                 uint32_t base = 0;
                 if ((int)lane == first) base = atomicAdd(&cnt[tt], (uint32_t)__popcll(peers));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-                if (valid && t_id == tt) slot = base + (uint32_t)__popcll(peers & lt_mask);
+                if (listed && t_id == tt) slot = base + (uint32_t)__popcll(peers & lt_mask);
                 todo &= ~peers;
             }
-            if (valid) slot_in_blk[r] = slot;
+            if (listed) slot_in_blk[r] = slot;
         }
         {
             const unsigned long long rm = __ballot(resolved);
@@ -427,7 +470,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
                                                             const uint32_t* __restrict__ slot_in_blk, uint32_t n_reads,
                                                             const uint32_t* __restrict__ blk_counts,
                                                             uint32_t* __restrict__ tier_info,
-                                                            uint32_t* __restrict__ list) {
+                                                            uint32_t* __restrict__ list, int skip_plain_walks) {
     __shared__ uint32_t base[MAX_PLANS], before[MAX_PLANS];
     if (threadIdx.x < MAX_PLANS) before[threadIdx.x] = 0;
     __syncthreads();
@@ -467,7 +510,10 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_scatter(const uint8_t* __rest
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             const uint32_t r = r0 + u * blockDim.x;
-            if (r < hi) list[base[t[u]] + sl[u]] = r;
+            // (skip_plain_walks: a placement call -- k_route placed or listed the reads of the plain walk classes itself and
+            // gave them no slot)
+            const uint32_t cls = plan_class(t[u]);
+            if (r < hi && !(skip_plain_walks && (cls == PLAN_WALK8 || cls == PLAN_WALK16))) list[base[t[u]] + sl[u]] = r;
         }
     }
 }
@@ -534,9 +580,9 @@ hipError_t launch_walk_keys(const uint32_t* list, uint32_t n, const uint8_t* tie
 }
 
 hipError_t launch_scatter(const uint8_t* tier_of, const uint32_t* slot_in_blk, uint32_t n_reads, const uint32_t* blk_counts,
-                          uint32_t* tier_info, uint32_t* list, hipStream_t stream) {
+                          uint32_t* tier_info, uint32_t* list, bool skip_plain_walks, hipStream_t stream) {
     hipLaunchKernelGGL(k_scatter, dim3(ROUTE_BLOCKS), dim3(ROUTE_THREADS), 0, stream, tier_of, slot_in_blk, n_reads,
-                       blk_counts, tier_info, list);
+                       blk_counts, tier_info, list, skip_plain_walks ? 1 : 0);
     return hipGetLastError();
 }
 
