@@ -702,7 +702,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
     // walk plans (device_mat.hpp): the reads of one (class, stream) that walk their own events
     WalkPlans walkc[2]{};
     uint32_t walkc_off[2] = {0, 0};   // list offsets of the chunked walk plans
-    uint64_t walk_reads = (uint64_t)info[TI_WCUR] + info[TI_WCUR + 1] + info[TI_RESOLVED], n_jobs[2] = {0, 0};     // (the plain walk classes: placed by k_route itself or by the blind walks behind it)
+    uint64_t walk_reads = (uint64_t)info[TI_WCUR] + info[TI_WCUR + 1] + info[TI_RESOLVED] + info[TI_W16WAVE], n_jobs[2] = {0, 0};     // (the plain walk classes: placed by k_route itself or by the blind walks behind it)
     uint32_t walkc_reads[2] = {0, 0};
     uint32_t arena_n = 0, arena_off = 0, arena_maxk = 1;
     uint32_t seed_n = 0, seed_off = 0, seed_maxk = 1;

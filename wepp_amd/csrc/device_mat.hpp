@@ -401,12 +401,14 @@ constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI
                    TI_CCUR = TI_JCUR + 2,                    // [2] reads it entered into the chunked classes' lists
                    TI_JOVER = TI_CCUR + 2,                   // [2] != 0: the class outgrew its blind tables (or is large enough to be sorted): the host plans it
                    TI_WWCUR = TI_JOVER + 2,                  // [2] reads k_route listed for the walk without a walk (wave_kernels.hip): <= 64 events, more
-                   TI_WORDS = TI_WWCUR + 2;
+                   TI_W16WAVE = TI_WWCUR + 2,                // [1] plain walkers of 9 - 16 entries k_route listed for k_walk_wave instead (few of them in their block)
+                   TI_WORDS = TI_W16WAVE + 1;
 // the chunked walk classes sized blind: tables of this many jobs / reads per class; a class that outgrows them (N-rich
 // batches on the tree-wide streams: millions of jobs, which the planned path also sorts by position) is left to the host
 constexpr uint32_t BLIND_JOB_CAP = 1u << 20, BLIND_CHUNKED_READS = 32768;
 // a read with more than WALK_MAX_EVENTS and at most this many events is placed by a wave of its own, lane = list entry
 // (wave_kernels.hip); beyond, its walk is cut into jobs (the chunked classes).  A multiple of 64.
+constexpr uint32_t WALK16_TO_WAVE_MAX = 8;     // plain walkers of 9 - 16 entries per routing block up to which they go to k_walk_wave
 constexpr uint32_t WAVE_WALK_MAX_EVENTS = 256;
 
 }  // namespace wepp

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         }
         sid_tab[threadIdx.x] = (uint8_t)pick;
     }
-    __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2];
+    __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2], w16_to_wave[1];
     if (threadIdx.x < 2) { cj_count[threadIdx.x] = 0; cl_count[threadIdx.x] = 0; }
     if (threadIdx.x == 0) ww_count[0] = ww_count[1] = 0;
     if (threadIdx.x == 0) resolved_of[0] = 0;
@@ -386,7 +386,16 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
           __syncthreads();
           if (threadIdx.x < 2) {
               const uint32_t cc = threadIdx.x;
-              wl_base[cc] = wl_count[cc] ? atomicAdd(&tier_info[TI_WCUR + cc], wl_count[cc]) : 0u;
+              // a handful of plain walkers with 9 - 16 entries in the block (a sequencing run: one in a million reads): they
+              // join the reads with many events (a wave each, k_walk_wave) -- a launch of their own starts when the walks
+              // of the other class end, ~15 us at the end of every call, for a read or two
+              const bool to_wave = cc == 1 && direct.wwlist && wl_count[1] && wl_count[1] <= WALK16_TO_WAVE_MAX;
+              if (cc == 1) w16_to_wave[0] = to_wave ? 1u : 0u;
+              if (to_wave) {
+                  wl_base[1] = atomicAdd(&tier_info[TI_WWCUR], wl_count[1]);
+                  atomicAdd(&tier_info[TI_W16WAVE], wl_count[1]);
+              } else
+                  wl_base[cc] = wl_count[cc] ? atomicAdd(&tier_info[TI_WCUR + cc], wl_count[cc]) : 0u;
               wl_count[cc] = 0;
               // the chunked classes' job tables and lists: the block's ranges, or -- a table outgrown -- the class is
               // flagged and left to the host's planned launch (the blind kernels leave at once)
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
 #pragma unroll
           for (uint32_t u = 0; u < 4; u++) {
               const uint32_t r = r0 + u * blockDim.x;
-              if (app4[u]) (app4[u] == 1 ? direct.wlist[0] : direct.wlist[1])[wl_base[app4[u] - 1] + aslot4[u]] = r;     // (no indexing of the argument's arrays: that would copy them to scratch)
+              if (app4[u]) (app4[u] == 1 ? direct.wlist[0] : w16_to_wave[0] ? direct.wwlist : direct.wlist[1])[wl_base[app4[u] - 1] + aslot4[u]] = r;     // (no indexing of the argument's arrays: that would copy them to scratch)
               if (ww4[u]) {
                   const uint32_t big = ww4[u] & 1u, at = ww_base[big] + (ww4[u] >> 1) - 1u;
                   direct.wwlist[big ? n_reads - 1u - at : at] = r;
