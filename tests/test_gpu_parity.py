@@ -747,7 +747,7 @@ def test_pipeline_equals_unsplit_call(oracle):
     mat.close()
 
 
-def test_reads_with_many_events_vs_oracle(oracle):
+def test_reads_with_many_events_vs_oracle(oracle, monkeypatch):
     """Reads whose positions are mutated many times in their stream: 17 - 256 events go to the wave-per-read walk
     (wave_kernels.hip: lane = list entry, all-pairs instead of a walk), more to the walks cut into jobs.  A short genome
     makes every list long (60 K nodes over 1 500 positions: ~40 mutations per position); reads of 1 - 12 entries with
@@ -789,6 +789,16 @@ def test_reads_with_many_events_vs_oracle(oracle):
     for f in ("score", "best_bfs_j", "num_best", "flags"):
         assert (getattr(r0, f) == getattr(res, f)).all(), f
     mat.close()
+    # the same reads with their walks cut into jobs (what a handle does by itself after a call FULL of such reads), and
+    # with a few per routing block by waves and the rest by jobs
+    for small, big in (("0", "0"), ("3", "1")):
+        monkeypatch.setenv("WEPP_WW_BLOCK_MAX_SMALL", small)
+        monkeypatch.setenv("WEPP_WW_BLOCK_MAX_BIG", big)
+        m2 = w.Mat(g.tree)
+        r2 = m2.place_batch(reads)
+        for f in ("score", "best_bfs_j", "num_best", "flags"):
+            assert (getattr(r2, f) == getattr(res, f)).all(), (f, small, big)
+        m2.close()
 
 
 def test_host_pipeline_with_few_workers(oracle, monkeypatch):

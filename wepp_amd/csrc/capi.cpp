@@ -609,6 +609,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         }
         return e;
     };
+    const bool ww_jobs = mat->ww_by_jobs.load(std::memory_order_relaxed) != 0;     // (the reads with 17 - 256 events: a wave each, or jobs -- by the handle's previous call)
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
@@ -619,7 +620,8 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         // counters' trip to the host, the planning of the rarer classes and k_scatter are off their path
         RouteDirect direct{};
         if (walking) direct = RouteDirect{{wlist[0], wlist[1]}, {b_clist[0], b_clist[1]}, {b_jobs[0], b_jobs[1]}, b_first, wwlist,
-                                          d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work};
+                                          d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work,
+                                          tun.ww_fixed ? tun.ww_block_max_small : ww_jobs ? 0u : 0xFFFFFFFFu, tun.ww_fixed ? tun.ww_block_max_big : ww_jobs ? 0u : 0xFFFFFFFFu};
         HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, walking ? walk_max_events : 0u, job_events, stack8, stack16, seed_min_hard, tun.seed_min_nodes, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, wsid, direct, stream));
         L.info_idx ^= 1u;
@@ -684,6 +686,11 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         mat->job_events[cc] = je <= WALK_JOB_EVENTS ? je : ((je + 15u) & ~15u);       // (what the NEXT call's k_route cuts this class's walks into)
     }
 
+    // the reads with 17 - 256 events of the NEXT call: a wave per 64 events each while they are few (scaled to the call's size)
+    {
+        const uint64_t scale = std::max<uint64_t>(1, ((uint64_t)n_reads + (1u << 20) - 1) >> 20);
+        mat->ww_by_jobs.store((info[TI_WWCAND] > WW_CALL_MAX_SMALL * scale || info[TI_WWCAND + 1] > WW_CALL_MAX_BIG * scale) ? 1u : 0u, std::memory_order_relaxed);
+    }
     const bool blind_walks = mat->use_walk && walk_max_events;       // (launched behind k_route, joined below)
     bool late16[2] = {false, false};
     if (blind_walks) {

@@ -270,6 +270,7 @@ struct RouteDirect {
     uint32_t* num_best;
     uint32_t* flags;
     unsigned long long* work_counter;
+    uint32_t ww_max_small, ww_max_big;   // reads per routing block and round listed for k_walk_wave (<= 64 events / more): all or none (capi.cpp), WEPP_WW_BLOCK_MAX_*
 };
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,
                         int use_crowns, uint32_t walk_max_events, uint32_t job_events, uint32_t stack8, uint32_t stack16,
@@ -402,7 +403,8 @@ constexpr uint32_t TI_COUNT = 0, TI_MAXK = MAX_PLANS, TI_OFF = 2 * MAX_PLANS, TI
                    TI_JOVER = TI_CCUR + 2,                   // [2] != 0: the class outgrew its blind tables (or is large enough to be sorted): the host plans it
                    TI_WWCUR = TI_JOVER + 2,                  // [2] reads k_route listed for the walk without a walk (wave_kernels.hip): <= 64 events, more
                    TI_W16WAVE = TI_WWCUR + 2,                // [1] plain walkers of 9 - 16 entries k_route listed for k_walk_wave instead (few of them in their block)
-                   TI_WORDS = TI_W16WAVE + 1;
+                   TI_WWCAND = TI_W16WAVE + 1,               // [2] reads with 17 .. 64 / 65 .. 256 events in this call, whichever way they were placed
+                   TI_WORDS = TI_WWCAND + 2;
 // the chunked walk classes sized blind: tables of this many jobs / reads per class; a class that outgrows them (N-rich
 // batches on the tree-wide streams: millions of jobs, which the planned path also sorts by position) is left to the host
 constexpr uint32_t BLIND_JOB_CAP = 1u << 20, BLIND_CHUNKED_READS = 32768;
@@ -410,5 +412,6 @@ constexpr uint32_t BLIND_JOB_CAP = 1u << 20, BLIND_CHUNKED_READS = 32768;
 // (wave_kernels.hip); beyond, its walk is cut into jobs (the chunked classes).  A multiple of 64.
 constexpr uint32_t WALK16_TO_WAVE_MAX = 8;     // plain walkers of 9 - 16 entries per routing block up to which they go to k_walk_wave
 constexpr uint32_t WAVE_WALK_MAX_EVENTS = 256;
+constexpr uint32_t WW_CALL_MAX_SMALL = 16384, WW_CALL_MAX_BIG = 2048;     // reads with 17 .. 64 / 65 .. 256 events in a call of a million up to which the NEXT call gives them to k_walk_wave; beyond, their walks are cut into jobs
 
 }  // namespace wepp

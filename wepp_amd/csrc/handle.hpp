@@ -103,6 +103,7 @@ struct wepp_mat {
     PlaceLane lane[2];
     static constexpr uint32_t kRing = 64;
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    std::atomic<uint32_t> ww_by_jobs{0};  // the previous call held too many reads with 17 - 256 events for a wave each: this call cuts their walks into jobs (a hint, like job_events)
     std::atomic<uint64_t> n_timed{0}; // placement calls since the last timing reset (a call claims its slot of the event ring when it starts)
     std::mutex stat_mu;               // the counters below: the sub-batches of a pipelined wepp_place_batch finish on two host threads
     uint64_t plan_reads_in = 0;       // reads of the sub-batches of the current call that have been planned

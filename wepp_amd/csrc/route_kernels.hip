@@ -87,9 +87,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
         }
         sid_tab[threadIdx.x] = (uint8_t)pick;
     }
-    __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2], w16_to_wave[1];
+    __shared__ uint32_t wl_count[2], wl_base[2], cj_count[2], cl_count[2], cj_base[2], cl_base[2], c_ok[2], ww_count[2], ww_base[2], w16_to_wave[1], ww_cand[2];
     if (threadIdx.x < 2) { cj_count[threadIdx.x] = 0; cl_count[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) ww_count[0] = ww_count[1] = 0;
+    if (threadIdx.x == 0) ww_count[0] = ww_count[1] = ww_cand[0] = ww_cand[1] = 0;
     if (threadIdx.x == 0) resolved_of[0] = 0;
     if (threadIdx.x < 2) wl_count[threadIdx.x] = 0;
     // the counters of the NEXT call (the handle alternates between two sets) are cleared here: no memset
@@ -289,18 +289,27 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             } else if (cls == PLAN_WALKC8 || cls == PLAN_WALKC16) {
                 const uint32_t small = cls == PLAN_WALKC8 ? 1u : 0u;
                 if (t != WC_SLOT) wsid[r] = m.tw_base + t;
+                // many events, but few enough for a wave per 64 of them to hold them all (lane = list entry, wave_kernels.hip):
+                // no jobs; the read keeps its chunked class in the diagnostics.  (<= 64: a wave of its own, listed from the
+                // front; more: the four waves of a block, listed from the back.)  Up to direct.ww_max_* of them per routing
+                // block and round -- all or none in practice: the all-pairs pass is the cheaper way for the one read in a
+                // thousand of a sequencing run, the jobs for a batch FULL of such reads (a star-like tree: 29 000 of a
+                // million -- 0.60 ms a step by waves, 0.36 by jobs), and a call that needs both pays for both; the host
+                // picks from the counts of the handle's previous call (capi.cpp)
+                bool by_wave = false;
                 if (direct.wwlist && events <= WAVE_WALK_MAX_EVENTS) {
-                    // many events, but few enough for ONE wave to hold them all (lane = list entry, wave_kernels.hip):
-                    // no jobs; the read keeps its chunked class in the diagnostics
-                    job_n[r] = 0;
-                    // (<= 64: a wave of its own, listed from the front; more: the four waves of a block, listed from the back)
                     const uint32_t big = events > 64u ? 1u : 0u;
-                    ww4[u] = ((atomicAdd(&ww_count[big], 1u) + 1u) << 1) | big;
-                    nj = 0;
-                    events = 0;
-                } else {
-                    job_n[r] = nj;
+                    atomicAdd(&ww_cand[big], 1u);          // (how many there are, whichever way they go: the host's hint for the next call)
+                    const uint32_t slot = atomicAdd(&ww_count[big], 1u);          // (the reservation clamps the count)
+                    if (slot < (big ? direct.ww_max_big : direct.ww_max_small)) {
+                        by_wave = true;
+                        job_n[r] = 0;
+                        ww4[u] = ((slot + 1u) << 1) | big;
+                        nj = 0;
+                        events = 0;
+                    }
                 }
+                if (!by_wave) job_n[r] = nj;
                 if (nj && direct.jobs[0]) {      // (few reads: an LDS atomic each)
                     cj4[u] = small ? 1u : 2u;
                     cnj4[u] = nj;
@@ -410,7 +419,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
               cl_count[cc] = 0;
               if (cc == 0) {
                   for (uint32_t b = 0; b < 2; b++) {
-                      ww_base[b] = ww_count[b] ? atomicAdd(&tier_info[TI_WWCUR + b], ww_count[b]) : 0u;
+                      const uint32_t n = min(ww_count[b], b ? direct.ww_max_big : direct.ww_max_small);
+                      ww_base[b] = n ? atomicAdd(&tier_info[TI_WWCUR + b], n) : 0u;
                       ww_count[b] = 0;
                   }
               }
@@ -447,6 +457,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
     if (threadIdx.x < 2 * MAX_STREAMS && jobs_of[threadIdx.x]) atomicAdd(&tier_info[TI_JOBS + threadIdx.x], jobs_of[threadIdx.x]);
     if (threadIdx.x < 4 && open_of[threadIdx.x]) atomicMax(&tier_info[TI_OPEN + threadIdx.x], open_of[threadIdx.x]);
     if (threadIdx.x < 2 && events_of[threadIdx.x]) atomicAdd(&tier_info[TI_EVENTS + threadIdx.x], (events_of[threadIdx.x] + 63) >> 6);
+    if (threadIdx.x < 2 && ww_cand[threadIdx.x]) atomicAdd(&tier_info[TI_WWCAND + threadIdx.x], ww_cand[threadIdx.x]);
     if (threadIdx.x == 0 && resolved_of[0]) {
         atomicAdd(&tier_info[TI_RESOLVED], resolved_of[0]);
         // what a resolved read asked memory for: its offsets and words, a list head per entry, the aggregate, the result

@@ -21,6 +21,8 @@ struct PlaceTunables {
     uint32_t job_events = 0;             // WEPP_WALK_JOB_EVENTS (0: follow the handle's traffic)
     uint32_t stack8 = WALK8_ROWS;        // WEPP_WALK_STACK8  (<= WALK8_STACK: the rows a walk workgroup can get)
     uint32_t stack16 = WALK16_ROWS;      // WEPP_WALK_STACK16 (<= WALK16_STACK)
+    bool ww_fixed = false;               // WEPP_WW_BLOCK_MAX_SMALL / _BIG given: reads per routing block listed for k_walk_wave (default: all or none, by the previous call's counts)
+    uint32_t ww_block_max_small = 0xFFFFFFFFu, ww_block_max_big = 0xFFFFFFFFu;
     bool sort_reads = true;              // WEPP_SORT_READS=0: keep the caller's order on the whole-tree stream
     bool walk_sort = true;               // WEPP_WALK_SORT=0: keep the caller's order in the chunked walk classes
     bool walk_sort_plain = false;        // WEPP_WALK_SORT_PLAIN=1: sort the plain walk classes too
@@ -52,6 +54,9 @@ struct PlaceTunables {
         // a knob above the rows the walk kernels allocate would let a lane write past its wave's LDS region
         t.stack8 = (uint32_t)env::u64("WEPP_WALK_STACK8", WALK8_ROWS, 0, WALK8_STACK);
         t.stack16 = (uint32_t)env::u64("WEPP_WALK_STACK16", WALK16_ROWS, 0, WALK16_STACK);
+        t.ww_fixed = env::is_set("WEPP_WW_BLOCK_MAX_SMALL") || env::is_set("WEPP_WW_BLOCK_MAX_BIG");
+        t.ww_block_max_small = (uint32_t)env::u64("WEPP_WW_BLOCK_MAX_SMALL", 0xFFFFFFFFu, 0, 0xFFFFFFFFu);
+        t.ww_block_max_big = (uint32_t)env::u64("WEPP_WW_BLOCK_MAX_BIG", 0xFFFFFFFFu, 0, 0xFFFFFFFFu);
         t.sort_reads = env::flag("WEPP_SORT_READS", true);
         t.walk_sort = t.sort_reads && env::flag("WEPP_WALK_SORT", true);
         t.walk_sort_plain = env::is_set("WEPP_WALK_SORT_PLAIN") && env::flag("WEPP_WALK_SORT_PLAIN", false);
