@@ -7,7 +7,8 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["r3_bench_default.json", "r3_bench_config3_shard.json", "r3_bench_long_reads.json", "r3_bench_whole_tree.json"]
+LINES = ["r4_bench_default.json", "r4_bench_config3_shard.json", "r4_bench_long_reads.json", "r4_bench_genome_samples.json",
+         "r3_bench_default.json", "r3_bench_whole_tree.json"]
 
 
 @pytest.mark.parametrize("name", LINES)
@@ -41,6 +42,24 @@ def test_committed_bench_line_has_the_contract_shape(name):
         assert any(e["kernel_hash"] == d["config"]["kernel_hash"] for e in pmc.values())
 
 
+def test_default_line_carries_the_legs_and_the_ladder():
+    """the other configs as legs of the default run, each with its own contract-shaped roofline and a
+    sample checked against the oracle; the tree-shape ladder with every sample checked."""
+    with open(os.path.join(ROOT, "profiles", "r4_bench_default.json")) as fh:
+        d = json.load(fh)
+    legs = d["legs"]
+    assert len(legs) == 3
+    for leg in legs:
+        assert leg["sample_matches_gpu"] is True and leg["reads_per_s"] > 0 and leg["pcie_inclusive_reads_per_s"] > 0
+        r = leg["roofline"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["traffic"] is not None
+    trees = d["tree_ladder"]["trees"]
+    assert len(trees) >= 6
+    for t in trees:
+        assert t["default_batch"]["sample_matches_gpu"] is True and t["long_reads"]["sample_matches_gpu"] is True
+    assert d["roofline"]["traffic"] is not None and d["value_pcie_inclusive"] > 0
+
+
 def test_bench_defaults_to_one_gpu_and_a_short_run():
     import importlib.util
     import sys
@@ -57,5 +76,5 @@ def test_bench_defaults_to_one_gpu_and_a_short_run():
     # on -- kernel hash inside -- and prints null otherwise: a stale table is not an error, just not evidence)
     with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as fh:
         pmc = json.load(fh)
-    assert {"short_reads:1000000", "whole_tree:1000000", "long_reads:200000"} <= set(pmc)
+    assert {"short_reads:1000000", "short_reads:1250000", "whole_tree:1000000", "long_reads:125000", "genome_samples:20000"} <= set(pmc)
     assert all(len(e["kernel_hash"]) == len(bench.kernel_hash()) for e in pmc.values())
