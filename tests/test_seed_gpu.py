@@ -81,6 +81,45 @@ def test_samples_that_rule_nothing_out(oracle):
     mat.close()
 
 
+def test_second_pass_for_samples_with_many_chunks_left(oracle, monkeypatch):
+    """A sample far from every node faces levels of hundreds of chunks that can all tie: from a level of 256 chunks on
+    it is handed to the second pass (32 workgroups per sample, the bound shared, partials combined).  One block per
+    chunk makes a 120 K-node tree 1 900 chunks; the same samples with the second pass off and against the checker."""
+    monkeypatch.setenv("WEPP_SEED_CHUNK_BLOCKS", "1")
+    L = 29903
+    g = w.generate_tree(33, 120000)
+    rng = np.random.default_rng(6)
+    samples = []
+    for i in range(300):                       # (more than the second pass's table holds: the overflow stays with the first)
+        k = int(rng.integers(25, 70))
+        pos = np.sort(rng.choice(np.arange(1, L + 1), size=k, replace=False))
+        ents = []
+        for p in pos:
+            ref = 1 << int(rng.integers(0, 4))
+            if rng.random() < 0.2:
+                ents.append((int(p), ref, 15, 1))
+            else:
+                a = 1 << int(rng.integers(0, 4))
+                ents.append((int(p), ref, a if a != ref else (ref << 1 if ref < 8 else 1), 0))
+        samples.append(ents)
+    reads = w.Reads.from_lists(samples)
+    mat = w.Mat(g.tree)
+    assert mat.stats.seed_chunks > 1500
+    res = mat.place_batch(reads)
+    cls, _ = mat.last_plans(reads.n_reads)
+    assert (cls == PLAN_SEED).sum() >= 250
+    _, evaluated, _ = mat.last_seeds()
+    assert evaluated > 256 * 100                # (they do face such levels)
+    assert_same(res, oracle.IncrementalTree(oracle.OracleTree(g.tree)).place_batch(reads, nthreads=8), "second pass vs the checker")
+    res2 = mat.place_batch(reads)               # (the table is cleared between calls)
+    assert_same(res2, _as_dict(res), "second call")
+    mat.close()
+    monkeypatch.setenv("WEPP_SEED_HEAVY", "0")
+    m1 = w.Mat(g.tree)
+    assert_same(m1.place_batch(reads), _as_dict(res), "one pass")
+    m1.close()
+
+
 @pytest.mark.parametrize("blocks", [1, 3])
 def test_fuzz_trees_through_the_seed_kernel(oracle, monkeypatch, blocks):
     """Every read of the adversarial fuzz (masked nodes, multi-allelic alleles, repeated positions, back-mutations,

@@ -47,6 +47,7 @@ void release(wepp_mat* h) {
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->epp_ws) (void)hipFree(h->epp_ws);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_seed_heavy) (void)hipFree(h->d_seed_heavy);
     for (uint32_t i = 0; i < wepp_mat::kRing; i++) {
         if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
         if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
@@ -377,6 +378,10 @@ int upload_flat(const FlatMAT& f, int device, wepp_mat_t** out) {
     }
     if (e == hipSuccess) e = sweep_set_max_lds(160 * 1024);
     if (e == hipSuccess) e = seed_set_max_lds(160 * 1024);
+    if (e == hipSuccess && h->dev.seed_chunks) {
+        e = hipMalloc(&h->d_seed_heavy, seed_heavy_bytes());
+        if (e == hipSuccess) e = hipMemset(h->d_seed_heavy, 0, seed_heavy_bytes());
+    }
     if (e != hipSuccess) { release(h); return hip_fail(e, "handle setup"); }
     *out = h;
     return WEPP_OK;
@@ -1060,7 +1065,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         if (fork) HIP_TRY(hipStreamWaitEvent(q, L.fork_ev, 0));
         if (debug_plans) fprintf(stderr, "[plan] seed count=%u maxk=%u chunks=%u lds=%u\n", seed_n, seed_maxk, mat->dev.seed_chunks, seed_lds_bytes(mat->dev, cap));
         HIP_TRY(launch_seed(mat->dev, mat->streams.back(), list + seed_off, seed_n, cap, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score,
-                            d_num_best, d_flags, mat->d_work, q));
+                            d_num_best, d_flags, mat->d_work, tun.seed_heavy ? mat->d_seed_heavy : nullptr, q));
         if (fork) {
             HIP_TRY(hipEventRecord(L.join_ev[OTHER_SIDE_STREAMS - 2], q));
             bool listed = false;

@@ -123,6 +123,7 @@ constexpr uint32_t SEED_MAX_ENTRIES = 4096;         // entries of a seeded sampl
 #define WEPP_SEED_THREADS 512
 #endif
 constexpr uint32_t SEED_THREADS = WEPP_SEED_THREADS;   // one workgroup per sample (256 / 512 / 1024: 8.7 / 5.6 / 6.3 ms per 20 000 samples of ~67 entries at 16 M nodes)
+constexpr uint32_t SEED_HEAVY_LEVEL_MIN = 256, SEED_HEAVY_PARTS = 32, SEED_HEAVY_CAP = 128;   // second pass of k_seed: a level of that many chunks hands the sample over; workgroups per such sample; samples per call
 constexpr uint32_t SEED_MAX_HARD = 255;             // hard entries counted per chunk (byte counters; a subset is a valid bound)
 // PLAN_WIN: a read with more entries than a walk takes, all inside one genome window, sweeps that window's
 // stream (the whole tree reduced to the nodes that mutate the window + pseudo-nodes) instead of the whole tree.
@@ -283,10 +284,11 @@ hipError_t launch_rebase_index(IxHead* heads, uint32_t n_heads, IxEnt* ents, uin
 // the seeded samples of one call: a workgroup per sample writes its final results (seed_kernels.hip)
 uint32_t seed_lds_bytes(const DevMAT& m, uint32_t ent_cap);
 hipError_t seed_set_max_lds(uint32_t bytes);
+size_t seed_heavy_bytes();      // the second pass's table (handle.hpp: d_seed_heavy)
 hipError_t launch_seed(const DevMAT& m, const DevStream& full, const uint32_t* list, uint32_t n_list, uint32_t ent_cap,
                        const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score,
                        uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags,
-                       unsigned long long* work_counter, hipStream_t stream);
+                       unsigned long long* work_counter, void* heavy_table, hipStream_t stream);
 // order of the reads that sweep the whole-tree stream: by first listed position (sort_reads.hip)
 constexpr uint32_t SORT_KEY_BITS = 21;      // position + 1 (0 = the read lists nothing)
 constexpr uint32_t SORT_MIN_READS = 4096;   // below this a sweep costs less than the sort

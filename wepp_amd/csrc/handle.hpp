@@ -52,6 +52,7 @@ struct wepp_mat {
     int use_seeds = 1;                // whole-genome samples go by chunk signatures (WEPP_SEED=0: tile sweeps)
     std::atomic<uint32_t> job_events[2] = {{WALK_JOB_EVENTS}, {WALK_JOB_EVENTS}};   // events per job of the chunked classes in the next call (a hint: the two launch threads of a pipelined call read and write it freely)
     int walk_ok = 1;                  // 0: a stream is too large for the walk's packed interval stack (sweeps only)
+    void* d_seed_heavy = nullptr;     // k_seed's table of samples handed to its second pass (seed_kernels.hip), zero between calls
     unsigned long long* d_work = nullptr;   // [WALK_COUNTERS] loop iterations of the walks, [WALK_COUNTERS] bytes the walks / seeds asked memory for,
                                             // [D_WORK_EXTRA] seeded samples, chunks they evaluated, chunks in all, most per sample, histogram -- since the last timing reset
     static constexpr uint32_t D_WORK_EXTRA = 16;

@@ -47,12 +47,26 @@ constexpr uint32_t SEED_HIT_CAP = 96;                         // hit events of a
 __host__ __device__ inline uint32_t seed_h_words(uint32_t chunks) { return ((chunks + 63) & ~63u) / 4; }
 }  // namespace
 
+// A sample that still faces a level of SEED_HEAVY_LEVEL_MIN chunks or more (it sits far from every node of the tree: its
+// best score hardly beats the levels' bounds, thousands of chunks can tie) is handed over with what it has found so far
+// (SeedHeavy: a record in global memory): HEAVY = the second pass, SEED_HEAVY_PARTS workgroups per such sample, each
+// taking every SEED_HEAVY_PARTS-th slab of 64 chunks of the remaining levels, the best score shared through the
+// record; k_seed_heavy_finalize combines their partials.  (One workgroup took 8.8 ms for a sample with 7 013 chunks to
+// evaluate: the tail of a 13 ms step of 20 000 samples.)
+struct SeedHeavy {
+    uint32_t count;                                   // deferred samples (k_seed appends, the finalize kernel clears)
+    uint32_t pad[3];
+    struct Rec { uint32_t read; int level; int best; int score; uint32_t rank, cnt; } rec[SEED_HEAVY_CAP];   // (score, rank, cnt): what the first pass found; best: the bound the parts share (atomicMin)
+    struct Part { int score; uint32_t rank, cnt; } part[SEED_HEAVY_CAP * SEED_HEAVY_PARTS];
+};
+
+template <bool HEAVY>
 __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full, const uint32_t* __restrict__ list, uint32_t n_list,
                                                         uint32_t ent_cap, const uint32_t* __restrict__ read_off,
                                                         const uint32_t* __restrict__ read_word, const int32_t* __restrict__ root_score,
                                                         uint32_t* __restrict__ best_bfs_j, int32_t* __restrict__ score_out,
                                                         uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags,
-                                                        unsigned long long* __restrict__ work_counter) {
+                                                        unsigned long long* __restrict__ work_counter, SeedHeavy* __restrict__ heavy) {
     extern __shared__ uint32_t lds[];
     uint32_t* bitmap = lds;
     uint32_t* S = bitmap + m.bm_words;
@@ -66,7 +80,10 @@ __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full,
     // is entered with, [8 + 3 w ..] partial of wave w
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t r = list[blockIdx.x];
+    // HEAVY: workgroup = (deferred sample, part); the grid is sized for the record table, the count is on the device
+    const uint32_t hv_i = HEAVY ? blockIdx.x / SEED_HEAVY_PARTS : 0u, hv_p = HEAVY ? blockIdx.x % SEED_HEAVY_PARTS : 0u;
+    if (HEAVY && hv_i >= min(heavy->count, SEED_HEAVY_CAP)) return;
+    const uint32_t r = HEAVY ? heavy->rec[hv_i].read : list[blockIdx.x];
     const uint32_t so = read_off[r];
     const uint32_t k = min(read_off[r + 1] - so, ent_cap);
     const uint32_t bm_mask = m.bm_words - 1;
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full,
     for (uint32_t i = tid; i < m.bm_words; i += SEED_THREADS) bitmap[i] = 0;
     if (tid < SEED_SHARED_WORDS) sh[tid] = 0;
     __syncthreads();
-    if (tid == 0) sh[0] = root_score[r] + 1;        // the root always competes: nothing worse can win or tie
+    if (tid == 0) sh[0] = HEAVY ? heavy->rec[hv_i].best : root_score[r] + 1;        // the root always competes: nothing worse can win or tie
     // ---- (1) the sample ----
     for (uint32_t j = tid; j < k; j += SEED_THREADS) {
         const uint32_t w = read_word[so + j];
@@ -138,9 +155,23 @@ __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full,
     }
     __syncthreads();
     const int hmax = sh[4];
+    // chunks per level (first pass: a level of SEED_HEAVY_LEVEL_MIN chunks or more is where a sample is handed over)
+    uint32_t* lvl = hitbuf;                  // [256] (the waves' hit lists are not in use yet)
+    if (!HEAVY && heavy) {
+        for (uint32_t i = tid; i < 256; i += SEED_THREADS) lvl[i] = 0;
+        __syncthreads();
+        for (uint32_t c = tid; c < nch; c += SEED_THREADS) atomicAdd(&lvl[H[c]], 1u);
+        __syncthreads();
+    }
+    // (level -> count, read by every thread before the hit lists overwrite the table)
+    int defer_level = -1;
+    if (!HEAVY && heavy)
+        for (int h = hmax; h >= 0; h--)
+            if (lvl[h] >= SEED_HEAVY_LEVEL_MIN) { defer_level = h; break; }
+    __syncthreads();
 
     // ---- exact evaluation of one chunk by one wave ----
-    int bs = root_score[r] + 1;
+    int bs = HEAVY ? heavy->rec[hv_i].best : root_score[r] + 1;
     uint32_t br = 0xFFFFFFFFu, cnt = 0;
     uint32_t wbytes = 0, wchunks = 0;
     uint32_t* hits = hitbuf + wv * (3 * SEED_HIT_CAP);    // this wave's hit list: event index, tree word, sample word
@@ -334,17 +365,28 @@ __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full,
             }
         }
         wchunks++;
-        if (lane == 0) atomicMin(&sh[0], bs);
+        if (lane == 0) { atomicMin(&sh[0], bs); if (HEAVY) atomicMin(&heavy->rec[hv_i].best, bs); }
     };
 
     // ---- (3) + (4) best first: the chunks with the largest count, then level by level while the level's bound
     // |T| - h can still reach the best score found so far; the waves share a level's chunks in slabs of 64 ----
-    for (int h = hmax; h >= 0; h--) {
+    bool deferred = false;
+    for (int h = HEAVY ? min(hmax, heavy->rec[hv_i].level) : hmax; h >= 0; h--) {
         __syncthreads();
-        if (tid == 0) sh[6] = sh[0];
+        if (tid == 0) sh[6] = HEAVY ? min(sh[0], *reinterpret_cast<volatile int*>(&heavy->rec[hv_i].best)) : sh[0];
         __syncthreads();
         if (sT - h > sh[6]) break;                     // (the same value in every wave: the barriers above order it)
-        for (uint32_t s0 = wv * 64; s0 < nch; s0 += 64 * SEED_WAVES) {
+        if (!HEAVY && h == defer_level) {
+            // this level and the ones below go to the second pass -- if its table has a record left
+            if (tid == 0) {
+                const uint32_t slot = atomicAdd(&heavy->count, 1u);
+                sh[7] = slot < SEED_HEAVY_CAP ? (int)slot + 1 : 0;
+            }
+            __syncthreads();
+            if (sh[7]) { deferred = true; break; }
+            defer_level = -1;
+        }
+        for (uint32_t s0 = (hv_p * SEED_WAVES + wv) * 64; s0 < nch; s0 += 64 * SEED_WAVES * (HEAVY ? SEED_HEAVY_PARTS : 1u)) {
             const uint32_t c = s0 + lane;
             unsigned long long live = __ballot(c < nch && (int)H[min(c, nch - 1)] == h);
             while (live) {
@@ -376,8 +418,11 @@ __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full,
             if (ps < fs) { fs = ps; fr = pr; fc = pc; }
             else if (ps == fs) { fc += pc; fr = min(fr, pr); }
         }
-        emit_result(m, r, read_off, read_word, fs, fr, fc, best_bfs_j, score_out, num_best, flags);
-        if (work_counter) {
+        if (HEAVY) heavy->part[hv_i * SEED_HEAVY_PARTS + hv_p] = SeedHeavy::Part{fs, fr, fc};
+        else if (deferred) heavy->rec[sh[7] - 1] = SeedHeavy::Rec{r, defer_level, fc ? min(fs, root_score[r] + 1) : root_score[r] + 1, fs, fr, fc};
+        else emit_result(m, r, read_off, read_word, fs, fr, fc, best_bfs_j, score_out, num_best, flags);
+        if (work_counter && HEAVY) atomicAdd(work_counter + 2 * WALK_COUNTERS + 1, (unsigned long long)(uint32_t)sh[5]);
+        if (work_counter && !HEAVY) {
             // behind the walks' two counter arrays: seeded samples, chunks evaluated, chunks in all, the most chunks one
             // sample evaluated, and samples by chunks evaluated (<= 1, <= 4, <= 16, <= 64, <= 256, <= 1024, <= 4096, more)
             unsigned long long* sc = work_counter + 2 * WALK_COUNTERS;
@@ -393,9 +438,34 @@ __global__ __launch_bounds__(SEED_THREADS) void k_seed(DevMAT m, DevStream full,
     }
 }
 
-hipError_t seed_set_max_lds(uint32_t bytes) {
-    return hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+// the deferred samples' result = what the first pass found + the parts of the second; clears the table for the next call
+__global__ void k_seed_heavy_finalize(DevMAT m, SeedHeavy* __restrict__ heavy, const uint32_t* __restrict__ read_off,
+                                      const uint32_t* __restrict__ read_word, uint32_t* __restrict__ best_bfs_j,
+                                      int32_t* __restrict__ score_out, uint32_t* __restrict__ num_best, uint32_t* __restrict__ flags) {
+    const uint32_t n = min(heavy->count, SEED_HEAVY_CAP);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const SeedHeavy::Rec rc = heavy->rec[i];
+        int fs = rc.cnt ? rc.score : 0x7FFFFFFF;
+        uint32_t fr = rc.cnt ? rc.rank : 0xFFFFFFFFu, fc = rc.cnt;
+        for (uint32_t p = 0; p < SEED_HEAVY_PARTS; p++) {
+            const SeedHeavy::Part pt = heavy->part[i * SEED_HEAVY_PARTS + p];
+            if (!pt.cnt) continue;
+            if (pt.score < fs) { fs = pt.score; fr = pt.rank; fc = pt.cnt; }
+            else if (pt.score == fs) { fc += pt.cnt; fr = min(fr, pt.rank); }
+        }
+        emit_result(m, rc.read, read_off, read_word, fs, fr, fc, best_bfs_j, score_out, num_best, flags);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) heavy->count = 0;
 }
+
+hipError_t seed_set_max_lds(uint32_t bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_seed<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_seed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+size_t seed_heavy_bytes() { return sizeof(SeedHeavy); }
 
 uint32_t seed_lds_bytes(const DevMAT& m, uint32_t ent_cap) {
     return (m.bm_words + ent_cap + (SEED_MAX_HARD + 1) + seed_h_words(m.seed_chunks) + SEED_SHARED_WORDS + SEED_WAVES * 3 * SEED_HIT_CAP) * 4;
@@ -404,10 +474,17 @@ uint32_t seed_lds_bytes(const DevMAT& m, uint32_t ent_cap) {
 hipError_t launch_seed(const DevMAT& m, const DevStream& full, const uint32_t* list, uint32_t n_list, uint32_t ent_cap,
                        const uint32_t* d_read_off, const uint32_t* d_read_word, const int32_t* root_score,
                        uint32_t* best_bfs_j, int32_t* score, uint32_t* num_best, uint32_t* flags,
-                       unsigned long long* work_counter, hipStream_t stream) {
+                       unsigned long long* work_counter, void* heavy_table, hipStream_t stream) {
     if (n_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_seed, dim3(n_list), dim3(SEED_THREADS), seed_lds_bytes(m, ent_cap), stream, m, full, list, n_list, ent_cap,
-                       d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter);
+    SeedHeavy* heavy = static_cast<SeedHeavy*>(heavy_table);       // (zeroed at creation, cleared by the finalize kernel; nullptr: one pass)
+    hipLaunchKernelGGL(k_seed<false>, dim3(n_list), dim3(SEED_THREADS), seed_lds_bytes(m, ent_cap), stream, m, full, list, n_list, ent_cap,
+                       d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, heavy);
+    if (heavy) {
+        // sized for the whole table: the number of deferred samples stays on the device (workgroups beyond it leave at once)
+        hipLaunchKernelGGL(k_seed<true>, dim3(SEED_HEAVY_CAP * SEED_HEAVY_PARTS), dim3(SEED_THREADS), seed_lds_bytes(m, ent_cap), stream, m, full,
+                           list, n_list, ent_cap, d_read_off, d_read_word, root_score, best_bfs_j, score, num_best, flags, work_counter, heavy);
+        hipLaunchKernelGGL(k_seed_heavy_finalize, dim3(1), dim3(256), 0, stream, m, heavy, d_read_off, d_read_word, best_bfs_j, score, num_best, flags);
+    }
     return hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ struct PlaceTunables {
     bool windows_unfused = false;        // WEPP_WINDOWS_UNFUSED=1: one launch per window plan, chunks sized per plan (round 3's form; results identical)
     // seeds: whole-genome samples
     bool seed = true;                    // WEPP_SEED=0: whole-genome samples take the tile sweeps
+    bool seed_heavy = true;              // WEPP_SEED_HEAVY=0: no second pass (a sample's workgroup evaluates every chunk it must itself)
     uint32_t seed_min_hard = SEED_MIN_HARD;          // WEPP_SEED_MIN_HARD
     uint32_t seed_min_nodes = SEED_MIN_STREAM_NODES; // WEPP_SEED_MIN_NODES
     // host pipeline of wepp_place_batch
@@ -68,6 +69,7 @@ struct PlaceTunables {
         t.blind16 = env::flag("WEPP_BLIND16", false);
         t.windows_unfused = env::is_set("WEPP_WINDOWS_UNFUSED") && env::flag("WEPP_WINDOWS_UNFUSED", false);
         t.seed = env::flag("WEPP_SEED", true);
+        t.seed_heavy = env::flag("WEPP_SEED_HEAVY", true);
         t.seed_min_hard = (uint32_t)env::u64("WEPP_SEED_MIN_HARD", SEED_MIN_HARD, 0, 0xFFFFu);
         t.seed_min_nodes = (uint32_t)env::u64("WEPP_SEED_MIN_NODES", SEED_MIN_STREAM_NODES, 0, 0xFFFFFFFFu);
         t.pipe_sub_batches = (uint32_t)env::u64("WEPP_PIPE_SUBBATCHES", 0, 1, 8);
