@@ -43,6 +43,11 @@ def _worker(rank, world, port, out_path):
     before = w.flatten_count()
     flat = shared_flat_image(g.tree, dist, rank, f"test_{port}", directory=os.path.dirname(out_path))
     assert w.flatten_count() - before == (1 if rank == 0 else 0)
+    # no room (here: no such directory) for the image: every rank flattens for itself, nobody waits for a file
+    before = w.flatten_count()
+    own = shared_flat_image(g.tree, dist, rank, f"test_{port}", directory=os.path.join(os.path.dirname(out_path), "missing", "dir"))
+    assert w.flatten_count() - before == 1
+    own.close()
     fm = sm.FlatModel(flat)
 
     class Local:

@@ -27,14 +27,26 @@ def shared_flat_image(tree, dist=None, local_rank=0, tag="0", directory="/dev/sh
         return FlatView(tree)
     path = os.path.join(directory, f"wepp_flat_{tag}.bin")
     flat = None
+    ok = [True]
     if local_rank == 0:
         flat = FlatView(tree)
-        flat.save(path)
-    dist.barrier()
+        try:
+            flat.save(path)
+        except Exception:          # (no room in `directory`: every rank flattens for itself, as before)
+            ok[0] = False
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    # (a node's ranks agree on how they get the image; with several nodes the flag is the job's: one node short of
+    # space sends every rank to its own flatten)
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, ok[0])
+    shared = all(flags)
     if local_rank != 0:
-        flat = FlatView.load(path)
+        flat = FlatView.load(path) if shared else FlatView(tree)
     dist.barrier()
-    if local_rank == 0:
+    if local_rank == 0 and shared:
         os.remove(path)
     return flat
 
