@@ -25,7 +25,6 @@ struct PlaceTunables {
     uint32_t ww_block_max_small = 0xFFFFFFFFu, ww_block_max_big = 0xFFFFFFFFu;
     bool sort_reads = true;              // WEPP_SORT_READS=0: keep the caller's order on the whole-tree stream
     bool walk_sort = true;               // WEPP_WALK_SORT=0: keep the caller's order in the chunked walk classes
-    bool walk_sort_plain = false;        // WEPP_WALK_SORT_PLAIN=1: sort the plain walk classes too
     // sweeps
     bool win_eager = true;               // WEPP_WIN_EAGER=0: window streams prune with the block minimum
     uint32_t target_waves = 4096;        // WEPP_TARGET_WAVES
@@ -60,7 +59,6 @@ struct PlaceTunables {
         t.ww_block_max_big = (uint32_t)env::u64("WEPP_WW_BLOCK_MAX_BIG", 0xFFFFFFFFu, 0, 0xFFFFFFFFu);
         t.sort_reads = env::flag("WEPP_SORT_READS", true);
         t.walk_sort = t.sort_reads && env::flag("WEPP_WALK_SORT", true);
-        t.walk_sort_plain = env::is_set("WEPP_WALK_SORT_PLAIN") && env::flag("WEPP_WALK_SORT_PLAIN", false);
         t.win_eager = env::flag("WEPP_WIN_EAGER", true);
         t.target_waves = (uint32_t)env::u64("WEPP_TARGET_WAVES", 4096, 1, 1u << 24);
         t.target_waves_dense = (uint32_t)env::u64("WEPP_TARGET_WAVES_DENSE", 16384, 1, 1u << 24);
