@@ -502,7 +502,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         if (L.ws) {
             HIP_TRY(hipStreamSynchronize(stream));
             HIP_TRY(hipStreamSynchronize(L.side[MAX_STREAMS - 1]));
-            for (uint32_t i : {MAX_STREAMS - 6, MAX_STREAMS - 7, MAX_STREAMS - 3}) HIP_TRY(hipStreamSynchronize(L.side[i]));
+            for (uint32_t i : {MAX_STREAMS - 6, MAX_STREAMS - 7, MAX_STREAMS - 3, MAX_STREAMS - 2}) HIP_TRY(hipStreamSynchronize(L.side[i]));
             (void)hipFree(L.ws);
             L.ws = nullptr;
             L.ws_bytes = 0;
@@ -646,8 +646,13 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
                 HIP_TRY(hipStreamWaitEvent(q, L.route_ev, 0));
                 HIP_TRY(launch_walk_wave(mat->dev, wwlist, tier_info + TI_WWCUR, n_reads, d_read_off, d_read_word, root_score, d_best_bfs_j, d_score, d_num_best,
                                          d_flags, mat->d_work, wsid, q));
-                HIP_TRY(blind_class(PLAN_WALKC8, q, false));
                 HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 1], q));
+                // (the job class on a stream of its own: nearly always two launches that find nothing, ~10 us that
+                // used to sit behind the wave kernel on the call's longest chain)
+                hipStream_t q2 = L.side[MAX_STREAMS - 2];
+                HIP_TRY(hipStreamWaitEvent(q2, L.route_ev, 0));
+                HIP_TRY(blind_class(PLAN_WALKC8, q2, false));
+                HIP_TRY(hipEventRecord(L.join_ev[MAX_STREAMS - 2], q2));
             }
             if (tun.blind16) {
                 // ... and the plain walks of 9 - 16 entries on a stream of their own: launched once the counters have
@@ -1106,6 +1111,7 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         HIP_TRY(hipEventRecord(L.join_ev[PLAN_STREAM], ps));
         HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[PLAN_STREAM], 0));
         HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[MAX_STREAMS - 1], 0));
+        HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[MAX_STREAMS - 2], 0));
         if (late16[0]) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[BLIND16_STREAM], 0));
         if (late16[1]) HIP_TRY(hipStreamWaitEvent(stream, L.join_ev[MAX_STREAMS - 3], 0));
     }

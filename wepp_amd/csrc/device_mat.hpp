@@ -152,7 +152,9 @@ constexpr uint32_t WALK_XCDS = 8;          // XCDs of an MI355X: workgroup b of 
 constexpr uint32_t WALK_PLAN_ALIGN = WALK_XCDS * WALK_WAVES;
 __host__ __device__ inline uint32_t walk_plan_waves(uint32_t n_lanes) { return ((n_lanes + 63) / 64 + WALK_PLAN_ALIGN - 1) / WALK_PLAN_ALIGN * WALK_PLAN_ALIGN; }
 constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would skip the sparse pre-test of a range query (measured slower at every size: off)
-constexpr uint32_t WALK_MAX_EVENTS = 16;   // reads with more events at their positions (in their stream) walk as several jobs (8 / 16 / 32 / 48 measured: 0.34-0.38 ms per default step)
+constexpr uint32_t WALK_MAX_EVENTS = 6;    // reads with more events at their positions (in their stream) do not walk lane-per-read: a wave per 64 events
+                                           // (k_walk_wave) or jobs.  The LONGEST walk of a launch is the launch's time -- an event is two or three dependent
+                                           // loop iterations of ~1.5 us, whatever the batch: 16 events 56 - 65 us for 125 K as for 1 M reads, 6 events 37 us
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
 constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
 // an open interval on a walk's stack is one dword: (subtree end << WALK_DELTA_BITS) | (delta + WALK_DELTA_BIAS).  The

@@ -272,7 +272,8 @@ __global__ __launch_bounds__(64 * WW_WAVES) void k_walk_wave(DevMAT m, const uin
         }
         __syncthreads();
     }
-    for (uint32_t it = blockIdx.x * WW_WAVES + wv; it < n_small; it += gridDim.x * WW_WAVES) {
+    // (the small reads are dealt from the END of the grid: the first workgroups hold the large ones)
+    for (uint32_t it = gridDim.x * WW_WAVES - 1u - (blockIdx.x * WW_WAVES + wv); it < n_small; it += gridDim.x * WW_WAVES) {
         const uint32_t rd = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[it]);
         const WcInfo wi = m.wc_info[wsid[rd]];
         const ReadLists L = read_lists(m, ix, wi, lane, rd, read_off, read_word);
