@@ -615,6 +615,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         return e;
     };
     const bool ww_jobs = mat->ww_by_jobs.load(std::memory_order_relaxed) != 0;     // (the reads with 17 - 256 events: a wave each, or jobs -- by the handle's previous call)
+    // (... and then reads of up to 16 events walk plainly, as before the waves: 100 000 reads with 7 - 16 events are
+    // nothing to a walk launch -- its time is its longest walk -- and 0.3 ms as jobs)
+    const uint32_t walk_limit = (ww_jobs && !tun.ww_fixed) ? std::max(walk_max_events, WALK_MAX_EVENTS_BY_JOBS) : walk_max_events;
     auto route = [&]() -> int {
         // the counters alternate between two sets: this call's set is zero (cleared at creation or by the
         // previous k_route), and this k_route clears the other one for the next call
@@ -625,9 +628,9 @@ int place_device(wepp_mat_t* mat, const uint32_t* d_read_off, const uint32_t* d_
         // counters' trip to the host, the planning of the rarer classes and k_scatter are off their path
         RouteDirect direct{};
         if (walking) direct = RouteDirect{{wlist[0], wlist[1]}, {b_clist[0], b_clist[1]}, {b_jobs[0], b_jobs[1]}, b_first, wwlist,
-                                          d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work,
+                                          d_best_bfs_j, d_score, d_num_best, d_flags, mat->d_work, walk_max_events,
                                           tun.ww_fixed ? tun.ww_block_max_small : ww_jobs ? 0u : 0xFFFFFFFFu, tun.ww_fixed ? tun.ww_block_max_big : ww_jobs ? 0u : 0xFFFFFFFFu};
-        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, walking ? walk_max_events : 0u, job_events, stack8, stack16, seed_min_hard, tun.seed_min_nodes, job_n, tier_of, root_score, blk_counts,
+        HIP_TRY(launch_route(mat->dev, d_read_off, d_read_word, n_reads, mat->use_crowns, walking ? walk_limit : 0u, job_events, stack8, stack16, seed_min_hard, tun.seed_min_nodes, job_n, tier_of, root_score, blk_counts,
                              tier_info, slot_in_blk, tier_info_next, wsid, direct, stream));
         L.info_idx ^= 1u;
         HIP_TRY(hipEventRecord(mat->ev0[ev_slot], stream));        // (the timed span of a call: everything behind the routing kernel)

@@ -155,6 +155,7 @@ constexpr uint32_t WALK_EAGER_MAX_NODES = 0;   // streams up to this size would 
 constexpr uint32_t WALK_MAX_EVENTS = 6;    // reads with more events at their positions (in their stream) do not walk lane-per-read: a wave per 64 events
                                            // (k_walk_wave) or jobs.  The LONGEST walk of a launch is the launch's time -- an event is two or three dependent
                                            // loop iterations of ~1.5 us, whatever the batch: 16 events 56 - 65 us for 125 K as for 1 M reads, 6 events 37 us
+constexpr uint32_t WALK_MAX_EVENTS_BY_JOBS = 16;   // ... while the handle cuts the reads beyond into jobs (a batch full of them: capi.cpp)
 constexpr uint32_t WALK_COUNTERS = 1024;   // slots of the walks' iteration counter (summed by the host)
 constexpr uint32_t WALK8_K = 8, WALK8_STACK = 16, WALK16_K = 16, WALK16_STACK = 32;
 // an open interval on a walk's stack is one dword: (subtree end << WALK_DELTA_BITS) | (delta + WALK_DELTA_BIAS).  The
@@ -273,6 +274,7 @@ struct RouteDirect {
     uint32_t* num_best;
     uint32_t* flags;
     unsigned long long* work_counter;
+    uint32_t cand_min;           // events above which a read counts as a candidate for k_walk_wave (the handle's walk limit while it uses the waves)
     uint32_t ww_max_small, ww_max_big;   // reads per routing block and round listed for k_walk_wave (<= 64 events / more): all or none (capi.cpp), WEPP_WW_BLOCK_MAX_*
 };
 hipError_t launch_route(const DevMAT& m, const uint32_t* d_read_off, const uint32_t* d_read_word, uint32_t n_reads,

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void k_route(DevMAT m, const uint32_
             }
             if (cls == PLAN_SWEEP) cls = classify(m.tw_base + t, nj, open_max, events);
             if (cls == PLAN_WALK8 || cls == PLAN_WALK16) {
+                // (a handle that cuts such reads into jobs lets up to 16 events walk plainly: they stay counted as what a
+                // wave each would have to take, or the host's choice for the next call would swing back and forth)
+                if (events > direct.cand_min) atomicAdd(&ww_cand[events > 64u ? 1 : 0], 1u);
                 // the deepest stack a walk of the class can need in this call: its kernel's LDS request
                 if (open_max > open_of[cls]) atomicMax(&open_of[cls], open_max);
                 // every stream is a slice of the walk arena: the read walks the slice wsid names (a window crown's, set
